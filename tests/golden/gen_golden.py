@@ -1,0 +1,267 @@
+"""
+Golden-vector generator: runs the REAL reference (read-only at /root/reference, imported through the shims in
+``ref_stubs.py``) on small seeded inputs and stores inputs/outputs as ``.npz`` fixtures next to this script.
+
+Run in the development container only (the reference never travels to the GPU box):
+
+    python tests/golden/gen_golden.py            # all fixtures
+    python tests/golden/gen_golden.py interp     # one group
+
+Fixture groups:
+    interp_*      export.interpolate_data                        (reference export.py:446-468)
+    knncache_*    ExportData._build_knn_cache idx / weights      (reference export.py:403-444)
+    predict_*     KNeighborsRegressor(weights="distance").predict as used at s_cube.py:161-163,224,328,372
+    masks         geometry check_cell truth tables                (geometry/*.py)
+    uniform_*     _refine_uniform() neighbour + node tables       (s_cube.py:508-561, 904-1536)
+    refine_*      full SamplingTree.refine() outputs + traces     (s_cube.py:563-667)
+
+The script must stay a real file with a ``__main__`` guard: the reference creates a *spawn* multiprocessing pool
+(s_cube.py:159) whose workers re-import this module and need the shims installed before unpickling.
+"""
+import hashlib
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_stubs  # noqa: E402,F401  (installs shims + sys.path; must run in spawned workers too)
+
+import numpy as np  # noqa: E402
+import torch as pt  # noqa: E402
+
+
+def sha(*arrays):
+    h = hashlib.sha256()
+    for a in arrays:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+def save(name, **kw):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **kw)
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# shared synthetic input builders (tests re-create the same inputs from the seed and verify the stored hash)
+# ----------------------------------------------------------------------------------------------------------------
+def cloud(seed, n, lo, hi):
+    rng = np.random.default_rng(seed)
+    lo, hi = np.asarray(lo, dtype=np.float64), np.asarray(hi, dtype=np.float64)
+    return lo + rng.random((n, len(lo))) * (hi - lo)
+
+
+def wake_metric(xyz, centre, decay=6.0):
+    """Smooth, strictly positive synthetic 'std-of-pressure' style metric peaking behind ``centre``."""
+    d = xyz[:, :2] - np.asarray(centre)[None, :2]
+    r = np.sqrt((d ** 2).sum(1))
+    wake = np.exp(-((d[:, 1]) / 0.08) ** 2) * np.where(d[:, 0] > 0, np.exp(-d[:, 0]), 0.0)
+    m = 0.05 + np.exp(-decay * r) + 0.8 * wake * (1 + 0.3 * np.sin(9.0 * d[:, 0]))
+    if xyz.shape[1] == 3:
+        m = m * (1.0 + 0.2 * np.cos(5.0 * xyz[:, 2]))
+    return m
+
+
+# ----------------------------------------------------------------------------------------------------------------
+def gen_interp():
+    from sparseSpatialSampling.export import interpolate_data
+    for tag, (n, nc, k, ncomp, t, dtype) in {
+        "interp_k8_c1_f32": (800, 300, 8, 1, 7, np.float32),
+        "interp_k8_c3_f64": (800, 300, 8, 3, 7, np.float64),
+        "interp_k26_c1_f32": (800, 300, 26, 1, 7, np.float32),
+        "interp_k26_c3_f32": (800, 300, 26, 3, 5, np.float32),
+        "interp_k26_c1_f64": (800, 300, 26, 1, 33, np.float64),
+    }.items():
+        rng = np.random.default_rng(abs(hash(tag)) % 2 ** 31 if False else sum(map(ord, tag)))
+        w = rng.random((nc, k))
+        w /= w.sum(1, keepdims=True)
+        idx = rng.integers(0, n, (nc, k), dtype=np.int64)
+        data = rng.standard_normal((n, ncomp, t)).astype(dtype)
+        out = interpolate_data(pt.from_numpy(w), pt.from_numpy(idx), pt.from_numpy(data), chunk_size=128)
+        save(tag, w=w, idx=idx, data=data, out=out.numpy())
+
+
+def gen_knncache():
+    from sklearn.neighbors import NearestNeighbors
+    from sparseSpatialSampling.export import ExportData
+
+    class _FakeSCube:  # the attributes ExportData.__init__ reads (export.py:74-83)
+        def __init__(self, centers, vertices):
+            self.n_dimensions = centers.shape[1]
+            self.faces = None
+            self.centers = pt.from_numpy(centers)
+            self.vertices = pt.from_numpy(vertices)
+            self.levels = None
+            self.metric = None
+            self.size_initial_cell = 1.0
+            self.save_path, self.save_name, self.grid_name = "/tmp", "x", "g"
+
+    for tag, (d, n, nc, nv) in {"knncache_2d": (2, 3000, 400, 120), "knncache_3d": (3, 4000, 300, 90)}.items():
+        coords = cloud(11 + d, n, [0.0] * d, [1.0, 0.7, 0.4][:d])
+        centers = cloud(21 + d, nc, [0.0] * d, [1.0, 0.7, 0.4][:d])
+        vertices = cloud(31 + d, nv, [-0.1] * d, [1.1, 0.8, 0.5][:d])     # some queries outside the cloud
+        centers[5] = coords[17]                                            # exact hit -> clamp(1e-12) path
+        centers[6] = coords[n - 1]
+        ex = ExportData(_FakeSCube(centers, vertices), write_times=["0"], interpolate_at_vertices=True, n_jobs=1)
+        ex._build_knn_cache(pt.from_numpy(coords))
+        nn = NearestNeighbors(n_neighbors=8 if d == 2 else 26).fit(coords)
+        dist_c, _ = nn.kneighbors(centers)
+        save(tag, coords=coords, centers=centers, vertices=vertices,
+             idx_c=ex._knn_idx_centers.numpy(), w_c=ex._knn_w_centers.numpy(), dist_c=dist_c,
+             idx_v=ex._knn_idx_vertices.numpy(), w_v=ex._knn_w_vertices.numpy())
+
+
+def gen_predict():
+    from sklearn.neighbors import KNeighborsRegressor
+    for tag, (d, n, nq, k) in {"predict_2d": (2, 2500, 500, 8), "predict_3d": (3, 3000, 500, 26)}.items():
+        x = cloud(41 + d, n, [0.0] * d, [2.2, 0.41, 0.3][:d])
+        y = wake_metric(x, [0.2, 0.2, 0.0][:d])
+        q = cloud(51 + d, nq, [-0.05] * d, [2.25, 0.45, 0.35][:d])
+        q[3] = x[10]                                                       # exact hit: indicator weights
+        q[4] = x[11]
+        knn = KNeighborsRegressor(n_neighbors=k, weights="distance", n_jobs=1).fit(x, y)
+        save(tag, x=x, y=y, q=q, pred=knn.predict(q))
+
+
+def gen_masks():
+    from sparseSpatialSampling.geometry import CubeGeometry, SphereGeometry, CylinderGeometry3D, \
+        GeometryCoordinates2D
+    out = {}
+    rng = np.random.default_rng(7)
+
+    def cells(d, n):
+        c = rng.random((n, d)) * 2.0 - 0.5
+        h = rng.random(n) * 0.4 + 0.01
+        dirs = np.array([[-1, -1], [-1, 1], [1, 1], [1, -1]] if d == 2 else
+                        [[-1, -1, 1], [-1, 1, 1], [1, 1, 1], [1, -1, 1],
+                         [-1, -1, -1], [-1, 1, -1], [1, 1, -1], [1, -1, -1]], dtype=np.float64)
+        return c[:, None, :] + dirs[None] * h[:, None, None]              # [n, 2^d, d]
+
+    c2, c3 = cells(2, 400), cells(3, 400)
+    out["cells2"], out["cells3"] = c2, c3
+    poly = [(0.1, 0.1), (0.9, 0.2), (1.2, 0.8), (0.6, 0.5), (0.2, 1.0)]   # concave pentagon
+    out["poly"] = np.asarray(poly)
+    geos = {}
+    for ki in (True, False):
+        geos[f"cube2_{int(ki)}"] = (CubeGeometry("g", ki, [0.0, 0.1], [1.0, 0.9]), c2)
+        geos[f"cube3_{int(ki)}"] = (CubeGeometry("g", ki, [0.0, 0.1, -0.2], [1.0, 0.9, 0.7]), c3)
+        geos[f"sphere2_{int(ki)}"] = (SphereGeometry("g", ki, [0.4, 0.5], 0.45), c2)
+        geos[f"sphere3_{int(ki)}"] = (SphereGeometry("g", ki, [0.4, 0.5, 0.3], 0.6), c3)
+        geos[f"cyl3_{int(ki)}"] = (CylinderGeometry3D("g", ki, [(0.2, 0.3, -0.1), (0.9, 0.6, 0.8)], 0.35), c3)
+        geos[f"cone3_{int(ki)}"] = (CylinderGeometry3D("g", ki, [(0.8, 1.0, -1.0), (0.8, 1.0, 1.0)], [0.5, 0.1]), c3)
+        geos[f"poly2_{int(ki)}"] = (GeometryCoordinates2D("g", ki, poly), c2)
+    for key, (g, c) in geos.items():
+        for rm in (False, True):
+            out[f"{key}_r{int(rm)}"] = np.array([g.check_cell(pt.from_numpy(c[i]), rm) for i in range(len(c))])
+    save("masks", **out)
+
+
+def _tree_arrays(tree):
+    """Dump the per-cell state of a reference SamplingTree into arrays (None -> -1)."""
+    cells = tree._cells
+    nd = tree.n_dimensions
+    nb = np.array([[(-1 if n is None else n.index) for n in c.nb] for c in cells], dtype=np.int32)
+    node_idx = np.array([c.node_idx for c in cells], dtype=np.int64)
+    level = np.array([c.level for c in cells], dtype=np.int32)
+    state = np.array([0 if c.children is None else (2 if len(c.children) == 0 else 1) for c in cells], dtype=np.int8)
+    parent = np.array([-1 if c.parent is None else c.parent.index for c in cells], dtype=np.int32)
+    center = np.stack([np.asarray(c.center, dtype=np.float64).reshape(nd) for c in cells])
+    gain = np.array([float(c.gain) for c in cells], dtype=np.float64)
+    metric = np.array([float(c.metric) for c in cells], dtype=np.float64)
+    return dict(nb=nb, node_idx=node_idx, level=level, state=state, parent=parent, center=center, gain=gain,
+                metric=metric, leaf_order=np.array(list(tree._leaf_cells), dtype=np.int64))
+
+
+def gen_uniform():
+    from sparseSpatialSampling.geometry import CubeGeometry
+    from sparseSpatialSampling.s_cube import SamplingTree
+    for d in (2, 3):
+        x = cloud(61 + d, 500, [0.0] * d, [10.0] * d)
+        y = wake_metric(x / 10.0, [0.3, 0.4, 0.0][:d])
+        tree = SamplingTree(pt.from_numpy(x), pt.from_numpy(y), uniform_level=3,
+                            geometry_obj=[CubeGeometry("domain", True, [0] * d, [10] * d)])
+        tree._refine_uniform()
+        tree._pool.close()
+        arr = _tree_arrays(tree)
+        save(f"uniform_{d}d", x=x, y=y, all_nodes=pt.stack(tree.all_nodes).numpy(), **arr)
+
+
+REFINE_CASES = {
+    # 2-D cylinder-like: cube domain + refined sphere body, metric stopping
+    "refine_2d_metric": dict(d=2, seed=71, n=6000, lo=[0.0, 0.0], hi=[2.2, 0.41], body="sphere",
+                             kw=dict(uniform_level=4, min_metric=0.6)),
+    # 2-D, n_cells_max stopping + n_cells_iter ramp
+    "refine_2d_ncells": dict(d=2, seed=72, n=5000, lo=[0.0, 0.0], hi=[2.2, 0.41], body="sphere_norefine",
+                             kw=dict(uniform_level=3, n_cells=900, n_cells_iter_start=12, n_cells_iter_end=4)),
+    # 2-D with 2:1 balance (max_delta_level=True) -> host-only neighbour walks (a14)
+    "refine_2d_delta": dict(d=2, seed=73, n=4000, lo=[0.0, 0.0], hi=[2.2, 0.41], body="sphere",
+                            kw=dict(uniform_level=3, min_metric=0.5, max_delta_level=True)),
+    # 3-D: cube + cylinder body (refined), metric stopping
+    "refine_3d_metric": dict(d=3, seed=74, n=20000, lo=[0.0, 0.0, 0.0], hi=[2.4, 2.0, 0.3], body="cylinder",
+                             kw=dict(uniform_level=3, min_metric=0.45)),
+}
+
+
+def refine_inputs(case):
+    from sparseSpatialSampling.geometry import CubeGeometry, SphereGeometry, CylinderGeometry3D
+    d = case["d"]
+    x = cloud(case["seed"], case["n"], case["lo"], case["hi"])
+    if d == 2:
+        centre, rad = [0.2, 0.2], 0.05
+        keep = ((x - np.asarray(centre)) ** 2).sum(1) > rad ** 2
+        x = x[keep]
+        if case["body"] == "sphere":
+            body = SphereGeometry("cylinder", False, centre, rad, refine=True, min_refinement_level=6)
+        else:
+            body = SphereGeometry("cylinder", False, centre, rad)
+        y = wake_metric(x, centre)
+    else:
+        centre, rad = [0.8, 1.0, 0.0], 0.15
+        keep = ((x[:, :2] - np.asarray(centre[:2])) ** 2).sum(1) > rad ** 2
+        x = x[keep]
+        body = CylinderGeometry3D("cylinder", False, [(0.8, 1.0, -1.0), (0.8, 1.0, 1.0)], rad, refine=True)
+        y = wake_metric(x, centre, decay=2.5)
+    geos = [CubeGeometry("domain", True, case["lo"], case["hi"]), body]
+    return x, y, geos
+
+
+def gen_refine(only=None):
+    from sparseSpatialSampling.s_cube import SamplingTree
+    for tag, case in REFINE_CASES.items():
+        if only and tag not in only:
+            continue
+        x, y, geos = refine_inputs(case)
+        trace = []
+        orig = SamplingTree._refine_cells
+
+        def _traced(self, to_refine, _orig=orig, _trace=trace):
+            _trace.append(np.array(list(to_refine), dtype=np.int64))
+            return _orig(self, to_refine)
+
+        SamplingTree._refine_cells = _traced
+        try:
+            tree = SamplingTree(pt.from_numpy(x), pt.from_numpy(y), geometry_obj=geos, n_jobs=2, **case["kw"])
+            tree.refine()
+        finally:
+            SamplingTree._refine_cells = orig
+        arr = _tree_arrays(tree)
+        info = tree.data_final_mesh
+        save(tag, input_sha=np.array(sha(x, y)), n_points=np.array(len(x)),
+             all_centers=tree.all_centers.numpy(), all_levels=tree.all_levels.numpy(),
+             face_ids=tree.face_ids.numpy(), all_nodes=tree.all_nodes.numpy(),
+             metric_hist=np.array(tree._metric), n_cells_log=np.array(tree._n_cells_log),
+             trace_len=np.array([len(t) for t in trace]), trace=np.concatenate(trace) if trace else np.zeros(0),
+             width=np.array(float(tree._width)), gain0=np.array(float(tree._cells[0].gain)),
+             iterations=np.array(info["iterations"]), min_level=np.array(info["min_level"]),
+             max_level=np.array(info["max_level"]), **arr)
+
+
+if __name__ == "__main__":
+    groups = sys.argv[1:] or ["interp", "knncache", "predict", "masks", "uniform", "refine"]
+    pt.manual_seed(0)
+    for g in groups:
+        if g.startswith("refine_"):
+            gen_refine(only=[g])
+        else:
+            globals()["gen_" + g]()

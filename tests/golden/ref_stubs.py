@@ -1,0 +1,136 @@
+"""
+Import shims that let the *real* reference package (read-only at /root/reference) be imported in the
+development container, where several of its third-party dependencies are not installed.
+
+This file contains NO reference code.  It only pre-seeds ``sys.modules`` with small stand-ins for
+packages the reference imports at module level:
+
+* ``numba``      -> ``njit`` is an identity decorator, ``prange`` is ``range``
+* ``flowtorch``  -> ``flowtorch.data.mask_box`` / ``mask_sphere`` with the semantics the reference's own
+                    unit tests pin (inclusive bounds; tests/test_cube_geometry.py:46-78,
+                    tests/test_sphere_geometry.py:43-75), dummy ``FOAMDataloader`` and ``SVD``
+* ``shapely``    -> minimal ``Point`` / ``Polygon`` (strict-interior ``within``; bounds; boundary.is_closed)
+* ``pyvista``, ``pymeshfix``, ``h5py`` -> import-only dummies (never exercised by the golden generator)
+
+It is used ONLY by ``tests/golden/gen_golden.py`` (fixture generation in the dev container).  Nothing in the
+product, the GPU tests, ``smoke()`` or ``bench.py`` imports it, and /root/reference never travels to the GPU box.
+"""
+import sys
+import types
+
+import numpy as np
+import torch as pt
+
+REFERENCE_ROOT = "/root/reference"
+
+
+def _njit(*args, **kwargs):
+    if len(args) == 1 and callable(args[0]) and not kwargs:
+        return args[0]
+
+    def deco(fn):
+        return fn
+
+    return deco
+
+
+def _mask_box(vertices, lower, upper):
+    mask = pt.ones(vertices.shape[0], dtype=pt.bool)
+    for i in range(len(lower)):
+        mask &= (vertices[:, i] >= lower[i]) & (vertices[:, i] <= upper[i])
+    return mask
+
+
+def _mask_sphere(vertices, center, radius):
+    c = pt.as_tensor(center, dtype=vertices.dtype)
+    return (vertices - c).norm(dim=1) <= radius
+
+
+class _Boundary:
+    is_closed = True
+
+
+class _Polygon:
+    """Simple polygon; ``contains_strict`` = point strictly inside (boundary excluded) by crossing number."""
+
+    def __init__(self, coordinates):
+        xy = np.asarray(coordinates, dtype=np.float64)
+        if np.all(xy[0] == xy[-1]):
+            xy = xy[:-1]
+        self.xy = xy
+        self.bounds = (xy[:, 0].min(), xy[:, 1].min(), xy[:, 0].max(), xy[:, 1].max())
+        self.boundary = _Boundary()
+
+    def contains_strict(self, px, py):
+        x, y = self.xy[:, 0], self.xy[:, 1]
+        n = len(x)
+        inside = False
+        for i in range(n):
+            j = (i + 1) % n
+            xi, yi, xj, yj = x[i], y[i], x[j], y[j]
+            # on-edge -> not strictly inside
+            cross = (xj - xi) * (py - yi) - (yj - yi) * (px - xi)
+            if cross == 0 and min(xi, xj) <= px <= max(xi, xj) and min(yi, yj) <= py <= max(yi, yj):
+                return False
+            if (yi > py) != (yj > py):
+                xint = xi + (py - yi) * (xj - xi) / (yj - yi)
+                if px < xint:
+                    inside = not inside
+        return inside
+
+
+class _Point:
+    def __init__(self, xy):
+        self.x, self.y = float(xy[0]), float(xy[1])
+
+    def within(self, poly):
+        return poly.contains_strict(self.x, self.y)
+
+
+def install():
+    """Seed ``sys.modules`` and put the reference on ``sys.path``.  Idempotent."""
+    if "numba" not in sys.modules:
+        numba = types.ModuleType("numba")
+        numba.njit = _njit
+        numba.prange = range
+        sys.modules["numba"] = numba
+
+    if "flowtorch" not in sys.modules:
+        ft = types.ModuleType("flowtorch")
+        ft_data = types.ModuleType("flowtorch.data")
+        ft_data.mask_box = _mask_box
+        ft_data.mask_sphere = _mask_sphere
+        ft_data.FOAMDataloader = type("FOAMDataloader", (), {})
+        ft_an = types.ModuleType("flowtorch.analysis")
+        ft_an.SVD = type("SVD", (), {})
+        ft.data, ft.analysis = ft_data, ft_an
+        sys.modules.update({"flowtorch": ft, "flowtorch.data": ft_data, "flowtorch.analysis": ft_an})
+
+    if "shapely" not in sys.modules:
+        sh = types.ModuleType("shapely")
+        sh.Point, sh.Polygon = _Point, _Polygon
+        sys.modules["shapely"] = sh
+
+    if "pyvista" not in sys.modules:
+        pv = types.ModuleType("pyvista")
+        pv.PolyData = type("PolyData", (), {})
+        pv.read = lambda *a, **k: None
+        sys.modules["pyvista"] = pv
+
+    if "pymeshfix" not in sys.modules:
+        pm = types.ModuleType("pymeshfix")
+        pm.MeshFix = type("MeshFix", (), {})
+        sys.modules["pymeshfix"] = pm
+
+    try:
+        import h5py  # noqa: F401
+    except ModuleNotFoundError:
+        h5 = types.ModuleType("h5py")
+        h5.File = type("File", (), {})
+        sys.modules["h5py"] = h5
+
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, REFERENCE_ROOT)
+
+
+install()

@@ -1,0 +1,78 @@
+"""
+Seeded synthetic inputs shared by the golden generator (which feeds them to the REAL reference) and by the tests
+(which feed them to the oracle / the HIP path).  Pure numpy; no reference code, no product code.
+"""
+import hashlib
+
+import numpy as np
+
+
+def sha(*arrays):
+    h = hashlib.sha256()
+    for a in arrays:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+def cloud(seed, n, lo, hi):
+    rng = np.random.default_rng(seed)
+    lo, hi = np.asarray(lo, dtype=np.float64), np.asarray(hi, dtype=np.float64)
+    return lo + rng.random((n, len(lo))) * (hi - lo)
+
+
+def wake_metric(xyz, centre, decay=6.0):
+    """Smooth, strictly positive synthetic 'std-of-pressure' style metric peaking behind ``centre``."""
+    d = xyz[:, :2] - np.asarray(centre)[None, :2]
+    r = np.sqrt((d ** 2).sum(1))
+    wake = np.exp(-((d[:, 1]) / 0.08) ** 2) * np.where(d[:, 0] > 0, np.exp(-d[:, 0]), 0.0)
+    m = 0.05 + np.exp(-decay * r) + 0.8 * wake * (1 + 0.3 * np.sin(9.0 * d[:, 0]))
+    if xyz.shape[1] == 3:
+        m = m * (1.0 + 0.2 * np.cos(5.0 * xyz[:, 2]))
+    return m
+
+
+REFINE_CASES = {
+    # 2-D cylinder-like: cube domain + refined sphere body, metric stopping
+    "refine_2d_metric": dict(d=2, seed=71, n=6000, lo=[0.0, 0.0], hi=[2.2, 0.41], body="sphere",
+                             kw=dict(uniform_level=4, min_metric=0.6)),
+    # 2-D, n_cells_max stopping + n_cells_iter ramp arguments
+    "refine_2d_ncells": dict(d=2, seed=72, n=5000, lo=[0.0, 0.0], hi=[2.2, 0.41], body="sphere_norefine",
+                             kw=dict(uniform_level=3, n_cells=900, n_cells_iter_start=12, n_cells_iter_end=4)),
+    # 2-D with 2:1 balance (max_delta_level=True) -> host-only neighbour walks
+    "refine_2d_delta": dict(d=2, seed=73, n=4000, lo=[0.0, 0.0], hi=[2.2, 0.41], body="sphere",
+                            kw=dict(uniform_level=3, min_metric=0.5, max_delta_level=True)),
+    # 3-D: cube + cylinder body (refined), metric stopping
+    "refine_3d_metric": dict(d=3, seed=74, n=20000, lo=[0.0, 0.0, 0.0], hi=[2.4, 2.0, 0.3], body="cylinder",
+                             kw=dict(uniform_level=3, min_metric=0.45)),
+}
+
+
+def refine_inputs(name, geometry):
+    """``geometry`` = module exposing CubeGeometry / SphereGeometry / CylinderGeometry3D (reference or product)."""
+    case = REFINE_CASES[name]
+    d = case["d"]
+    x = cloud(case["seed"], case["n"], case["lo"], case["hi"])
+    if d == 2:
+        centre, rad = [0.2, 0.2], 0.05
+        keep = ((x - np.asarray(centre)) ** 2).sum(1) > rad ** 2
+        x = np.ascontiguousarray(x[keep])
+        if case["body"] == "sphere":
+            body = geometry.SphereGeometry("cylinder", False, centre, rad, refine=True, min_refinement_level=6)
+        else:
+            body = geometry.SphereGeometry("cylinder", False, centre, rad)
+        y = wake_metric(x, centre)
+    else:
+        centre, rad = [0.8, 1.0, 0.0], 0.15
+        keep = ((x[:, :2] - np.asarray(centre[:2])) ** 2).sum(1) > rad ** 2
+        x = np.ascontiguousarray(x[keep])
+        body = geometry.CylinderGeometry3D("cylinder", False, [(0.8, 1.0, -1.0), (0.8, 1.0, 1.0)], rad, refine=True)
+        y = wake_metric(x, centre, decay=2.5)
+    geos = [geometry.CubeGeometry("domain", True, case["lo"], case["hi"]), body]
+    return x, y, geos, case["kw"]
+
+
+def mask_cells(d, n, rng):
+    """Cell stream of the ``masks`` fixture: centre + half-width per cell."""
+    c = rng.random((n, d)) * 2.0 - 0.5
+    h = rng.random(n) * 0.4 + 0.01
+    return c, h

@@ -1,0 +1,139 @@
+"""
+Pins the CPU oracle (oracle/s3_oracle.c) against golden vectors produced by the REAL reference
+(tests/golden/gen_golden.py).  CPU only.
+"""
+import ctypes
+import os
+import types
+
+import numpy as np
+import pytest
+
+from oracle import s3_oracle as orc
+from inputs import mask_cells, refine_inputs, sha
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+# geometry "module" that just records constructor arguments (the oracle tests need inputs, not predicates)
+SPEC = types.SimpleNamespace(
+    CubeGeometry=lambda *a, **k: ("cube", a, k),
+    SphereGeometry=lambda *a, **k: ("sphere", a, k),
+    CylinderGeometry3D=lambda *a, **k: ("cylinder", a, k),
+)
+
+
+def load(name):
+    return np.load(os.path.join(G, name + ".npz"))
+
+
+@pytest.mark.parametrize("name", ["interp_k8_c1_f32", "interp_k8_c3_f64", "interp_k26_c1_f32", "interp_k26_c3_f32",
+                                  "interp_k26_c1_f64"])
+def test_interp(name):
+    z = load(name)
+    out = orc.interp(z["w"], z["idx"], z["data"])
+    assert out.shape == z["out"].shape and out.dtype == np.float64
+    scale = np.abs(z["out"]).max()
+    assert np.abs(out - z["out"]).max() <= 1e-14 * scale      # reference export.py:467; contract in BASELINE: 1e-5
+
+
+@pytest.mark.parametrize("name,k", [("knncache_2d", 8), ("knncache_3d", 26)])
+def test_knn_cache(name, k):
+    z = load(name)
+    for q, idx_ref, w_ref in ((z["centers"], z["idx_c"], z["w_c"]), (z["vertices"], z["idx_v"], z["w_v"])):
+        idx, dist = orc.knn(z["coords"], q, k)
+        assert np.array_equal(idx, idx_ref)                     # bit-exact neighbour indices (export.py:425)
+        w = orc.idw_weights(dist)
+        assert np.array_equal(w, w_ref)                         # bit-exact weights incl. clamp rows (export.py:428-429)
+    idx, dist = orc.knn(z["coords"], z["centers"], k)
+    assert np.array_equal(dist, z["dist_c"])
+    assert dist[5, 0] == 0.0 and dist[6, 0] == 0.0              # the exact-hit rows are really exercised
+
+
+@pytest.mark.parametrize("name,k", [("predict_2d", 8), ("predict_3d", 26)])
+def test_predict(name, k):
+    z = load(name)
+    pred = orc.idw_predict(z["x"], z["y"], z["q"], k)
+    assert np.array_equal(pred, z["pred"])                      # bit-exact incl. the indicator-weight rows
+    assert pred[3] == z["y"][10] and pred[4] == z["y"][11]
+
+
+def test_masks():
+    z = load("masks")
+    rng = np.random.default_rng(7)
+    c2, h2 = mask_cells(2, 400, rng)
+    c3, h3 = mask_cells(3, 400, rng)
+    assert np.array_equal(c2[:, None, :] + orc.DIRS[2][None] * h2[:, None, None], z["cells2"])
+    assert np.array_equal(c3[:, None, :] + orc.DIRS[3][None] * h3[:, None, None], z["cells3"])
+
+    # the oracle API is (centre, level, width) with node offset (0.5*width)/2^level; level 0 and width = 2h give
+    # offset == h exactly, so the nodes are bit-identical to the fixture's
+    def run(fn, c, h, *args):
+        out = np.zeros(len(c), dtype=bool)
+        lv = np.zeros(1, dtype=np.int32)
+        for i in range(len(c)):
+            out[i] = fn(c[i:i + 1], lv, 2.0 * h[i], *args)[0]
+        return out
+
+    for ki in (True, False):
+        for rm in (False, True):
+            sfx = f"_{int(ki)}_r{int(rm)}"
+            assert np.array_equal(run(orc.mask_box, c2, h2, [0.0, 0.1], [1.0, 0.9], rm, ki), z["cube2" + sfx])
+            assert np.array_equal(run(orc.mask_box, c3, h3, [0.0, 0.1, -0.2], [1.0, 0.9, 0.7], rm, ki),
+                                  z["cube3" + sfx])
+            assert np.array_equal(run(orc.mask_sphere, c2, h2, [0.4, 0.5], 0.45, rm, ki), z["sphere2" + sfx])
+            assert np.array_equal(run(orc.mask_sphere, c3, h3, [0.4, 0.5, 0.3], 0.6, rm, ki), z["sphere3" + sfx])
+            assert np.array_equal(run(orc.mask_cylinder, c3, h3, [(0.2, 0.3, -0.1), (0.9, 0.6, 0.8)], 0.35, rm, ki),
+                                  z["cyl3" + sfx])
+            assert np.array_equal(run(orc.mask_cylinder, c3, h3, [(0.8, 1.0, -1.0), (0.8, 1.0, 1.0)], [0.5, 0.1], rm, ki),
+                                  z["cone3" + sfx])
+            assert np.array_equal(run(orc.mask_polygon, c2, h2, z["poly"], rm, ki), z["poly2" + sfx])
+    assert 0 < z["cyl3_0_r0"].sum() < 400 and 0 < z["poly2_1_r1"].sum() < 400     # non-trivial truth tables
+
+
+@pytest.mark.parametrize("name,k", [("refine_2d_metric", 8), ("refine_2d_delta", 8), ("refine_3d_metric", 26)])
+def test_child_gain_trace(name, k):
+    """metric + gain of every cell the reference created (s_cube.py:207-241,1859) -- bit exact."""
+    z = load(name)
+    x, y, _, _ = refine_inputs(name, SPEC)
+    assert sha(x, y) == str(z["input_sha"])
+    width, gain0 = float(z["width"]), float(z["gain0"])
+    sel = np.arange(1, len(z["level"]))
+    metric, gain = orc.child_gain(x, y, k, z["center"][sel], z["level"][sel], width, gain0)
+    assert np.array_equal(metric[:, 0], z["metric"][sel])
+    valid = z["state"][sel] != 2                                  # invalid cells get gain = 0 (s_cube.py:723)
+    assert np.array_equal(gain[valid], z["gain"][sel][valid])
+    assert np.all(z["gain"][sel][~valid] == 0)
+
+
+def test_child_centers_recurrence():
+    """centre(child) = centre(parent) + dir * (0.25*width)/2^level(parent)  (s_cube.py:441) -- bit exact."""
+    for name in ("refine_2d_metric", "refine_3d_metric"):
+        z = load(name)
+        d = z["center"].shape[1]
+        width = float(z["width"])
+        par = z["parent"][1:]
+        child_no = (np.arange(1, len(par) + 1) - 1) % (2 ** d)       # children are created consecutively
+        off = (0.25 * width) / (2.0 ** z["level"][par])
+        expect = z["center"][par] + orc.DIRS[d][child_no] * off[:, None]
+        assert np.array_equal(expect, z["center"][1:])
+
+
+def test_topn_matches_heapq():
+    import heapq
+    rng = np.random.default_rng(3)
+    g = np.round(rng.random(500), 2)                              # many exact ties -> exercises the -idx tie rule
+    ids = rng.permutation(5000)[:500]
+    gain_of = dict(zip(ids.tolist(), g.tolist()))
+    ref = heapq.nlargest(37, set(ids.tolist()), key=lambda i: (gain_of[i], -i))      # s_cube.py:601-602
+    assert orc.topn(g, ids, 37).tolist() == ref
+
+
+def test_sum_orders():
+    import torch
+    rng = np.random.default_rng(5)
+    for n in (4, 8, 26):
+        a = rng.random((64, n))
+        t = torch.from_numpy(a).sum(dim=1).numpy()
+        mine = np.array([orc.lib().s3o_torch_inner_sum(np.ascontiguousarray(r).ctypes.data_as(ctypes.c_void_p), n)
+                         for r in a])
+        assert np.array_equal(t, mine)

@@ -1,0 +1,140 @@
+/*
+ * s3hip.h -- C ABI of libs3hip.so: the MI355X (gfx950) implementation of the S^3 hot path.
+ *
+ * The reference (JanisGeise/sparseSpatialSampling) is pure Python and has no FFI; its boundary for this path is the
+ * set of Python call sites listed per function below (file:line relative to the reference checkout).  A maintainer
+ * binds this library with ctypes.  Conventions:
+ *
+ *   - every pointer named d_* is a DEVICE pointer (HBM of the current HIP device); h_* are host pointers;
+ *   - arrays are dense row-major; `double` = IEEE f64; indices are int32 on the device (N < 2^31);
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls are asynchronous on that stream unless
+ *     stated otherwise; nothing allocates inside a call except s3_knn_create / s3_malloc;
+ *   - return value 0 = success, negative = error (S3_E*); s3_last_error() returns the message of the last failure on
+ *     the calling thread;
+ *   - there is NO CPU fallback: without a HIP device every compute entry point fails with S3_ENODEV.
+ *
+ * Cell conventions (reference s_cube.py:188-194, 399-445): a cell is (centre[dim] f64, level i32); children and
+ * nodes are enumerated in the reference's direction-table order; child centre = centre + dir*(0.25*width)/2^level,
+ * node = centre + dir*(0.5*width)/2^level.
+ */
+#ifndef S3HIP_H
+#define S3HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define S3_OK 0
+#define S3_EINVAL (-1)   /* bad argument (shape, k, dim, null pointer) */
+#define S3_ENODEV (-2)   /* no usable HIP device */
+#define S3_EHIP (-3)     /* HIP runtime error, see s3_last_error() */
+#define S3_ENOMEM (-4)
+
+#define S3_DTYPE_F32 0
+#define S3_DTYPE_F64 1
+
+#define S3_MAX_K 64
+
+typedef struct s3_knn s3_knn; /* opaque: grid-sorted copy of the original point cloud, resident in HBM */
+typedef void *s3_stream;
+
+/* ---- runtime / plumbing ------------------------------------------------------------------------------------ */
+const char *s3_last_error(void);
+int s3_abi_version(void);
+int s3_device_count(int *h_count);
+int s3_set_device(int device);
+int s3_malloc(void **d_ptr, size_t bytes);
+int s3_free(void *d_ptr);
+int s3_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes, s3_stream stream);
+int s3_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes, s3_stream stream);
+int s3_stream_synchronize(s3_stream stream);
+
+/* ---- KNN index over the original CFD points -------------------------------------------------------------------
+ * Replaces KNeighborsRegressor(...).fit(vertices, target)           s_cube.py:161-163
+ *      and NearestNeighbors(...).fit(coordinates)                   export.py:120,423
+ * Builds a uniform-grid bucket index (bounding box, counting sort) on the device.  Synchronous (returns after the
+ * build finished).  `target_occupancy` <= 0 selects the default (3 points per grid cell in 2-D, 8 in 3-D). */
+int s3_knn_create(const double *d_pts /*[n,dim]*/, int64_t n, int dim, double target_occupancy, s3_stream stream,
+                  s3_knn **out);
+void s3_knn_destroy(s3_knn *knn);
+/* attach the regression target y[n] (the S^3 metric, original point order); permuted into grid order */
+int s3_knn_set_values(s3_knn *knn, const double *d_y /*[n]*/, s3_stream stream);
+
+/* exact k nearest neighbours, ascending in (distance, original index); dist = sqrt(sum_j (q_j-p_j)^2).
+ * Replaces NearestNeighbors.kneighbors(centers)                      export.py:425,438 */
+int s3_knn_query(const s3_knn *knn, const double *d_q /*[nq,dim]*/, int64_t nq, int k, int32_t *d_idx /*[nq,k]*/,
+                 double *d_dist /*[nq,k]*/, s3_stream stream);
+
+/* inverse-distance KNN regression with scikit-learn's exact-hit rule and numpy's summation order.
+ * Replaces self._knn.predict(...)                                    s_cube.py:224,328,372 */
+int s3_idw_predict(const s3_knn *knn, const double *d_q /*[nq,dim]*/, int64_t nq, int k, double *d_yhat /*[nq]*/,
+                   s3_stream stream);
+
+/* ---- refine kernels ---------------------------------------------------------------------------------------- */
+/* a3: children of `n_par` parents.  Child c of parent p_i gets cell id new_index + i*2^dim + c; its centre/level
+ * are written into the cell arrays.  Replaces _compute_cell_centers(to_refine, keep_parent=False)
+ *                                                                    s_cube.py:875,399-445 */
+int s3_make_children(double *d_center /*[cap,dim]*/, int32_t *d_level /*[cap]*/, const int32_t *d_parents /*[n_par]*/,
+                     int64_t n_par, int64_t new_index, int dim, double width, s3_stream stream);
+
+/* a4: metric at the centre of each of n cells (ids first..first+n-1) and at its 2^dim candidate child centres, then
+ * gain = level_factor[level] * sum_j |m0 - mj| / gain0.  d_level_factor[64] holds the reference's Python expression
+ * 1/2^d*(width/2^level)^d evaluated on the host.  d_scratch: n*(2^dim+1) doubles.
+ * Replaces SamplingTree._update_gain + _update_gain                  s_cube.py:207-241,1840-1859 */
+int s3_child_gain(const s3_knn *knn, int k, const double *d_center, const int32_t *d_level, int64_t first, int64_t n,
+                  int dim, double width, const double *d_level_factor, double gain0, double *d_metric /*[cap]*/,
+                  double *d_gain /*[cap]*/, double *d_scratch, s3_stream stream);
+
+/* a12: geometry predicates on the nodes of the listed cells (d_cells == NULL: ids first..first+n-1).  Each call ORs
+ * its verdict into d_invalid[n] (zero it first): GeometryObject._apply_mask policy, geometry_base.py:40-76.
+ *   box:      lo <= x <= hi in every dimension                       cube_geometry.py:50-74
+ *   sphere:   ||x - pos|| <= radius                                  sphere_geometry.py:47-72
+ *   cylinder: 0 <= proj <= norm && normal distance <= local radius   cylinder_geometry.py:126-157
+ *   polygon:  strictly inside (boundary excluded)                    coordinates_2d.py:54-75 */
+int s3_mask_box(const double *d_center, const int32_t *d_level, const int32_t *d_cells, int64_t first, int64_t n, int dim,
+                double width, const double *h_lo, const double *h_hi, int refine_mode, int keep_inside,
+                uint8_t *d_invalid, s3_stream stream);
+int s3_mask_sphere(const double *d_center, const int32_t *d_level, const int32_t *d_cells, int64_t first, int64_t n,
+                   int dim, double width, const double *h_pos, double radius, int refine_mode, int keep_inside,
+                   uint8_t *d_invalid, s3_stream stream);
+int s3_mask_cylinder(const double *d_center, const int32_t *d_level, const int32_t *d_cells, int64_t first, int64_t n,
+                     double width, const double *h_p0, const double *h_axis, double norm, double r0, double r1,
+                     int is_cone, int refine_mode, int keep_inside, uint8_t *d_invalid, s3_stream stream);
+int s3_mask_polygon(const double *d_center, const int32_t *d_level, const int32_t *d_cells, int64_t first, int64_t n,
+                    double width, const double *d_poly /*[nv,2] device*/, int nv, int refine_mode, int keep_inside,
+                    uint8_t *d_invalid, s3_stream stream);
+
+/* bookkeeping of one refine batch on the device-resident cell arrays: parents stop being leaves, valid children
+ * become leaves, invalid children get gain 0 (s_cube.py:721-723, 250-251) */
+int s3_commit_batch(uint8_t *d_leaf /*[cap]*/, double *d_gain /*[cap]*/, const int32_t *d_parents, int64_t n_par,
+                    int64_t first, int64_t n_new, const uint8_t *d_invalid /*[n_new] or NULL*/, s3_stream stream);
+
+/* a6 local part: sum over leaf cells of metric^2 (the captured-metric numerator, s_cube.py:327-335), restricted to
+ * cell ids in [begin, end) so that ranks can split the array; deterministic two-stage reduction.  d_out: 1 double.
+ * d_scratch: 1024 doubles. */
+int s3_sumsq_leaf(const double *d_metric, const uint8_t *d_leaf, int64_t begin, int64_t end, double *d_out,
+                  double *d_scratch, s3_stream stream);
+
+/* a8: the n_top leaf cells with the largest (gain, -id), ordered like heapq.nlargest (s_cube.py:601-602).
+ * Radix select on the device, final ordering of the n_top survivors on the host: writes the ordered ids to the HOST
+ * array h_out[n_top]; h_count receives min(n_top, #leaves).  Synchronous.  d_scratch: s3_topn_scratch_bytes(). */
+size_t s3_topn_scratch_bytes(int64_t n_cells, int64_t n_top);
+int s3_topn_leaf(const double *d_gain, const uint8_t *d_leaf, int64_t n_cells, int64_t n_top, int32_t *h_out,
+                 int64_t *h_count, void *d_scratch, s3_stream stream);
+
+/* ---- export kernels ---------------------------------------------------------------------------------------- */
+/* a16: w = 1/clamp(dist, 1e-12), rows normalised to sum 1 (torch's summation order).  export.py:428-429 */
+int s3_idw_weights(const double *d_dist /*[nc,k]*/, int64_t nc, int k, double *d_w /*[nc,k]*/, s3_stream stream);
+
+/* a17/a18: out[c, l] = sum_m w[c,m] * data[idx[c,m], l], l over the contiguous (n_comp*T) axis, f64 accumulate,
+ * f64 output.  Replaces interpolate_data                             export.py:446-468, and :215 with row_len=1 */
+int s3_interp(const double *d_w /*[nc,k]*/, const int32_t *d_idx /*[nc,k]*/, int64_t nc, int k, const void *d_data,
+              int dtype, int64_t n_src, int64_t row_len, double *d_out /*[nc,row_len]*/, s3_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* S3HIP_H */

@@ -1,0 +1,132 @@
+"""
+ctypes bindings of the two native libraries of this package:
+
+* ``libs3hip.so``  -- the MI355X (gfx950) kernels behind the C ABI declared in ``include/s3hip.h``
+* ``libs3topo.so`` -- the host-side topology engine (``csrc/topology.cpp``; plain C++, no GPU)
+
+Both are built in-tree by ``__graft_entry__.build()`` (or ``python -m sparsespatialsampling_amd.build``).  There is no
+fallback: if a library is missing, or no HIP device is present when a compute entry point is reached, the caller gets a
+``HipUnavailableError`` / ``S3HipError``.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_SO = os.path.join(_HERE, "libs3hip.so")
+TOPO_SO = os.path.join(_HERE, "libs3topo.so")
+
+
+class HipUnavailableError(RuntimeError):
+    """libs3hip.so is missing/unloadable or no HIP device is visible.  There is no CPU fallback."""
+
+
+class S3HipError(RuntimeError):
+    """A libs3hip entry point returned an error code."""
+
+
+_hip = None
+_topo = None
+
+c_i64, c_i32, c_int, c_dbl, c_vp = C.c_int64, C.c_int32, C.c_int, C.c_double, C.c_void_p
+
+# name -> (restype, argtypes); must list every symbol include/s3hip.h declares (tests/test_abi.py checks this)
+HIP_SIGNATURES = {
+    "s3_last_error": (C.c_char_p, []),
+    "s3_abi_version": (c_int, []),
+    "s3_device_count": (c_int, [C.POINTER(c_int)]),
+    "s3_set_device": (c_int, [c_int]),
+    "s3_malloc": (c_int, [C.POINTER(c_vp), C.c_size_t]),
+    "s3_free": (c_int, [c_vp]),
+    "s3_memcpy_h2d": (c_int, [c_vp, c_vp, C.c_size_t, c_vp]),
+    "s3_memcpy_d2h": (c_int, [c_vp, c_vp, C.c_size_t, c_vp]),
+    "s3_stream_synchronize": (c_int, [c_vp]),
+    "s3_knn_create": (c_int, [c_vp, c_i64, c_int, c_dbl, c_vp, C.POINTER(c_vp)]),
+    "s3_knn_destroy": (None, [c_vp]),
+    "s3_knn_set_values": (c_int, [c_vp, c_vp, c_vp]),
+    "s3_knn_query": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp]),
+    "s3_idw_predict": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_vp]),
+    "s3_make_children": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_dbl, c_vp]),
+    "s3_child_gain": (c_int, [c_vp, c_int, c_vp, c_vp, c_i64, c_i64, c_int, c_dbl, c_vp, c_dbl, c_vp, c_vp, c_vp, c_vp]),
+    "s3_mask_box": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_dbl, c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
+    "s3_mask_sphere": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_dbl, c_vp, c_dbl, c_int, c_int, c_vp, c_vp]),
+    "s3_mask_cylinder": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_dbl, c_vp, c_vp, c_dbl, c_dbl, c_dbl, c_int, c_int,
+                                 c_int, c_vp, c_vp]),
+    "s3_mask_polygon": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_dbl, c_vp, c_int, c_int, c_int, c_vp, c_vp]),
+    "s3_commit_batch": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp]),
+    "s3_sumsq_leaf": (c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp]),
+    "s3_topn_scratch_bytes": (C.c_size_t, [c_i64, c_i64]),
+    "s3_topn_leaf": (c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, C.POINTER(c_i64), c_vp, c_vp]),
+    "s3_idw_weights": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp]),
+    "s3_interp": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_int, c_i64, c_i64, c_vp, c_vp]),
+}
+
+TOPO_SIGNATURES = {
+    "s3t_create": (c_vp, [c_int, c_dbl, c_vp]),
+    "s3t_destroy": (None, [c_vp]),
+    "s3t_n_cells": (c_i64, [c_vp]),
+    "s3t_n_nodes": (c_i64, [c_vp]),
+    "s3t_level": (c_vp, [c_vp]),
+    "s3t_parent": (c_vp, [c_vp]),
+    "s3t_first_child": (c_vp, [c_vp]),
+    "s3t_nb": (c_vp, [c_vp]),
+    "s3t_node_idx": (c_vp, [c_vp]),
+    "s3t_center": (c_vp, [c_vp]),
+    "s3t_nodes": (c_vp, [c_vp]),
+    "s3t_refine": (c_i64, [c_vp, c_vp, c_i64, c_int]),
+    "s3t_relink_parent_of": (None, [c_vp, c_vp, c_i64]),
+    "s3t_mark_invalid": (None, [c_vp, c_vp, c_i64]),
+    "s3t_check_nb": (c_int, [c_vp, c_i64, c_vp]),
+    "s3t_finalize": (c_i64, [c_vp, C.POINTER(c_i64)]),
+    "s3t_face_ids": (c_vp, [c_vp]),
+    "s3t_unique_nodes": (c_vp, [c_vp]),
+    "s3t_selfcheck": (c_int, [c_int]),
+}
+
+
+def _bind(lib, signatures):
+    for name, (res, args) in signatures.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+def hip_lib():
+    """Load libs3hip.so (no device is touched by loading)."""
+    global _hip
+    if _hip is None:
+        if not os.path.exists(HIP_SO):
+            raise HipUnavailableError(f"{HIP_SO} not found -- build it with `python -c 'import __graft_entry__ as g; "
+                                      f"g.build()'`.  This package has no CPU fallback.")
+        try:
+            _hip = _bind(C.CDLL(HIP_SO), HIP_SIGNATURES)
+        except OSError as e:
+            raise HipUnavailableError(f"cannot load {HIP_SO}: {e}") from e
+    return _hip
+
+
+def topo_lib():
+    global _topo
+    if _topo is None:
+        if not os.path.exists(TOPO_SO):
+            raise HipUnavailableError(f"{TOPO_SO} not found -- build it with `__graft_entry__.build()`.")
+        _topo = _bind(C.CDLL(TOPO_SO), TOPO_SIGNATURES)
+    return _topo
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = hip_lib().s3_last_error().decode(errors="replace")
+        if rc == -2:
+            raise HipUnavailableError(f"{what}: no usable HIP device ({msg})")
+        raise S3HipError(f"{what} failed with code {rc}: {msg}")
+
+
+def require_device():
+    """Raise unless at least one HIP device is visible to libs3hip.so."""
+    n = c_int(0)
+    rc = hip_lib().s3_device_count(C.byref(n))
+    if rc != 0 or n.value < 1:
+        raise HipUnavailableError("no HIP device visible to libs3hip.so -- the S^3 hot path runs on MI355X only "
+                                  "(there is no CPU fallback).")
+    return n.value

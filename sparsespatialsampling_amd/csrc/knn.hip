@@ -1,0 +1,651 @@
+// Exact k-nearest-neighbour search on a uniform bucket grid + the KNN consumers of the S^3 refine path
+// (inverse-distance regression, child-centre gain).  gfx950 only.
+//
+// Reference behaviour restated here (file:line relative to the reference checkout):
+//   KNeighborsRegressor(k, weights="distance").fit/predict   s_cube.py:161-163,224,328,372
+//   NearestNeighbors(k).fit/kneighbors                       export.py:120,423-425,438
+//   SamplingTree._update_gain + numba _update_gain           s_cube.py:207-241,1840-1859
+//
+// Layout in HBM: the point cloud is copied once into bucket order (counting sort by grid cell) as an array of
+// structures [n][dim] f64 so that one query thread streams whole points from consecutive addresses; cell_start[]
+// (int32, ncell+1) gives each bucket's range; orig[] maps bucket order back to the caller's point ids; y[] holds the
+// regression target in bucket order.  One thread owns one query; its running k-best list (squared distance f64 +
+// bucket position i32) lives in LDS, laid out [slot][thread] so the 64 lanes of a wavefront hit 64 distinct banks.
+// The search visits Chebyshev rings of buckets around the query's bucket and stops when the k-th best squared
+// distance is smaller than the squared distance to the nearest unvisited bucket face.
+//
+// Arithmetic is kept bit-identical to the reference stack (no FMA contraction: this file is compiled with
+// -ffp-contract=off): rdist = sum_j (q_j-p_j)^2 in dimension order, dist = sqrt(rdist), w = 1/dist, numpy pairwise
+// summation of y*w and w.  Ties in rdist are ordered by the original point id.
+#include "common.h"
+
+#include <cfloat>
+#include <cmath>
+#include <vector>
+
+struct s3_knn {
+    int dim = 0;
+    int device = 0;
+    int64_t n = 0;
+    double lo[3] = {0, 0, 0}, h[3] = {1, 1, 1}, inv_h[3] = {1, 1, 1};
+    int res[3] = {1, 1, 1};
+    int64_t ncell = 1;
+    double *pts = nullptr;         // [n][dim] bucket order
+    int32_t *orig = nullptr;       // [n]
+    int32_t *cell_start = nullptr; // [ncell+1]
+    double *y = nullptr;           // [n] bucket order (optional)
+};
+
+namespace s3 {
+
+constexpr int KNN_BLOCK = 128;
+
+template <int DIM>
+struct Grid {
+    double lo[DIM], h[DIM], inv_h[DIM];
+    int res[DIM];
+};
+
+template <int DIM>
+static Grid<DIM> make_grid(const s3_knn *k) {
+    Grid<DIM> g;
+    for (int j = 0; j < DIM; ++j) {
+        g.lo[j] = k->lo[j];
+        g.h[j] = k->h[j];
+        g.inv_h[j] = k->inv_h[j];
+        g.res[j] = k->res[j];
+    }
+    return g;
+}
+
+template <int DIM>
+__device__ __forceinline__ int cell_coord(const Grid<DIM> &g, double x, int j) {
+    double t = (x - g.lo[j]) * g.inv_h[j];
+    t = fmin(fmax(t, 0.0), (double)(g.res[j] - 1));   // also maps NaN to 0
+    return (int)t;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// build kernels
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void bbox_kernel(const double *__restrict__ pts, int64_t n, int dim, double *__restrict__ partial) {
+    __shared__ double smin[3][256], smax[3][256];
+    double mn[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, mx[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        for (int j = 0; j < dim; ++j) {
+            double v = pts[i * dim + j];
+            mn[j] = fmin(mn[j], v);
+            mx[j] = fmax(mx[j], v);
+        }
+    for (int j = 0; j < 3; ++j) {
+        smin[j][threadIdx.x] = mn[j];
+        smax[j][threadIdx.x] = mx[j];
+    }
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s)
+            for (int j = 0; j < 3; ++j) {
+                smin[j][threadIdx.x] = fmin(smin[j][threadIdx.x], smin[j][threadIdx.x + s]);
+                smax[j][threadIdx.x] = fmax(smax[j][threadIdx.x], smax[j][threadIdx.x + s]);
+            }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        for (int j = 0; j < 3; ++j) {
+            partial[blockIdx.x * 6 + j] = smin[j][0];
+            partial[blockIdx.x * 6 + 3 + j] = smax[j][0];
+        }
+}
+
+template <int DIM>
+__global__ void cell_count_kernel(Grid<DIM> g, const double *__restrict__ pts, int64_t n, int32_t *__restrict__ cid,
+                                  int32_t *__restrict__ count) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int64_t c = 0;
+    for (int j = DIM - 1; j >= 0; --j) c = c * g.res[j] + cell_coord<DIM>(g, pts[i * DIM + j], j);
+    cid[i] = (int32_t)c;
+    atomicAdd(&count[c], 1);
+}
+
+// exclusive scan, 1024 items per block (4 per thread), three passes
+__global__ void scan_block_kernel(int32_t *__restrict__ data, int64_t n, int32_t *__restrict__ block_sums) {
+    __shared__ int32_t s[256];
+    int64_t base = (int64_t)blockIdx.x * 1024 + threadIdx.x * 4;
+    int32_t v[4], t = 0;
+    for (int j = 0; j < 4; ++j) {
+        v[j] = (base + j < n) ? data[base + j] : 0;
+        t += v[j];
+    }
+    s[threadIdx.x] = t;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        int32_t add = ((int)threadIdx.x >= off) ? s[threadIdx.x - off] : 0;
+        __syncthreads();
+        s[threadIdx.x] += add;
+        __syncthreads();
+    }
+    int32_t excl = s[threadIdx.x] - t;
+    for (int j = 0; j < 4; ++j) {
+        if (base + j < n) data[base + j] = excl;
+        excl += v[j];
+    }
+    if (threadIdx.x == 255) block_sums[blockIdx.x] = s[255];
+}
+
+__global__ void scan_sums_kernel(int32_t *__restrict__ block_sums, int64_t nb) {
+    // single block, serial over chunks of 256
+    __shared__ int32_t s[256];
+    __shared__ int32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < nb; base += 256) {
+        int64_t i = base + threadIdx.x;
+        int32_t t = i < nb ? block_sums[i] : 0;
+        s[threadIdx.x] = t;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            int32_t add = ((int)threadIdx.x >= off) ? s[threadIdx.x - off] : 0;
+            __syncthreads();
+            s[threadIdx.x] += add;
+            __syncthreads();
+        }
+        if (i < nb) block_sums[i] = carry + s[threadIdx.x] - t;
+        __syncthreads();
+        if (threadIdx.x == 255) carry += s[255];
+        __syncthreads();
+    }
+}
+
+__global__ void scan_add_kernel(int32_t *__restrict__ data, int64_t n, const int32_t *__restrict__ block_sums) {
+    int64_t base = (int64_t)blockIdx.x * 1024 + threadIdx.x * 4;
+    int32_t add = block_sums[blockIdx.x];
+    for (int j = 0; j < 4; ++j)
+        if (base + j < n) data[base + j] += add;
+}
+
+template <int DIM>
+__global__ void scatter_kernel(const double *__restrict__ pts, int64_t n, const int32_t *__restrict__ cid,
+                               const int32_t *__restrict__ cell_start, int32_t *__restrict__ cursor,
+                               double *__restrict__ out_pts, int32_t *__restrict__ orig) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int32_t c = cid[i];
+    int32_t pos = cell_start[c] + atomicAdd(&cursor[c], 1);
+    for (int j = 0; j < DIM; ++j) out_pts[(int64_t)pos * DIM + j] = pts[i * DIM + j];
+    orig[pos] = (int32_t)i;
+}
+
+__global__ void permute_values_kernel(const double *__restrict__ y, const int32_t *__restrict__ orig, int64_t n,
+                                      double *__restrict__ out) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n) out[i] = y[orig[i]];
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// the search
+// ------------------------------------------------------------------------------------------------------------------
+struct KBest {
+    double *sd;    // LDS, this thread's column: slot m at sd[m*KNN_BLOCK]
+    int32_t *sp;
+    int k;
+    int cnt;
+    double worst;  // sd[k-1] once the list is full, +inf before
+};
+
+__device__ __forceinline__ bool kb_less(double d, int32_t p, double d2, int32_t p2, const int32_t *__restrict__ orig) {
+    return d < d2 || (d == d2 && orig[p] < orig[p2]);
+}
+
+__device__ __forceinline__ void kb_offer(KBest &b, double d, int32_t p, const int32_t *__restrict__ orig) {
+    if (b.cnt == b.k) {
+        if (d > b.worst) return;
+        if (d == b.worst && !(orig[p] < orig[b.sp[(b.k - 1) * KNN_BLOCK]])) return;
+    }
+    int j = b.cnt < b.k ? b.cnt : b.k - 1;
+    while (j > 0 && kb_less(d, p, b.sd[(j - 1) * KNN_BLOCK], b.sp[(j - 1) * KNN_BLOCK], orig)) {
+        b.sd[j * KNN_BLOCK] = b.sd[(j - 1) * KNN_BLOCK];
+        b.sp[j * KNN_BLOCK] = b.sp[(j - 1) * KNN_BLOCK];
+        --j;
+    }
+    b.sd[j * KNN_BLOCK] = d;
+    b.sp[j * KNN_BLOCK] = p;
+    if (b.cnt < b.k) ++b.cnt;
+    if (b.cnt == b.k) b.worst = b.sd[(b.k - 1) * KNN_BLOCK];
+}
+
+template <int DIM>
+__device__ __forceinline__ void scan_range(KBest &b, const double *__restrict__ pts, const int32_t *__restrict__ orig,
+                                           const double (&q)[DIM], int32_t p0, int32_t p1) {
+    for (int32_t p = p0; p < p1; ++p) {
+        double d = 0.0;
+#pragma unroll
+        for (int j = 0; j < DIM; ++j) {
+            double t = q[j] - pts[(int64_t)p * DIM + j];
+            d += t * t;
+        }
+        kb_offer(b, d, p, orig);
+    }
+}
+
+template <int DIM>
+__device__ void knn_search(const Grid<DIM> &g, const double *__restrict__ pts, const int32_t *__restrict__ orig,
+                           const int32_t *__restrict__ cs, const double (&q)[DIM], KBest &b) {
+    int c[DIM];
+    int rmax = 0;
+    double hmin = DBL_MAX;
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) {
+        c[j] = cell_coord<DIM>(g, q[j], j);
+        rmax = max(rmax, max(c[j], g.res[j] - 1 - c[j]));
+        hmin = fmin(hmin, g.h[j]);
+    }
+    const int c2 = DIM == 3 ? c[DIM - 1] : 0;
+    const int res2 = DIM == 3 ? g.res[DIM - 1] : 1;
+
+    for (int r = 0; r <= rmax; ++r) {
+        const int x0 = max(c[0] - r, 0), x1 = min(c[0] + r, g.res[0] - 1);
+        const int y0 = max(c[1] - r, 0), y1 = min(c[1] + r, g.res[1] - 1);
+        const int z0 = DIM == 3 ? max(c2 - r, 0) : 0, z1 = DIM == 3 ? min(c2 + r, res2 - 1) : 0;
+        for (int z = z0; z <= z1; ++z) {
+            const int dz = DIM == 3 ? abs(z - c2) : 0;
+            for (int y = y0; y <= y1; ++y) {
+                const int dy = abs(y - c[1]);
+                const int64_t row = ((int64_t)z * g.res[1] + y) * g.res[0];
+                if (max(dz, dy) == r) {
+                    // whole x-run of this row belongs to the ring: buckets are consecutive in memory
+                    scan_range<DIM>(b, pts, orig, q, cs[row + x0], cs[row + x1 + 1]);
+                } else {
+                    if (c[0] - r >= 0) scan_range<DIM>(b, pts, orig, q, cs[row + c[0] - r], cs[row + c[0] - r + 1]);
+                    if (c[0] + r < g.res[0]) scan_range<DIM>(b, pts, orig, q, cs[row + c[0] + r], cs[row + c[0] + r + 1]);
+                }
+            }
+        }
+        if (b.cnt == b.k) {
+            // distance from q to the nearest face of the visited box that still has buckets behind it
+            double bound = DBL_MAX;
+#pragma unroll
+            for (int j = 0; j < DIM; ++j) {
+                if (c[j] - r > 0) bound = fmin(bound, q[j] - (g.lo[j] + (double)(c[j] - r) * g.h[j]));
+                if (c[j] + r < g.res[j] - 1) bound = fmin(bound, (g.lo[j] + (double)(c[j] + r + 1) * g.h[j]) - q[j]);
+            }
+            if (bound == DBL_MAX) break;          // the box covers the whole grid
+            bound -= 1e-9 * hmin;                 // bucket assignment rounds; stay conservative
+            if (bound > 0.0 && b.worst < bound * bound) break;
+        }
+    }
+}
+
+// numpy pairwise sum of f(m), m = 0..k-1 (see oracle/s3_oracle.c numpy_pairwise_sum)
+template <typename F>
+__device__ __forceinline__ double numpy_pairwise(int k, F f) {
+    if (k < 8) {
+        double r = 0.0;
+        for (int i = 0; i < k; ++i) r += f(i);
+        return r;
+    }
+    double r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = f(j);
+    int i = 8;
+    for (; i < k - (k % 8); i += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] += f(i + j);
+    }
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < k; ++i) res += f(i);
+    return res;
+}
+
+__device__ __forceinline__ double idw_from_list(const KBest &b, const double *__restrict__ y) {
+    bool has_zero = false;
+    for (int m = 0; m < b.k; ++m) has_zero |= (b.sd[m * KNN_BLOCK] == 0.0);
+    auto wgt = [&](int m) {
+        double rd = b.sd[m * KNN_BLOCK];
+        return has_zero ? (rd == 0.0 ? 1.0 : 0.0) : 1.0 / sqrt(rd);
+    };
+    double num = numpy_pairwise(b.k, [&](int m) { return y[b.sp[m * KNN_BLOCK]] * wgt(m); });
+    double den = numpy_pairwise(b.k, wgt);
+    return num / den;
+}
+
+__device__ __forceinline__ KBest kb_init(double *lds, int k) {
+    KBest b;
+    b.sd = lds + threadIdx.x;
+    b.sp = reinterpret_cast<int32_t *>(lds + (size_t)k * KNN_BLOCK) + threadIdx.x;
+    b.k = k;
+    b.cnt = 0;
+    b.worst = DBL_MAX;
+    return b;
+}
+
+template <int DIM>
+__global__ void __launch_bounds__(KNN_BLOCK)
+knn_query_kernel(Grid<DIM> g, const double *__restrict__ pts, const int32_t *__restrict__ orig,
+                 const int32_t *__restrict__ cs, const double *__restrict__ q_in, int64_t nq, int k,
+                 int32_t *__restrict__ idx_out, double *__restrict__ dist_out) {
+    extern __shared__ double lds[];
+    int64_t i = blockIdx.x * (int64_t)KNN_BLOCK + threadIdx.x;
+    if (i >= nq) return;
+    double q[DIM];
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) q[j] = q_in[i * DIM + j];
+    KBest b = kb_init(lds, k);
+    knn_search<DIM>(g, pts, orig, cs, q, b);
+    for (int m = 0; m < k; ++m) {
+        idx_out[i * k + m] = orig[b.sp[m * KNN_BLOCK]];
+        dist_out[i * k + m] = sqrt(b.sd[m * KNN_BLOCK]);
+    }
+}
+
+template <int DIM>
+__global__ void __launch_bounds__(KNN_BLOCK)
+idw_predict_kernel(Grid<DIM> g, const double *__restrict__ pts, const int32_t *__restrict__ orig,
+                   const int32_t *__restrict__ cs, const double *__restrict__ y, const double *__restrict__ q_in,
+                   int64_t nq, int k, double *__restrict__ yhat) {
+    extern __shared__ double lds[];
+    int64_t i = blockIdx.x * (int64_t)KNN_BLOCK + threadIdx.x;
+    if (i >= nq) return;
+    double q[DIM];
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) q[j] = q_in[i * DIM + j];
+    KBest b = kb_init(lds, k);
+    knn_search<DIM>(g, pts, orig, cs, q, b);
+    yhat[i] = idw_from_list(b, y);
+}
+
+// a3+a4 first half: query t = (cell i, point j) with j = 0 the cell centre and j = 1..2^DIM its candidate children
+template <int DIM>
+__global__ void __launch_bounds__(KNN_BLOCK)
+child_metric_kernel(Grid<DIM> g, const double *__restrict__ pts, const int32_t *__restrict__ orig,
+                    const int32_t *__restrict__ cs, const double *__restrict__ y, const double *__restrict__ center,
+                    const int32_t *__restrict__ level, int64_t first, int64_t n, double quarter_width, int k,
+                    double *__restrict__ metric_all) {
+    constexpr int NQ = (1 << DIM) + 1;
+    extern __shared__ double lds[];
+    int64_t t = blockIdx.x * (int64_t)KNN_BLOCK + threadIdx.x;
+    if (t >= n * NQ) return;
+    int64_t i = t / NQ;
+    int jq = (int)(t - i * NQ);
+    int64_t cell = first + i;
+    double q[DIM];
+    double off = cell_offset(quarter_width, level[cell]);
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) {
+        double cj = center[cell * DIM + j];
+        q[j] = jq == 0 ? cj : cj + dir_comp(DIM, jq - 1, j) * off;
+    }
+    KBest b = kb_init(lds, k);
+    knn_search<DIM>(g, pts, orig, cs, q, b);
+    metric_all[t] = idw_from_list(b, y);
+}
+
+// torch CPU inner-dimension sum order (oracle/s3_oracle.c torch_inner_sum), n <= 64
+template <typename F>
+__device__ __forceinline__ double torch_inner_sum(int n, F f) {
+    const int nv = n / 4;
+    double part[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int l = 0; l < 4; ++l) part[a][l] = 0.0;
+    const int size_ilp = nv / 4;
+    for (int i = 0; i < size_ilp; ++i)
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int l = 0; l < 4; ++l) part[a][l] += f((i * 4 + a) * 4 + l);
+    for (int i = size_ilp * 4; i < nv; ++i)
+#pragma unroll
+        for (int l = 0; l < 4; ++l) part[0][l] += f(i * 4 + l);
+#pragma unroll
+    for (int a = 1; a < 4; ++a)
+#pragma unroll
+        for (int l = 0; l < 4; ++l) part[0][l] += part[a][l];
+    double acc = 0.0;
+    for (int i = nv * 4; i < n; ++i) acc += f(i);
+#pragma unroll
+    for (int l = 0; l < 4; ++l) acc += part[0][l];
+    return acc;
+}
+
+template <int DIM>
+__global__ void child_gain_kernel(const double *__restrict__ metric_all, const int32_t *__restrict__ level,
+                                  int64_t first, int64_t n, const double *__restrict__ level_factor, double gain0,
+                                  double *__restrict__ metric, double *__restrict__ gain) {
+    constexpr int NCH = 1 << DIM, NQ = NCH + 1;
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double *m = metric_all + i * NQ;
+    double m0 = m[0];
+    double sd = torch_inner_sum(NCH, [&](int c) { return fabs(m0 - m[1 + c]); });
+    int lv = level[first + i];
+    metric[first + i] = m0;
+    gain[first + i] = level_factor[lv] * sd / gain0;
+}
+
+__global__ void idw_weights_kernel(const double *__restrict__ dist, int64_t nc, int k, double *__restrict__ w) {
+    int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (c >= nc) return;
+    const double *d = dist + c * k;
+    auto inv = [&](int m) {
+        double v = d[m];
+        return 1.0 / (v < 1e-12 ? 1e-12 : v);
+    };
+    double s = torch_inner_sum(k, inv);
+    for (int m = 0; m < k; ++m) w[c * k + m] = inv(m) / s;
+}
+
+static size_t knn_lds_bytes(int k) { return (size_t)k * KNN_BLOCK * (sizeof(double) + sizeof(int32_t)); }
+
+static int check_query_args(const s3_knn *knn, const void *q, int64_t nq, int k, const char *who) {
+    S3_REQUIRE(knn != nullptr && knn->pts != nullptr, "%s: null index", who);
+    S3_REQUIRE(nq >= 0 && (nq == 0 || q != nullptr), "%s: bad query array", who);
+    S3_REQUIRE(k >= 1 && k <= S3_MAX_K, "%s: k=%d outside [1,%d]", who, k, S3_MAX_K);
+    S3_REQUIRE((int64_t)k <= knn->n, "%s: k=%d exceeds the number of points %lld", who, k, (long long)knn->n);
+    return S3_OK;
+}
+
+}  // namespace s3
+
+using namespace s3;
+
+extern "C" {
+
+int s3_knn_create(const double *d_pts, int64_t n, int dim, double target_occupancy, s3_stream stream, s3_knn **out) {
+    S3_REQUIRE(out != nullptr, "s3_knn_create: null output");
+    *out = nullptr;
+    S3_REQUIRE(dim == 2 || dim == 3, "s3_knn_create: dim must be 2 or 3, got %d", dim);
+    S3_REQUIRE(n >= 1 && n < ((int64_t)1 << 31), "s3_knn_create: n=%lld outside [1, 2^31)", (long long)n);
+    S3_REQUIRE(d_pts != nullptr, "s3_knn_create: null points");
+    hipStream_t st = as_stream(stream);
+    int dev = 0;
+    S3_HIP_CHECK(hipGetDevice(&dev));
+
+    // bounding box
+    const int nb = 256;
+    double *d_partial = nullptr;
+    S3_HIP_CHECK(hipMalloc(&d_partial, sizeof(double) * nb * 6));
+    bbox_kernel<<<nb, 256, 0, st>>>(d_pts, n, dim, d_partial);
+    S3_LAUNCH_CHECK();
+    std::vector<double> part(nb * 6);
+    S3_HIP_CHECK(hipMemcpyAsync(part.data(), d_partial, sizeof(double) * nb * 6, hipMemcpyDeviceToHost, st));
+    S3_HIP_CHECK(hipStreamSynchronize(st));
+    S3_HIP_CHECK(hipFree(d_partial));
+    double lo[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, hi[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+    for (int b = 0; b < nb; ++b)
+        for (int j = 0; j < dim; ++j) {
+            lo[j] = std::fmin(lo[j], part[b * 6 + j]);
+            hi[j] = std::fmax(hi[j], part[b * 6 + 3 + j]);
+        }
+    for (int j = 0; j < dim; ++j)
+        S3_REQUIRE(std::isfinite(lo[j]) && std::isfinite(hi[j]), "s3_knn_create: non-finite coordinates");
+
+    s3_knn *k = new s3_knn();
+    k->dim = dim;
+    k->n = n;
+    k->device = dev;
+    double occ = target_occupancy > 0 ? target_occupancy : (dim == 2 ? 3.0 : 8.0);
+    double ext[3], vol = 1.0;
+    int nz = 0;
+    for (int j = 0; j < dim; ++j) {
+        ext[j] = hi[j] - lo[j];
+        if (ext[j] > 0) {
+            vol *= ext[j];
+            ++nz;
+        }
+    }
+    double target_cells = std::fmax(1.0, (double)n / occ);
+    double s = nz > 0 ? std::pow(vol / target_cells, 1.0 / nz) : 1.0;
+    const int rmax = dim == 2 ? 8192 : 512;
+    int64_t ncell = 1;
+    for (int j = 0; j < dim; ++j) {
+        int r = 1;
+        if (ext[j] > 0 && s > 0) r = (int)std::fmin((double)rmax, std::fmax(1.0, std::ceil(ext[j] / s)));
+        k->res[j] = r;
+        k->lo[j] = lo[j];
+        double e = ext[j] > 0 ? ext[j] * (1.0 + 1e-12) : 1.0;
+        k->h[j] = e / r;
+        k->inv_h[j] = r / e;
+        ncell *= r;
+    }
+    k->ncell = ncell;
+
+    int32_t *cid = nullptr, *cursor = nullptr, *block_sums = nullptr;
+    int64_t nscan = ncell + 1;
+    int64_t nblk = (nscan + 1023) / 1024;
+    auto fail = [&](int rc) {
+        if (cid) (void)hipFree(cid);
+        if (cursor) (void)hipFree(cursor);
+        if (block_sums) (void)hipFree(block_sums);
+        s3_knn_destroy(k);
+        return rc;
+    };
+#define S3_TRY(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess) {                                                                        \
+            s3::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__);  \
+            return fail(_e == hipErrorOutOfMemory ? S3_ENOMEM : S3_EHIP);                              \
+        }                                                                                              \
+    } while (0)
+    S3_TRY(hipMalloc(&k->pts, sizeof(double) * n * dim));
+    S3_TRY(hipMalloc(&k->orig, sizeof(int32_t) * n));
+    S3_TRY(hipMalloc(&k->cell_start, sizeof(int32_t) * nscan));
+    S3_TRY(hipMalloc(&cid, sizeof(int32_t) * n));
+    S3_TRY(hipMalloc(&cursor, sizeof(int32_t) * ncell));
+    S3_TRY(hipMalloc(&block_sums, sizeof(int32_t) * nblk));
+    S3_TRY(hipMemsetAsync(k->cell_start, 0, sizeof(int32_t) * nscan, st));
+    S3_TRY(hipMemsetAsync(cursor, 0, sizeof(int32_t) * ncell, st));
+    if (dim == 2)
+        cell_count_kernel<2><<<grid_for(n, 256), 256, 0, st>>>(make_grid<2>(k), d_pts, n, cid, k->cell_start);
+    else
+        cell_count_kernel<3><<<grid_for(n, 256), 256, 0, st>>>(make_grid<3>(k), d_pts, n, cid, k->cell_start);
+    S3_TRY(hipGetLastError());
+    scan_block_kernel<<<(unsigned)nblk, 256, 0, st>>>(k->cell_start, nscan, block_sums);
+    scan_sums_kernel<<<1, 256, 0, st>>>(block_sums, nblk);
+    scan_add_kernel<<<(unsigned)nblk, 256, 0, st>>>(k->cell_start, nscan, block_sums);
+    S3_TRY(hipGetLastError());
+    if (dim == 2)
+        scatter_kernel<2><<<grid_for(n, 256), 256, 0, st>>>(d_pts, n, cid, k->cell_start, cursor, k->pts, k->orig);
+    else
+        scatter_kernel<3><<<grid_for(n, 256), 256, 0, st>>>(d_pts, n, cid, k->cell_start, cursor, k->pts, k->orig);
+    S3_TRY(hipGetLastError());
+    S3_TRY(hipStreamSynchronize(st));
+    (void)hipFree(cid);
+    (void)hipFree(cursor);
+    (void)hipFree(block_sums);
+#undef S3_TRY
+    *out = k;
+    return S3_OK;
+}
+
+void s3_knn_destroy(s3_knn *knn) {
+    if (!knn) return;
+    if (knn->pts) (void)hipFree(knn->pts);
+    if (knn->orig) (void)hipFree(knn->orig);
+    if (knn->cell_start) (void)hipFree(knn->cell_start);
+    if (knn->y) (void)hipFree(knn->y);
+    delete knn;
+}
+
+int s3_knn_set_values(s3_knn *knn, const double *d_y, s3_stream stream) {
+    S3_REQUIRE(knn != nullptr && d_y != nullptr, "s3_knn_set_values: null argument");
+    if (!knn->y) S3_HIP_CHECK(hipMalloc(&knn->y, sizeof(double) * knn->n));
+    permute_values_kernel<<<grid_for(knn->n, 256), 256, 0, as_stream(stream)>>>(d_y, knn->orig, knn->n, knn->y);
+    S3_LAUNCH_CHECK();
+    return S3_OK;
+}
+
+int s3_knn_query(const s3_knn *knn, const double *d_q, int64_t nq, int k, int32_t *d_idx, double *d_dist,
+                 s3_stream stream) {
+    if (int rc = check_query_args(knn, d_q, nq, k, "s3_knn_query")) return rc;
+    S3_REQUIRE(nq == 0 || (d_idx && d_dist), "s3_knn_query: null output");
+    if (nq == 0) return S3_OK;
+    unsigned grid = grid_for(nq, KNN_BLOCK);
+    size_t lds = knn_lds_bytes(k);
+    if (knn->dim == 2)
+        knn_query_kernel<2><<<grid, KNN_BLOCK, lds, as_stream(stream)>>>(make_grid<2>(knn), knn->pts, knn->orig,
+                                                                         knn->cell_start, d_q, nq, k, d_idx, d_dist);
+    else
+        knn_query_kernel<3><<<grid, KNN_BLOCK, lds, as_stream(stream)>>>(make_grid<3>(knn), knn->pts, knn->orig,
+                                                                         knn->cell_start, d_q, nq, k, d_idx, d_dist);
+    S3_LAUNCH_CHECK();
+    return S3_OK;
+}
+
+int s3_idw_predict(const s3_knn *knn, const double *d_q, int64_t nq, int k, double *d_yhat, s3_stream stream) {
+    if (int rc = check_query_args(knn, d_q, nq, k, "s3_idw_predict")) return rc;
+    S3_REQUIRE(knn->y != nullptr, "s3_idw_predict: call s3_knn_set_values first");
+    S3_REQUIRE(nq == 0 || d_yhat, "s3_idw_predict: null output");
+    if (nq == 0) return S3_OK;
+    unsigned grid = grid_for(nq, KNN_BLOCK);
+    size_t lds = knn_lds_bytes(k);
+    if (knn->dim == 2)
+        idw_predict_kernel<2><<<grid, KNN_BLOCK, lds, as_stream(stream)>>>(
+            make_grid<2>(knn), knn->pts, knn->orig, knn->cell_start, knn->y, d_q, nq, k, d_yhat);
+    else
+        idw_predict_kernel<3><<<grid, KNN_BLOCK, lds, as_stream(stream)>>>(
+            make_grid<3>(knn), knn->pts, knn->orig, knn->cell_start, knn->y, d_q, nq, k, d_yhat);
+    S3_LAUNCH_CHECK();
+    return S3_OK;
+}
+
+int s3_child_gain(const s3_knn *knn, int k, const double *d_center, const int32_t *d_level, int64_t first, int64_t n,
+                  int dim, double width, const double *d_level_factor, double gain0, double *d_metric, double *d_gain,
+                  double *d_scratch, s3_stream stream) {
+    if (int rc = check_query_args(knn, d_center, n, k, "s3_child_gain")) return rc;
+    S3_REQUIRE(knn->y != nullptr, "s3_child_gain: call s3_knn_set_values first");
+    S3_REQUIRE(dim == knn->dim, "s3_child_gain: dim %d does not match the index (%d)", dim, knn->dim);
+    S3_REQUIRE(first >= 0 && n >= 0, "s3_child_gain: bad range");
+    S3_REQUIRE(n == 0 || (d_level && d_level_factor && d_metric && d_gain && d_scratch), "s3_child_gain: null array");
+    S3_REQUIRE(gain0 != 0.0, "s3_child_gain: gain0 must be non-zero");
+    if (n == 0) return S3_OK;
+    hipStream_t st = as_stream(stream);
+    size_t lds = knn_lds_bytes(k);
+    const double qw = 0.25 * width;
+    if (dim == 2) {
+        child_metric_kernel<2><<<grid_for(n * 5, KNN_BLOCK), KNN_BLOCK, lds, st>>>(
+            make_grid<2>(knn), knn->pts, knn->orig, knn->cell_start, knn->y, d_center, d_level, first, n, qw, k, d_scratch);
+        child_gain_kernel<2><<<grid_for(n, 256), 256, 0, st>>>(d_scratch, d_level, first, n, d_level_factor, gain0,
+                                                              d_metric, d_gain);
+    } else {
+        child_metric_kernel<3><<<grid_for(n * 9, KNN_BLOCK), KNN_BLOCK, lds, st>>>(
+            make_grid<3>(knn), knn->pts, knn->orig, knn->cell_start, knn->y, d_center, d_level, first, n, qw, k, d_scratch);
+        child_gain_kernel<3><<<grid_for(n, 256), 256, 0, st>>>(d_scratch, d_level, first, n, d_level_factor, gain0,
+                                                              d_metric, d_gain);
+    }
+    S3_LAUNCH_CHECK();
+    return S3_OK;
+}
+
+int s3_idw_weights(const double *d_dist, int64_t nc, int k, double *d_w, s3_stream stream) {
+    S3_REQUIRE(nc >= 0 && k >= 1 && k <= S3_MAX_K, "s3_idw_weights: bad shape nc=%lld k=%d", (long long)nc, k);
+    S3_REQUIRE(nc == 0 || (d_dist && d_w), "s3_idw_weights: null array");
+    if (nc == 0) return S3_OK;
+    idw_weights_kernel<<<grid_for(nc, 256), 256, 0, as_stream(stream)>>>(d_dist, nc, k, d_w);
+    S3_LAUNCH_CHECK();
+    return S3_OK;
+}
+
+}  // extern "C"

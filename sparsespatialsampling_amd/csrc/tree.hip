@@ -1,0 +1,455 @@
+// Device-resident cell arrays of the S^3 sampling tree: child creation, geometry predicates, batch bookkeeping,
+// captured-metric reduction and top-N gain selection.  gfx950 only.
+//
+// The tree itself (which cell gets which id, neighbour links, shared-node numbering) is decided on the host exactly as
+// the reference does (ordering comes from CPython set iteration); the arrays below are the
+// structure-of-arrays image of the reference's `Cell` objects (s_cube.py:32-83) that the kernels work on:
+//   center[cap][dim] f64, level[cap] i32, metric[cap] f64, gain[cap] f64, leaf[cap] u8.
+#include "common.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cstring>
+#include <vector>
+
+namespace s3 {
+
+// ------------------------------------------------------------------------------------------------------------------
+// a3: children.  s_cube.py:875 -> 399-445 with _factor = 0.25
+// ------------------------------------------------------------------------------------------------------------------
+template <int DIM>
+__global__ void make_children_kernel(double *__restrict__ center, int32_t *__restrict__ level,
+                                     const int32_t *__restrict__ parents, int64_t n_par, int64_t new_index,
+                                     double quarter_width) {
+    constexpr int NCH = 1 << DIM;
+    int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= n_par * NCH) return;
+    int64_t i = t / NCH;
+    int c = (int)(t - i * NCH);
+    int64_t p = parents[i];
+    int lv = level[p];
+    double off = cell_offset(quarter_width, lv);
+    int64_t child = new_index + t;
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) center[child * DIM + j] = center[p * DIM + j] + dir_comp(DIM, c, j) * off;
+    level[child] = lv + 1;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// a12: geometry predicates.  combine() = GeometryObject._apply_mask (geometry_base.py:40-76)
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint8_t combine(int n_in, int n_nodes, int refine_mode, int keep_inside) {
+    bool all = n_in == n_nodes, any = n_in > 0;
+    if (!refine_mode) return keep_inside ? !any : all;
+    return keep_inside ? !all : any;
+}
+
+struct BoxParams { double lo[3], hi[3]; };
+struct SphereParams { double pos[3], radius; };
+struct CylParams { double p0[3], axis[3], norm, r0, r1; int is_cone; };
+struct PolyParams { const double *poly; int nv; };
+
+template <int DIM>
+__device__ __forceinline__ bool inside(const BoxParams &g, const double (&x)[DIM]) {
+    bool in = true;
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) in &= (x[j] >= g.lo[j]) & (x[j] <= g.hi[j]);
+    return in;
+}
+
+template <int DIM>
+__device__ __forceinline__ bool inside(const SphereParams &g, const double (&x)[DIM]) {
+    double s = 0.0;
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) {
+        double t = x[j] - g.pos[j];
+        s += t * t;
+    }
+    return sqrt(s) <= g.radius;
+}
+
+template <int DIM>
+__device__ __forceinline__ bool inside(const CylParams &g, const double (&x)[DIM]) {
+    static_assert(DIM == 3, "cylinder is 3-D only");
+    double v[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) v[j] = x[j] - g.p0[j];
+    double c0 = g.axis[1] * v[2] - g.axis[2] * v[1];
+    double c1 = g.axis[2] * v[0] - g.axis[0] * v[2];
+    double c2 = g.axis[0] * v[1] - g.axis[1] * v[0];
+    double nd = sqrt(c0 * c0 + c1 * c1 + c2 * c2) / g.norm;
+    double proj = ((v[0] * g.axis[0] + v[1] * g.axis[1]) + v[2] * g.axis[2]) / g.norm;
+    double rad = g.is_cone ? g.r0 + proj / g.norm * (g.r1 - g.r0) : g.r0;
+    return (0.0 <= proj) & (proj <= g.norm) & (nd <= rad);
+}
+
+template <int DIM>
+__device__ __forceinline__ bool inside(const PolyParams &g, const double (&x)[DIM]) {
+    static_assert(DIM == 2, "polygon is 2-D only");
+    const double px = x[0], py = x[1];
+    bool in = false;
+    for (int i = 0; i < g.nv; ++i) {
+        int j = i + 1 == g.nv ? 0 : i + 1;
+        double xi = g.poly[2 * i], yi = g.poly[2 * i + 1], xj = g.poly[2 * j], yj = g.poly[2 * j + 1];
+        double cross = (xj - xi) * (py - yi) - (yj - yi) * (px - xi);
+        if (cross == 0.0 && fmin(xi, xj) <= px && px <= fmax(xi, xj) && fmin(yi, yj) <= py && py <= fmax(yi, yj))
+            return false;   // on the boundary -> not strictly inside
+        if ((yi > py) != (yj > py)) {
+            double xint = xi + (py - yi) * (xj - xi) / (yj - yi);
+            if (px < xint) in = !in;
+        }
+    }
+    return in;
+}
+
+template <int DIM, typename G>
+__global__ void mask_kernel(const double *__restrict__ center, const int32_t *__restrict__ level,
+                            const int32_t *__restrict__ cells, int64_t first, int64_t n, double half_width, G g,
+                            int refine_mode, int keep_inside, uint8_t *__restrict__ invalid) {
+    constexpr int NN = 1 << DIM;
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int64_t cell = cells ? (int64_t)cells[i] : first + i;
+    double off = cell_offset(half_width, level[cell]);
+    double cx[DIM];
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) cx[j] = center[cell * DIM + j];
+    int n_in = 0;
+#pragma unroll
+    for (int c = 0; c < NN; ++c) {
+        double x[DIM];
+#pragma unroll
+        for (int j = 0; j < DIM; ++j) x[j] = cx[j] + dir_comp(DIM, c, j) * off;
+        n_in += inside<DIM>(g, x) ? 1 : 0;
+    }
+    invalid[i] |= combine(n_in, NN, refine_mode, keep_inside);
+}
+
+static int check_mask_args(const void *center, const void *level, int64_t first, int64_t n, int dim, const void *inv,
+                           const char *who) {
+    S3_REQUIRE(dim == 2 || dim == 3, "%s: dim must be 2 or 3", who);
+    S3_REQUIRE(n >= 0 && first >= 0, "%s: bad range", who);
+    S3_REQUIRE(n == 0 || (center && level && inv), "%s: null array", who);
+    return S3_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void commit_batch_kernel(uint8_t *__restrict__ leaf, double *__restrict__ gain,
+                                    const int32_t *__restrict__ parents, int64_t n_par, int64_t first, int64_t n_new,
+                                    const uint8_t *__restrict__ invalid) {
+    int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t < n_par) leaf[parents[t]] = 0;
+    if (t < n_new) {
+        bool bad = invalid && invalid[t];
+        leaf[first + t] = bad ? 0 : 1;
+        if (bad) gain[first + t] = 0.0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// a6: sum of metric^2 over leaves, fixed reduction tree (deterministic for a given range)
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double block_sum_256(double v, double *sh) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0) r = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    return r;
+}
+
+__global__ void __launch_bounds__(256)
+sumsq_partial_kernel(const double *__restrict__ metric, const uint8_t *__restrict__ leaf, int64_t begin, int64_t end,
+                     double *__restrict__ partial) {
+    __shared__ double sh[4];
+    double s = 0.0;
+    for (int64_t i = begin + blockIdx.x * (int64_t)256 + threadIdx.x; i < end; i += (int64_t)gridDim.x * 256)
+        if (leaf[i]) {
+            double m = metric[i];
+            s += m * m;
+        }
+    double r = block_sum_256(s, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+
+__global__ void __launch_bounds__(256) sumsq_final_kernel(const double *__restrict__ partial, int nb, double *__restrict__ out) {
+    __shared__ double sh[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nb; i += 256) s += partial[i];
+    double r = block_sum_256(s, sh);
+    if (threadIdx.x == 0) *out = r;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// a8: top-N by (gain desc, id asc) via a radix select over the 96-bit composite key (orderable gain bits, ~id)
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int SEL_BITS = 12, SEL_BINS = 1 << SEL_BITS, SEL_DIGITS = 8;
+
+struct Key96 { uint64_t hi; uint32_t lo; };
+
+__host__ __device__ __forceinline__ Key96 make_key(double gain, uint32_t id) {
+    uint64_t b;
+#if defined(__HIP_DEVICE_COMPILE__)
+    b = (uint64_t)__double_as_longlong(gain);
+#else
+    memcpy(&b, &gain, 8);
+#endif
+    b = (b >> 63) ? ~b : (b | 0x8000000000000000ull);   // total order of IEEE doubles as unsigned
+    return Key96{b, ~id};
+}
+
+__host__ __device__ __forceinline__ uint32_t key_digit(const Key96 &k, int digit) {
+    int shift = 84 - SEL_BITS * digit;                  // position of the digit's LSB in the 96-bit number
+    if (shift >= 32) return (uint32_t)(k.hi >> (shift - 32)) & (SEL_BINS - 1);
+    uint64_t low64 = (k.hi << 32) | k.lo;
+    return (uint32_t)(low64 >> shift) & (SEL_BINS - 1);
+}
+
+// keep the `nd` most significant digits
+__host__ __device__ __forceinline__ Key96 key_prefix(const Key96 &k, int nd) {
+    int bits = SEL_BITS * nd;
+    Key96 r;
+    if (bits == 0) { r.hi = 0; r.lo = 0; }
+    else if (bits <= 64) { r.hi = bits == 64 ? k.hi : (k.hi & (~0ull << (64 - bits))); r.lo = 0; }
+    else { r.hi = k.hi; r.lo = bits >= 96 ? k.lo : (k.lo & (~0u << (96 - bits))); }
+    return r;
+}
+
+__global__ void __launch_bounds__(256)
+select_hist_kernel(const double *__restrict__ gain, const uint8_t *__restrict__ leaf, int64_t n, Key96 prefix, int nd,
+                   uint32_t *__restrict__ hist) {
+    __shared__ uint32_t sh[SEL_BINS];
+    for (int i = threadIdx.x; i < SEL_BINS; i += 256) sh[i] = 0;
+    __syncthreads();
+    for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        if (!leaf[i]) continue;
+        Key96 k = make_key(gain[i], (uint32_t)i);
+        Key96 p = key_prefix(k, nd);
+        if (p.hi == prefix.hi && p.lo == prefix.lo) atomicAdd(&sh[key_digit(k, nd)], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < SEL_BINS; i += 256)
+        if (sh[i]) atomicAdd(&hist[i], sh[i]);
+}
+
+__global__ void __launch_bounds__(256)
+select_collect_kernel(const double *__restrict__ gain, const uint8_t *__restrict__ leaf, int64_t n, Key96 thr,
+                      int64_t cap, int32_t *__restrict__ out_id, double *__restrict__ out_gain,
+                      unsigned long long *__restrict__ counter) {
+    for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        if (!leaf[i]) continue;
+        double g = gain[i];
+        Key96 k = make_key(g, (uint32_t)i);
+        if (k.hi > thr.hi || (k.hi == thr.hi && k.lo >= thr.lo)) {
+            unsigned long long pos = atomicAdd(counter, 1ull);
+            if ((int64_t)pos < cap) {
+                out_id[pos] = (int32_t)i;
+                out_gain[pos] = g;
+            }
+        }
+    }
+}
+
+}  // namespace s3
+
+using namespace s3;
+
+extern "C" {
+
+int s3_make_children(double *d_center, int32_t *d_level, const int32_t *d_parents, int64_t n_par, int64_t new_index,
+                     int dim, double width, s3_stream stream) {
+    S3_REQUIRE(dim == 2 || dim == 3, "s3_make_children: dim must be 2 or 3");
+    S3_REQUIRE(n_par >= 0 && new_index >= 1, "s3_make_children: bad range");
+    S3_REQUIRE(n_par == 0 || (d_center && d_level && d_parents), "s3_make_children: null array");
+    if (n_par == 0) return S3_OK;
+    const double qw = 0.25 * width;
+    if (dim == 2)
+        make_children_kernel<2><<<grid_for(n_par * 4, 256), 256, 0, as_stream(stream)>>>(d_center, d_level, d_parents,
+                                                                                        n_par, new_index, qw);
+    else
+        make_children_kernel<3><<<grid_for(n_par * 8, 256), 256, 0, as_stream(stream)>>>(d_center, d_level, d_parents,
+                                                                                        n_par, new_index, qw);
+    S3_LAUNCH_CHECK();
+    return S3_OK;
+}
+
+int s3_mask_box(const double *d_center, const int32_t *d_level, const int32_t *d_cells, int64_t first, int64_t n, int dim,
+                double width, const double *h_lo, const double *h_hi, int refine_mode, int keep_inside,
+                uint8_t *d_invalid, s3_stream stream) {
+    if (int rc = check_mask_args(d_center, d_level, first, n, dim, d_invalid, "s3_mask_box")) return rc;
+    S3_REQUIRE(h_lo && h_hi, "s3_mask_box: null bounds");
+    if (n == 0) return S3_OK;
+    BoxParams g{};
+    for (int j = 0; j < dim; ++j) { g.lo[j] = h_lo[j]; g.hi[j] = h_hi[j]; }
+    const double hw = 0.5 * width;
+    if (dim == 2)
+        mask_kernel<2, BoxParams><<<grid_for(n, 256), 256, 0, as_stream(stream)>>>(d_center, d_level, d_cells, first, n,
+                                                                                  hw, g, refine_mode, keep_inside, d_invalid);
+    else
+        mask_kernel<3, BoxParams><<<grid_for(n, 256), 256, 0, as_stream(stream)>>>(d_center, d_level, d_cells, first, n,
+                                                                                  hw, g, refine_mode, keep_inside, d_invalid);
+    S3_LAUNCH_CHECK();
+    return S3_OK;
+}
+
+int s3_mask_sphere(const double *d_center, const int32_t *d_level, const int32_t *d_cells, int64_t first, int64_t n,
+                   int dim, double width, const double *h_pos, double radius, int refine_mode, int keep_inside,
+                   uint8_t *d_invalid, s3_stream stream) {
+    if (int rc = check_mask_args(d_center, d_level, first, n, dim, d_invalid, "s3_mask_sphere")) return rc;
+    S3_REQUIRE(h_pos, "s3_mask_sphere: null position");
+    if (n == 0) return S3_OK;
+    SphereParams g{};
+    for (int j = 0; j < dim; ++j) g.pos[j] = h_pos[j];
+    g.radius = radius;
+    const double hw = 0.5 * width;
+    if (dim == 2)
+        mask_kernel<2, SphereParams><<<grid_for(n, 256), 256, 0, as_stream(stream)>>>(
+            d_center, d_level, d_cells, first, n, hw, g, refine_mode, keep_inside, d_invalid);
+    else
+        mask_kernel<3, SphereParams><<<grid_for(n, 256), 256, 0, as_stream(stream)>>>(
+            d_center, d_level, d_cells, first, n, hw, g, refine_mode, keep_inside, d_invalid);
+    S3_LAUNCH_CHECK();
+    return S3_OK;
+}
+
+int s3_mask_cylinder(const double *d_center, const int32_t *d_level, const int32_t *d_cells, int64_t first, int64_t n,
+                     double width, const double *h_p0, const double *h_axis, double norm, double r0, double r1,
+                     int is_cone, int refine_mode, int keep_inside, uint8_t *d_invalid, s3_stream stream) {
+    if (int rc = check_mask_args(d_center, d_level, first, n, 3, d_invalid, "s3_mask_cylinder")) return rc;
+    S3_REQUIRE(h_p0 && h_axis && norm > 0, "s3_mask_cylinder: bad axis");
+    if (n == 0) return S3_OK;
+    CylParams g{};
+    for (int j = 0; j < 3; ++j) { g.p0[j] = h_p0[j]; g.axis[j] = h_axis[j]; }
+    g.norm = norm; g.r0 = r0; g.r1 = r1; g.is_cone = is_cone;
+    mask_kernel<3, CylParams><<<grid_for(n, 256), 256, 0, as_stream(stream)>>>(d_center, d_level, d_cells, first, n,
+                                                                              0.5 * width, g, refine_mode, keep_inside,
+                                                                              d_invalid);
+    S3_LAUNCH_CHECK();
+    return S3_OK;
+}
+
+int s3_mask_polygon(const double *d_center, const int32_t *d_level, const int32_t *d_cells, int64_t first, int64_t n,
+                    double width, const double *d_poly, int nv, int refine_mode, int keep_inside, uint8_t *d_invalid,
+                    s3_stream stream) {
+    if (int rc = check_mask_args(d_center, d_level, first, n, 2, d_invalid, "s3_mask_polygon")) return rc;
+    S3_REQUIRE(d_poly && nv >= 3, "s3_mask_polygon: need >= 3 vertices");
+    if (n == 0) return S3_OK;
+    PolyParams g{d_poly, nv};
+    mask_kernel<2, PolyParams><<<grid_for(n, 256), 256, 0, as_stream(stream)>>>(d_center, d_level, d_cells, first, n,
+                                                                               0.5 * width, g, refine_mode, keep_inside,
+                                                                               d_invalid);
+    S3_LAUNCH_CHECK();
+    return S3_OK;
+}
+
+int s3_commit_batch(uint8_t *d_leaf, double *d_gain, const int32_t *d_parents, int64_t n_par, int64_t first,
+                    int64_t n_new, const uint8_t *d_invalid, s3_stream stream) {
+    S3_REQUIRE(n_par >= 0 && n_new >= 0 && first >= 0, "s3_commit_batch: bad range");
+    S3_REQUIRE(d_leaf && d_gain && (n_par == 0 || d_parents), "s3_commit_batch: null array");
+    int64_t n = std::max(n_par, n_new);
+    if (n == 0) return S3_OK;
+    commit_batch_kernel<<<grid_for(n, 256), 256, 0, as_stream(stream)>>>(d_leaf, d_gain, d_parents, n_par, first, n_new,
+                                                                        d_invalid);
+    S3_LAUNCH_CHECK();
+    return S3_OK;
+}
+
+int s3_sumsq_leaf(const double *d_metric, const uint8_t *d_leaf, int64_t begin, int64_t end, double *d_out,
+                  double *d_scratch, s3_stream stream) {
+    S3_REQUIRE(d_metric && d_leaf && d_out && d_scratch, "s3_sumsq_leaf: null array");
+    S3_REQUIRE(begin >= 0 && end >= begin, "s3_sumsq_leaf: bad range");
+    int nb = (int)std::min<int64_t>(1024, std::max<int64_t>(1, (end - begin + 1023) / 1024));
+    sumsq_partial_kernel<<<nb, 256, 0, as_stream(stream)>>>(d_metric, d_leaf, begin, end, d_scratch);
+    sumsq_final_kernel<<<1, 256, 0, as_stream(stream)>>>(d_scratch, nb, d_out);
+    S3_LAUNCH_CHECK();
+    return S3_OK;
+}
+
+size_t s3_topn_scratch_bytes(int64_t n_cells, int64_t n_top) {
+    (void)n_cells;
+    if (n_top < 1) n_top = 1;
+    return sizeof(uint32_t) * SEL_BINS + 64 + (size_t)n_top * (sizeof(int32_t) + sizeof(double)) + 64;
+}
+
+int s3_topn_leaf(const double *d_gain, const uint8_t *d_leaf, int64_t n_cells, int64_t n_top, int32_t *h_out,
+                 int64_t *h_count, void *d_scratch, s3_stream stream) {
+    S3_REQUIRE(d_gain && d_leaf && h_out && h_count && d_scratch, "s3_topn_leaf: null argument");
+    S3_REQUIRE(n_cells >= 0 && n_cells < ((int64_t)1 << 31) && n_top >= 0, "s3_topn_leaf: bad sizes");
+    *h_count = 0;
+    if (n_cells == 0 || n_top == 0) return S3_OK;
+    hipStream_t st = as_stream(stream);
+    char *base = static_cast<char *>(d_scratch);
+    uint32_t *d_hist = reinterpret_cast<uint32_t *>(base);
+    unsigned long long *d_counter = reinterpret_cast<unsigned long long *>(base + sizeof(uint32_t) * SEL_BINS);
+    double *d_og = reinterpret_cast<double *>(base + sizeof(uint32_t) * SEL_BINS + 64);
+    int32_t *d_oi = reinterpret_cast<int32_t *>(base + sizeof(uint32_t) * SEL_BINS + 64 + sizeof(double) * n_top);
+    unsigned grid = grid_for(n_cells, 256, 2048);
+
+    std::vector<uint32_t> hist(SEL_BINS);
+    Key96 prefix{0, 0};
+    int64_t need = n_top;        // how many still to take from the current prefix class
+    Key96 thr{0, 0};             // keys >= thr are selected
+    bool take_all = false;
+    for (int d = 0; d < SEL_DIGITS; ++d) {
+        S3_HIP_CHECK(hipMemsetAsync(d_hist, 0, sizeof(uint32_t) * SEL_BINS, st));
+        select_hist_kernel<<<grid, 256, 0, st>>>(d_gain, d_leaf, n_cells, prefix, d, d_hist);
+        S3_LAUNCH_CHECK();
+        S3_HIP_CHECK(hipMemcpyAsync(hist.data(), d_hist, sizeof(uint32_t) * SEL_BINS, hipMemcpyDeviceToHost, st));
+        S3_HIP_CHECK(hipStreamSynchronize(st));
+        int64_t total = 0;
+        for (int b = 0; b < SEL_BINS; ++b) total += hist[b];
+        if (d == 0 && total <= need) {   // fewer leaves than requested: take everything
+            take_all = true;
+            break;
+        }
+        int64_t acc = 0;
+        int b = SEL_BINS - 1;
+        for (; b >= 0; --b) {
+            if (acc + hist[b] >= need) break;
+            acc += hist[b];
+        }
+        // bins above b are taken entirely; from bin b we still need (need - acc) of hist[b]
+        need -= acc;
+        int shift = 84 - SEL_BITS * d;
+        if (shift >= 32) prefix.hi |= (uint64_t)b << (shift - 32);
+        else {
+            uint64_t low64 = (uint64_t)b << shift;      // bits 0..43
+            prefix.hi |= low64 >> 32;
+            prefix.lo |= (uint32_t)low64;
+        }
+        thr = prefix;
+        if ((int64_t)hist[b] == need) break;            // the whole bin is taken: threshold = this prefix
+    }
+    if (take_all) thr = Key96{0, 0};
+
+    S3_HIP_CHECK(hipMemsetAsync(d_counter, 0, sizeof(unsigned long long), st));
+    select_collect_kernel<<<grid, 256, 0, st>>>(d_gain, d_leaf, n_cells, thr, n_top, d_oi, d_og, d_counter);
+    S3_LAUNCH_CHECK();
+    unsigned long long cnt = 0;
+    S3_HIP_CHECK(hipMemcpyAsync(&cnt, d_counter, sizeof(cnt), hipMemcpyDeviceToHost, st));
+    S3_HIP_CHECK(hipStreamSynchronize(st));
+    if ((int64_t)cnt > n_top) {
+        s3::set_error("s3_topn_leaf: internal selection error (%llu > %lld)", cnt, (long long)n_top);
+        return S3_EHIP;
+    }
+    std::vector<int32_t> ids(cnt);
+    std::vector<double> gs(cnt);
+    if (cnt) {
+        S3_HIP_CHECK(hipMemcpyAsync(ids.data(), d_oi, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, st));
+        S3_HIP_CHECK(hipMemcpyAsync(gs.data(), d_og, sizeof(double) * cnt, hipMemcpyDeviceToHost, st));
+        S3_HIP_CHECK(hipStreamSynchronize(st));
+    }
+    std::vector<int32_t> order(cnt);
+    for (size_t i = 0; i < cnt; ++i) order[i] = (int32_t)i;
+    std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
+        Key96 ka = make_key(gs[a], (uint32_t)ids[a]), kb = make_key(gs[b], (uint32_t)ids[b]);
+        return ka.hi > kb.hi || (ka.hi == kb.hi && ka.lo > kb.lo);
+    });
+    for (size_t i = 0; i < cnt; ++i) h_out[i] = ids[order[i]];
+    *h_count = (int64_t)cnt;
+    return S3_OK;
+}
+
+}  // extern "C"

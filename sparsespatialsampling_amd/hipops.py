@@ -1,0 +1,192 @@
+"""
+Thin Python front-end of the libs3hip.so C ABI (include/s3hip.h).
+
+torch is used here only as plumbing: device memory (``torch.empty(..., device="cuda")``), host<->device copies and the
+current HIP stream.  Every function below ends in exactly one hand-written HIP kernel family of libs3hip.so; no torch
+operator runs on the hot path.  All tensors passed in must live on the current CUDA(HIP) device and be contiguous.
+"""
+import ctypes as C
+
+import numpy as np
+import torch as pt
+
+from . import _lib
+from ._lib import check
+
+DTYPE_CODE = {pt.float32: 0, pt.float64: 1}
+
+
+def _stream():
+    return C.c_void_p(pt.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    if t is None:
+        return C.c_void_p(0)
+    assert t.is_cuda and t.is_contiguous(), "device-resident contiguous tensor required"
+    return C.c_void_p(t.data_ptr())
+
+
+def _host_f64(values, n=3):
+    a = np.zeros(n, dtype=np.float64)
+    v = np.asarray(values, dtype=np.float64).ravel()
+    a[:len(v)] = v
+    return a
+
+
+def device():
+    """The torch device of the hot path; raises HipUnavailableError when there is none (no CPU fallback)."""
+    _lib.require_device()
+    if not pt.cuda.is_available():
+        raise _lib.HipUnavailableError("torch sees no HIP device; it is needed for device memory and streams.")
+    return pt.device("cuda", pt.cuda.current_device())
+
+
+def to_device(x, dtype=None):
+    """numpy / CPU tensor / CUDA tensor -> contiguous CUDA tensor (optionally cast)."""
+    if isinstance(x, np.ndarray):
+        x = pt.from_numpy(np.ascontiguousarray(x))
+    if dtype is not None and x.dtype != dtype:
+        x = x.to(dtype)
+    return x.to(device(), non_blocking=False).contiguous()
+
+
+class KnnIndex:
+    """Bucket-grid KNN index over the original CFD points (replaces sklearn's kd-tree, s_cube.py:161-163,
+    export.py:120,423)."""
+
+    def __init__(self, points, target_occupancy=0.0):
+        pts = to_device(points, pt.float64)
+        assert pts.dim() == 2 and pts.shape[1] in (2, 3), "points must be [N, 2|3]"
+        self.n, self.dim = int(pts.shape[0]), int(pts.shape[1])
+        self._handle = C.c_void_p(0)
+        check(_lib.hip_lib().s3_knn_create(_ptr(pts), self.n, self.dim, float(target_occupancy), _stream(),
+                                           C.byref(self._handle)), "s3_knn_create")
+        self._has_values = False
+
+    def close(self):
+        if getattr(self, "_handle", None) is not None and self._handle.value:
+            _lib.hip_lib().s3_knn_destroy(self._handle)
+            self._handle = C.c_void_p(0)
+
+    __del__ = close
+
+    def set_values(self, y):
+        y = to_device(y, pt.float64)
+        assert y.numel() == self.n
+        check(_lib.hip_lib().s3_knn_set_values(self._handle, _ptr(y), _stream()), "s3_knn_set_values")
+        pt.cuda.current_stream().synchronize()      # y may be freed by the caller
+        self._has_values = True
+
+    def query(self, q, k):
+        """-> (idx int32 [nq,k], dist f64 [nq,k]) on the device, ascending in (dist, idx)."""
+        q = to_device(q, pt.float64)
+        nq = int(q.shape[0])
+        idx = pt.empty((nq, k), dtype=pt.int32, device=q.device)
+        dist = pt.empty((nq, k), dtype=pt.float64, device=q.device)
+        check(_lib.hip_lib().s3_knn_query(self._handle, _ptr(q), nq, int(k), _ptr(idx), _ptr(dist), _stream()),
+              "s3_knn_query")
+        return idx, dist
+
+    def predict(self, q, k):
+        q = to_device(q, pt.float64)
+        nq = int(q.shape[0])
+        out = pt.empty(nq, dtype=pt.float64, device=q.device)
+        check(_lib.hip_lib().s3_idw_predict(self._handle, _ptr(q), nq, int(k), _ptr(out), _stream()), "s3_idw_predict")
+        return out
+
+    @property
+    def handle(self):
+        return self._handle
+
+
+def idw_weights(dist):
+    w = pt.empty_like(dist)
+    check(_lib.hip_lib().s3_idw_weights(_ptr(dist), int(dist.shape[0]), int(dist.shape[1]), _ptr(w), _stream()),
+          "s3_idw_weights")
+    return w
+
+
+def interp(w, idx, data, out=None):
+    """out[c, ...] = sum_m w[c,m] * data[idx[c,m], ...]   (export.py:446-468).  w f64 [nc,k], idx int32 [nc,k],
+    data f32/f64 [n_src, ...] -- all on the device; returns f64 [nc, ...] on the device."""
+    assert w.dtype == pt.float64 and idx.dtype == pt.int32 and data.dtype in DTYPE_CODE
+    nc, k = int(w.shape[0]), int(w.shape[1])
+    n_src = int(data.shape[0])
+    row_len = int(np.prod(data.shape[1:])) if data.dim() > 1 else 1
+    if out is None:
+        out = pt.empty((nc,) + tuple(data.shape[1:]), dtype=pt.float64, device=data.device)
+    check(_lib.hip_lib().s3_interp(_ptr(w), _ptr(idx), nc, k, _ptr(data), DTYPE_CODE[data.dtype], n_src, row_len,
+                                   _ptr(out), _stream()), "s3_interp")
+    return out
+
+
+# ---- refine kernels on the device-resident cell arrays ----------------------------------------------------------
+def make_children(center, level, parents, new_index, width):
+    dim = int(center.shape[1])
+    check(_lib.hip_lib().s3_make_children(_ptr(center), _ptr(level), _ptr(parents), int(parents.numel()),
+                                          int(new_index), dim, float(width), _stream()), "s3_make_children")
+
+
+def child_gain(knn, k, center, level, first, n, width, level_factor, gain0, metric, gain, scratch):
+    dim = int(center.shape[1])
+    check(_lib.hip_lib().s3_child_gain(knn.handle, int(k), _ptr(center), _ptr(level), int(first), int(n), dim,
+                                       float(width), _ptr(level_factor), float(gain0), _ptr(metric), _ptr(gain),
+                                       _ptr(scratch), _stream()), "s3_child_gain")
+
+
+def mask_box(center, level, cells, first, n, width, lo, hi, refine_mode, keep_inside, invalid):
+    dim = int(center.shape[1])
+    lo, hi = _host_f64(lo), _host_f64(hi)
+    check(_lib.hip_lib().s3_mask_box(_ptr(center), _ptr(level), _ptr(cells), int(first), int(n), dim, float(width),
+                                     lo.ctypes.data_as(C.c_void_p), hi.ctypes.data_as(C.c_void_p), int(refine_mode),
+                                     int(keep_inside), _ptr(invalid), _stream()), "s3_mask_box")
+
+
+def mask_sphere(center, level, cells, first, n, width, pos, radius, refine_mode, keep_inside, invalid):
+    dim = int(center.shape[1])
+    pos = _host_f64(pos)
+    check(_lib.hip_lib().s3_mask_sphere(_ptr(center), _ptr(level), _ptr(cells), int(first), int(n), dim, float(width),
+                                        pos.ctypes.data_as(C.c_void_p), float(radius), int(refine_mode),
+                                        int(keep_inside), _ptr(invalid), _stream()), "s3_mask_sphere")
+
+
+def mask_cylinder(center, level, cells, first, n, width, p0, axis, norm, r0, r1, is_cone, refine_mode, keep_inside,
+                  invalid):
+    p0, axis = _host_f64(p0), _host_f64(axis)
+    check(_lib.hip_lib().s3_mask_cylinder(_ptr(center), _ptr(level), _ptr(cells), int(first), int(n), float(width),
+                                          p0.ctypes.data_as(C.c_void_p), axis.ctypes.data_as(C.c_void_p), float(norm),
+                                          float(r0), float(r1), int(is_cone), int(refine_mode), int(keep_inside),
+                                          _ptr(invalid), _stream()), "s3_mask_cylinder")
+
+
+def mask_polygon(center, level, cells, first, n, width, poly_dev, refine_mode, keep_inside, invalid):
+    check(_lib.hip_lib().s3_mask_polygon(_ptr(center), _ptr(level), _ptr(cells), int(first), int(n), float(width),
+                                         _ptr(poly_dev), int(poly_dev.shape[0]), int(refine_mode), int(keep_inside),
+                                         _ptr(invalid), _stream()), "s3_mask_polygon")
+
+
+def commit_batch(leaf, gain, parents, first, n_new, invalid):
+    n_par = int(parents.numel()) if parents is not None else 0
+    check(_lib.hip_lib().s3_commit_batch(_ptr(leaf), _ptr(gain), _ptr(parents), n_par, int(first), int(n_new),
+                                         _ptr(invalid), _stream()), "s3_commit_batch")
+
+
+def sumsq_leaf(metric, leaf, begin, end, out, scratch):
+    check(_lib.hip_lib().s3_sumsq_leaf(_ptr(metric), _ptr(leaf), int(begin), int(end), _ptr(out), _ptr(scratch),
+                                       _stream()), "s3_sumsq_leaf")
+
+
+def topn_leaf(gain, leaf, n_cells, n_top, scratch):
+    """-> numpy int32 ids ordered like heapq.nlargest(n_top, leaves, key=(gain, -id))  (s_cube.py:601-602)."""
+    out = np.empty(max(int(n_top), 1), dtype=np.int32)
+    cnt = C.c_int64(0)
+    check(_lib.hip_lib().s3_topn_leaf(_ptr(gain), _ptr(leaf), int(n_cells), int(n_top),
+                                      out.ctypes.data_as(C.c_void_p), C.byref(cnt), _ptr(scratch), _stream()),
+          "s3_topn_leaf")
+    return out[:cnt.value]
+
+
+def topn_scratch(n_cells, n_top, dev):
+    nbytes = _lib.hip_lib().s3_topn_scratch_bytes(int(n_cells), int(n_top))
+    return pt.empty((nbytes + 7) // 8, dtype=pt.float64, device=dev)

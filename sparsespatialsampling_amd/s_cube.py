@@ -1,0 +1,657 @@
+"""
+Sparse spatial sampling (S^3) grid generation for 2-D / 3-D CFD data -- MI355X-native drop-in for the reference's
+``sparseSpatialSampling/s_cube.py`` (class ``SamplingTree``, reference lines 86-1692).
+
+Division of labour:
+
+* **HBM / HIP kernels** (``tree_backend.HipTreeBackend`` -> libs3hip.so): KNN index over the original points, child
+  centres, inverse-distance metric prediction at every new cell centre and its 2^d candidate child centres, the gain,
+  the geometry predicates, the captured-metric reduction and the top-N gain selection.
+* **host, native** (``csrc/topology.cpp`` -> libs3topo.so): neighbour links, shared-node numbering, renumbering.
+* **host, Python** (this file): the control flow of ``refine()`` and -- deliberately -- every ``set`` the reference
+  uses, because the ids of new cells follow CPython's set iteration order (hard part 1).  Using
+  the same set operations in the same sequence reproduces the reference's cell numbering bit for bit.
+
+The reference rejects nothing on the CPU; this implementation has no CPU compute path: constructing a
+``SamplingTree`` without a HIP device raises ``HipUnavailableError``.
+"""
+import ctypes as C
+import logging
+from time import time
+from typing import Union
+
+import numpy as np
+import torch as pt
+
+from . import _lib
+
+logger = logging.getLogger(__name__)
+logging.basicConfig(level=logging.INFO, format='[%(asctime)s] %(levelname)-8s %(message)s', datefmt='%Y-%m-%d %H:%M:%S',
+                    force=True)
+
+# the reference switches torch to float64 globally when its modules are imported (s_cube.py:19, export.py:23); user
+# scripts written against it rely on that
+pt.set_default_dtype(pt.float64)
+
+# neighbour slots and child / node positions (reference s_cube.py:22-29)
+NB = {
+    "w": 0, "nw": 1, "n": 2, "ne": 3, "e": 4, "se": 5, "s": 6, "sw": 7,
+    "wl": 8, "nwl": 9, "nl": 10, "nel": 11, "el": 12, "sel": 13, "sl": 14, "swl": 15, "cl": 16,
+    "wu": 17, "nwu": 18, "nu": 19, "neu": 20, "eu": 21, "seu": 22, "su": 23, "swu": 24, "cu": 25
+}
+CH = {"swu": 0, "nwu": 1, "neu": 2, "seu": 3, "swl": 4, "nwl": 5, "nel": 6, "sel": 7}
+
+
+def _make_backend(vertices, target, k):
+    """The compute backend of the product: HIP kernels on MI355X, nothing else."""
+    from .tree_backend import HipTreeBackend
+    return HipTreeBackend(vertices, target, k)
+
+
+class _Topology:
+    """numpy-facing wrapper of the native topology engine (csrc/topology.cpp)."""
+
+    def __init__(self, dim, width, root_center):
+        self._lib = _lib.topo_lib()
+        self.dim, self.nch, self.nnb = dim, 2 ** dim, 8 if dim == 2 else 26
+        rc = np.ascontiguousarray(root_center, dtype=np.float64)
+        self._h = C.c_void_p(self._lib.s3t_create(dim, float(width), rc.ctypes.data_as(C.c_void_p)))
+        assert self._h.value, "topology engine: bad dimension"
+
+    def close(self):
+        if self._h is not None and self._h.value:
+            self._lib.s3t_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    @property
+    def n_cells(self):
+        return self._lib.s3t_n_cells(self._h)
+
+    @property
+    def n_nodes(self):
+        return self._lib.s3t_n_nodes(self._h)
+
+    def _view(self, fn, dtype, shape):
+        ptr = fn(self._h)
+        n = int(np.prod(shape))
+        if n == 0:
+            return np.zeros(shape, dtype=dtype)
+        buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr)
+        return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+    # views are valid until the next refine() call
+    @property
+    def level(self):
+        return self._view(self._lib.s3t_level, np.int32, (self.n_cells,))
+
+    @property
+    def parent(self):
+        return self._view(self._lib.s3t_parent, np.int32, (self.n_cells,))
+
+    @property
+    def first_child(self):
+        return self._view(self._lib.s3t_first_child, np.int32, (self.n_cells,))
+
+    @property
+    def nb(self):
+        return self._view(self._lib.s3t_nb, np.int32, (self.n_cells, self.nnb))
+
+    @property
+    def node_idx(self):
+        return self._view(self._lib.s3t_node_idx, np.int64, (self.n_cells, self.nch))
+
+    @property
+    def center(self):
+        return self._view(self._lib.s3t_center, np.float64, (self.n_cells, self.dim))
+
+    @property
+    def nodes(self):
+        return self._view(self._lib.s3t_nodes, np.float64, (self.n_nodes, self.dim))
+
+    @staticmethod
+    def _ids(a):
+        return np.ascontiguousarray(a, dtype=np.int64)
+
+    def refine(self, parents, relink):
+        p = self._ids(parents)
+        first = self._lib.s3t_refine(self._h, p.ctypes.data_as(C.c_void_p), len(p), int(relink))
+        if first < 0:
+            raise RuntimeError("topology engine: tried to refine a cell that is not a leaf")
+        return first
+
+    def relink_parent_of(self, cells):
+        c = self._ids(cells)
+        self._lib.s3t_relink_parent_of(self._h, c.ctypes.data_as(C.c_void_p), len(c))
+
+    def mark_invalid(self, cells):
+        c = self._ids(cells)
+        self._lib.s3t_mark_invalid(self._h, c.ctypes.data_as(C.c_void_p), len(c))
+
+    def check_nb(self, cell):
+        out = np.empty(self.nnb, dtype=np.int64)
+        n = self._lib.s3t_check_nb(self._h, int(cell), out.ctypes.data_as(C.c_void_p))
+        return out[:n].tolist()
+
+    def finalize(self):
+        n_nodes = C.c_int64(0)
+        n_leaf = self._lib.s3t_finalize(self._h, C.byref(n_nodes))
+        faces = self._view(self._lib.s3t_face_ids, np.int64, (n_leaf, self.nch)).copy()
+        nodes = self._view(self._lib.s3t_unique_nodes, np.float64, (n_nodes.value, self.dim)).copy()
+        return faces, nodes
+
+
+class Cell(object):
+    """Read-only view of one cell with the attribute names of the reference's ``Cell`` (s_cube.py:32-83).  The tree
+    itself is stored as arrays; views are created on demand (``tree._cells[i]``)."""
+
+    def __init__(self, tree, index):
+        self._tree = tree
+        self.index = int(index)
+
+    @property
+    def level(self):
+        return int(self._tree._topo.level[self.index])
+
+    @property
+    def center(self):
+        return pt.from_numpy(self._tree._topo.center[self.index].copy())
+
+    @property
+    def parent(self):
+        p = int(self._tree._topo.parent[self.index])
+        return None if p < 0 else Cell(self._tree, p)
+
+    @property
+    def children(self):
+        fc = int(self._tree._topo.first_child[self.index])
+        if fc == -1:
+            return None
+        if fc == -2:
+            return []
+        return tuple(Cell(self._tree, fc + c) for c in range(self._tree._topo.nch))
+
+    @property
+    def nb(self):
+        return [None if n < 0 else Cell(self._tree, n) for n in self._tree._topo.nb[self.index].tolist()]
+
+    @property
+    def node_idx(self):
+        return self._tree._topo.node_idx[self.index].tolist()
+
+    @property
+    def metric(self):
+        return self._tree._cell_values()["metric"][self.index]
+
+    @property
+    def gain(self):
+        return self._tree._cell_values()["gain"][self.index]
+
+    def leaf_cell(self) -> bool:
+        return self.children is None
+
+
+class _CellList:
+    def __init__(self, tree):
+        self._tree = tree
+
+    def __len__(self):
+        return self._tree._topo.n_cells
+
+    def __getitem__(self, i):
+        n = len(self)
+        if isinstance(i, slice):
+            return [Cell(self._tree, j) for j in range(*i.indices(n))]
+        if i < 0:
+            i += n
+        if not 0 <= i < n:
+            raise IndexError(i)
+        return Cell(self._tree, i)
+
+    def __iter__(self):
+        return (Cell(self._tree, i) for i in range(len(self)))
+
+
+class SamplingTree(object):
+    def __init__(self, vertices: pt.Tensor, target: pt.Tensor, geometry_obj: list, n_cells: int = None,
+                 uniform_level: int = 5, min_metric: float = 0.75, max_delta_level: bool = False,
+                 n_cells_iter_start: int = None, n_cells_iter_end: int = None, n_jobs: int = 1,
+                 relTol: Union[int, float] = 1e-3, reach_at_least: float = 0.75, pre_select: bool = False):
+        """Same arguments as the reference (s_cube.py:87-132).  ``n_jobs`` is accepted for compatibility; the work
+        runs on the GPU."""
+        from multiprocessing import cpu_count
+        self._pre_select = pre_select
+        self._n_jobs = n_jobs if n_jobs is not None else cpu_count()
+        self._max_delta_level = max_delta_level
+        self._geometry = geometry_obj
+        self._n_cells = 0
+        self._min_metric = min_metric
+        self._n_cells_max = n_cells
+        self._min_level = uniform_level
+        self._current_min_level = 0
+        self._current_max_level = 0
+        # cells refined per iteration: 0.1 % of the original grid (s_cube.py:147-154)
+        n_orig = vertices.size(0)
+        self._cells_per_iter_start = int(0.001 * n_orig) if n_cells_iter_start is None else n_cells_iter_start
+        if self._cells_per_iter_start <= 0:
+            self._cells_per_iter_start = 1
+        self._cells_per_iter_end = self._cells_per_iter_start if n_cells_iter_end is None else n_cells_iter_end
+        self._cells_per_iter = self._cells_per_iter_start
+        self._cells_per_iter_last = 1e9
+        self._reach_at_least = reach_at_least
+        self._width = None
+        self._n_dimensions = vertices.size(-1)
+        self._k = 8 if self._n_dimensions == 2 else 26
+        self._leaf_cells = set()
+        self._n_cells_after_uniform = None
+        self._N_cells_per_iter = []
+        self.all_nodes = []
+        self.all_centers = []
+        self.all_levels = None
+        self.face_ids = None
+        self._metric = []
+        self._n_cells_log = []
+        self._n_cells_orig = target.size(0)
+        self.data_final_mesh = {}
+        self._times = _initialize_time_dict()
+        if relTol is None:
+            self._relTol = 1e-3 if n_cells is None else 10
+        else:
+            self._relTol = relTol
+        self._print_settings()
+
+        # KNN index + metric go to the device (replaces KNeighborsRegressor.fit, s_cube.py:161-163)
+        self._backend = _make_backend(vertices.detach().cpu().to(pt.float64).numpy(),
+                                      target.detach().cpu().to(pt.float64).numpy(), self._k)
+        self._values = None
+        self._topo = None
+        self._cells = _CellList(self)
+        self._create_first_cell()
+        self._target_norm = pt.linalg.norm(target.detach().cpu().to(pt.float64)).item()
+
+    # ------------------------------------------------------------------------------------------------------------
+    def _create_first_cell(self) -> None:
+        """root cell from the ``keep_inside`` geometry (s_cube.py:338-397)"""
+        middle_ = None
+        for g in self._geometry:
+            if g.keep_inside:
+                self._width = g.main_width
+                middle_ = g.center
+            if g.center.size(0) != self._n_dimensions:
+                raise ValueError(f"The number of dimensions for geometry object '{g.name}' with dim = {g.center.size(0)} "
+                                 f"is not matching the number of dimensions within the CFD grid with dim = "
+                                 f"{self._n_dimensions}.")
+        if middle_ is None:
+            raise ValueError("No GeometryObject with 'keep_inside=True', representing the numerical domain, was found.")
+
+        nd = self._n_dimensions
+        dirs = _directions(nd)
+        root = middle_.detach().cpu().type(pt.float64).numpy()
+        queries = np.repeat(root[None, :], 2 ** nd + 1, axis=0)
+        queries[1:, :] += dirs * 0.25 * self._width
+        metric = self._backend.predict(queries)
+
+        # gain of the root: (width/2)^d * sum |m0 - mi|, accumulated like Python's sum() (s_cube.py:375-381)
+        sum_distances = sum([abs(metric[0] - metric[i]) for i in range(1, len(metric))])
+        gain = pow(self._width / 2, nd) * sum_distances
+        if abs(gain - 0) < 1e-6:
+            gain = 1.0
+        self._gain0 = float(gain)
+        self._n_cells += 1
+        self._topo = _Topology(nd, self._width, root)
+        self._backend.start(root, self._width, self._gain0, metric[0], self._gain0)
+        self._leaf_cells.add(0)
+
+    def _cell_values(self):
+        """metric / gain of all cells on the host (lazy download; used by the ``Cell`` views and the oracle tests)"""
+        if self._values is None or len(self._values["metric"]) != self._topo.n_cells:
+            self._values = self._backend.download(self._topo.n_cells)
+        return self._values
+
+    def _update_leaf_cells(self, idx_parents: set, idx_children: set) -> None:
+        self._leaf_cells -= idx_parents
+        self._leaf_cells.update(idx_children)
+
+    def _update_min_ref_level(self) -> None:
+        level = self._topo.level
+        leaves = np.fromiter(self._leaf_cells, dtype=np.int64, count=len(self._leaf_cells))
+        self._current_min_level = max(self._current_min_level, int(level[leaves].min()))
+
+    def _check_stopping_criteria(self) -> bool:
+        """True = keep refining (s_cube.py:263-284)"""
+        if self._n_cells_max is None:
+            if len(self._metric) > 1 and self._metric[-1] / self._min_metric >= self._reach_at_least:
+                return self._metric[-1] < self._min_metric and abs(self._metric[-1] - self._metric[-2]) > self._relTol
+        else:
+            if len(self._leaf_cells) / self._n_cells_max >= self._reach_at_least:
+                _relStop = abs(self._cells_per_iter / self._n_cells_max - self._cells_per_iter_last / self._n_cells_max)
+                return len(self._leaf_cells) < self._n_cells_max and _relStop > self._relTol
+        return True
+
+    def _compute_n_cells_per_iter(self) -> None:
+        """linear ramp of the batch size between start and end value (s_cube.py:286-315)"""
+        if self._n_cells_max is None:
+            _delta_x = self._min_metric - self._metric[0]
+            _current_x = self._metric[-1]
+        else:
+            _delta_x = self._n_cells_max - self._n_cells_after_uniform
+            _current_x = self._n_cells
+        _delta_y = self._cells_per_iter_start - self._cells_per_iter_end
+        _new = self._cells_per_iter_start - (_delta_y / _delta_x) * _current_x
+        self._cells_per_iter_last = self._cells_per_iter
+        self._cells_per_iter = int(_new) if _new > 1 else 1
+
+    def _compute_captured_metric(self) -> bool:
+        """||metric at the leaf centres||_2 / ||target||_2 (s_cube.py:317-336).  Each leaf's prediction was stored
+        when the cell was created (the reference recomputes the identical values); the sum of squares is one device
+        reduction.  Multi-GPU runs split the reduction range across ranks and all-reduce (parallel.py)."""
+        from . import parallel
+        sumsq = parallel.allreduce_sumsq(self._backend, self._topo.n_cells)
+        _ratio = float(np.sqrt(sumsq)) / self._target_norm
+        self._metric.append(_ratio)
+        return _ratio < self._min_metric
+
+    # ------------------------------------------------------------------------------------------------------------
+    def _refine_batch(self, order: np.ndarray, uniform: bool):
+        """create the children of the ordered parents: topology on the host, geometry + metric + gain on the device
+        (body shared by s_cube.py:531-555 and 879-900).  Returns (first new id, number of new cells)."""
+        nch = 2 ** self._n_dimensions
+        first = self._topo.refine(order, relink=uniform)
+        n_new = self._backend.refine_batch(order, first)
+        assert n_new == len(order) * nch and self._topo.n_cells == first + n_new
+        self._n_cells += n_new
+        self._values = None
+        return first, n_new
+
+    def _refine_uniform(self) -> None:
+        """level-synchronous refinement of all leaves (s_cube.py:508-561)"""
+        logger.info("Starting uniform refinement.")
+        self._times["t_start_uniform"] = time()
+        for j in range(self._min_level):
+            logger.info(f"\r\tStarting iteration no. {j}, N_cells = {len(self._leaf_cells)}")
+            order = np.fromiter(self._leaf_cells, dtype=np.int64, count=len(self._leaf_cells))
+            all_parents, all_children = set(), set()
+            all_parents.update(order.tolist())
+            first, n_new = self._refine_batch(order, uniform=True)
+            all_children.update(range(first, first + n_new))
+            self._update_leaf_cells(all_parents, all_children)
+            self._current_min_level += 1
+            self._current_max_level += 1
+            self._remove_invalid_cells(set(range(first, first + n_new)), _batch=(first, n_new))
+        logger.info("Finished uniform refinement.")
+        self._times["t_end_uniform"] = time()
+
+    def _refine_cells(self, to_refine: set):
+        """s_cube.py:865-902; returns the id range of the new cells"""
+        order = np.fromiter(to_refine, dtype=np.int64, count=len(to_refine))
+        all_parents, all_children = set(), set()
+        all_parents.update(order.tolist())
+        first, n_new = self._refine_batch(order, uniform=False)
+        all_children.update(range(first, first + n_new))
+        if len(order):
+            self._current_max_level = max(self._current_max_level, int(self._topo.level[order].max()) + 1)
+        self._update_leaf_cells(all_parents, all_children)
+        return first, n_new
+
+    def _remove_invalid_cells(self, _refined_cells: set, _refine_geometry: bool = False,
+                              _geometry_no: Union[int, list] = None, _batch=None) -> Union[None, set]:
+        """geometry verdict for the listed cells (s_cube.py:669-732).  ``_batch=(first, n)`` marks the call that
+        follows a refine batch: the flags then also finish the batch's bookkeeping on the device."""
+        if type(_geometry_no) is int:
+            _geometry_no = [_geometry_no]
+        _geometries = [self._geometry[g] for g in _geometry_no] if _geometry_no is not None else self._geometry
+
+        order = np.fromiter(_refined_cells, dtype=np.int64, count=len(_refined_cells))
+        if self._pre_select:
+            # reference quirk (s_cube.py:1832-1836): with pre_select the `elif` never runs, no cell is ever flagged
+            flags = np.zeros(len(order), dtype=bool)
+            if _batch is not None:
+                self._backend.commit(_batch[0], _batch[1], use_invalid=False)
+        elif _batch is not None:
+            flags_range = self._backend.mask(_geometries, int(_refine_geometry), first=_batch[0], n=_batch[1])
+            self._backend.commit(_batch[0], _batch[1], use_invalid=True)
+            flags = flags_range[order - _batch[0]]
+        else:
+            flags = self._backend.mask(_geometries, int(_refine_geometry), cells=order)
+
+        # set(filter(None, result)): insertion in iteration order, id 0 and None dropped (s_cube.py:709)
+        _idx = set(i for i in order[flags].tolist() if i)
+        if _idx == set():
+            return None
+        elif _refine_geometry:
+            return _idx
+        else:
+            self._topo.mark_invalid(np.fromiter(_idx, dtype=np.int64, count=len(_idx)))
+            self._leaf_cells -= _idx
+            return None
+
+    def refine(self) -> None:
+        """generate the grid (s_cube.py:563-667)"""
+        logger.info("Starting grid generation.")
+        self._refine_uniform()
+
+        iteration_count = 0
+        self._n_cells_after_uniform = len(self._leaf_cells)
+        if self._n_cells_max is None:
+            self._compute_captured_metric()
+        self._n_cells_log.append(len(self._leaf_cells))
+
+        logger.info("Starting metric-based refinement.")
+        self._times["t_start_adaptive"] = time()
+        while self._check_stopping_criteria():
+            if self._n_cells_max is None:
+                logger.info(f"\r\tStarting iteration no. {iteration_count}, captured metric: "
+                            f"{round(self._metric[-1] * 100, 2)} %, N_cells = {len(self._leaf_cells)}")
+            else:
+                logger.info(f"\r\tStarting iteration no. {iteration_count}, N_cells = {len(self._leaf_cells)}")
+            if len(self._metric) >= 2:
+                self._compute_n_cells_per_iter()
+
+            # top-N leaves by (gain, -id) -- radix select on the device (replaces heapq.nlargest, s_cube.py:601-602)
+            _leaf_cells_sorted = self._backend.topn(self._topo.n_cells, min(self._cells_per_iter, self._n_cells))
+            to_refine = set()
+            if self._max_delta_level:
+                for i in _leaf_cells_sorted.tolist():
+                    to_refine.add(i)
+                    self._topo.relink_parent_of([i])
+                    nb_to_refine_as_well = set(self._check_nb(i))
+                    to_refine.update(self._check_constraint(nb_to_refine_as_well))
+            else:
+                to_refine.update(_leaf_cells_sorted.tolist())
+                self._topo.relink_parent_of(_leaf_cells_sorted)
+
+            first, n_new = self._refine_cells(to_refine)
+            self._remove_invalid_cells(set(range(first, first + n_new)), _batch=(first, n_new))
+
+            if self._n_cells_max is None:
+                self._compute_captured_metric()
+            iteration_count += 1
+            self._n_cells_log.append(len(self._leaf_cells))
+
+        if self._n_cells_max is not None:
+            self._compute_captured_metric()
+        logger.info("Finished metric-based refinement.")
+
+        self._refine_geometries()
+        self._update_min_ref_level()
+        self._resort_nodes_and_indices_of_grid()
+        self._create_mesh_info(iteration_count)
+        logger.info(self)
+        if self._n_cells_max is not None and self._metric[-1] > 1:
+            logger.info("Detected a captured metric > 100%. This means that the current number of 'n_cells_max' can be"
+                        " reduced without further loss of information for this metric field, since the metric field is "
+                        "over-approximated.")
+
+    # -- 2:1 balance (max_delta_level=True), host only: s_cube.py:447-506 -------------------------------------------
+    def _check_nb(self, _cell_no: int) -> list:
+        return self._topo.check_nb(_cell_no)
+
+    def _check_constraint(self, nb_violating_constraint: set) -> set:
+        new_cells_to_check = True if nb_violating_constraint else False
+        while new_cells_to_check:
+            tmp = set()
+            for c in nb_violating_constraint:
+                self._topo.relink_parent_of([c])
+                tmp.update(self._check_nb(c))
+            if not tmp or tmp.issubset(nb_violating_constraint):
+                new_cells_to_check = False
+            else:
+                nb_violating_constraint.update(tmp)
+        return nb_violating_constraint
+
+    # -- geometry refinement: s_cube.py:774-863, 1538-1555 ------------------------------------------------------------
+    def _refine_geometries(self) -> None:
+        geometries_to_refine = [idx for idx, g in enumerate(self._geometry) if g.refine]
+        if geometries_to_refine:
+            self._times["t_start_geometry"] = time()
+            self._execute_geometry_refinement(_geometries=geometries_to_refine)
+            self._times["t_end_geometry"] = time()
+
+    def _execute_geometry_refinement(self, _geometries: list = None) -> None:
+        logger.info("Starting geometry refinement.")
+        for g in _geometries:
+            logger.info(f"Starting refining geometry {self._geometry[g].name}.")
+            touching = self._remove_invalid_cells(self._leaf_cells, _refine_geometry=True, _geometry_no=g)
+            if touching is None:
+                logger.warning("Could not find any cells to refine. Skipping geometry refinement.")
+                logger.info("Finished geometry refinement.")
+                return
+            _all_cells = set(touching)
+            level = self._topo.level
+            _global_min_level = min([int(level[cell]) for cell in _all_cells])
+            if self._geometry[g].min_refinement_level is None:
+                _global_max_level = max([int(level[cell]) for cell in _all_cells])
+            else:
+                _global_max_level = self._geometry[g].min_refinement_level
+            logger.info(f"Found a minimum cell level of {_global_min_level}. Target level is {_global_max_level}.")
+
+            while _global_max_level > _global_min_level:
+                logger.info(f"\r\t\t\t\t\t\t\t\t\tRefining level {_global_min_level+1} / {_global_max_level}.")
+                to_refine, checked = set(), set()
+                level = self._topo.level
+                for i in _all_cells:
+                    if i in checked:
+                        continue
+                    if int(level[i]) < _global_max_level:
+                        to_refine.add(i)
+                        self._topo.relink_parent_of([i])
+                    if self._max_delta_level:
+                        nb_to_refine_as_well = set(self._check_nb(i))
+                        nb_to_refine_as_well.update(self._check_constraint(nb_to_refine_as_well))
+                        to_refine.update(nb_to_refine_as_well)
+                        checked.update(nb_to_refine_as_well)
+
+                first, n_new = self._refine_cells(to_refine)
+                _idx_new = set(range(first, first + n_new))
+                self._remove_invalid_cells(_idx_new, _geometry_no=g, _batch=(first, n_new))
+
+                # among the new *valid* cells, which ones still touch the geometry?
+                fc = self._topo.first_child
+                still_leaf = {i for i in _idx_new if fc[i] == -1}
+                touching = self._remove_invalid_cells(still_leaf, _refine_geometry=True, _geometry_no=g)
+                if touching is None:
+                    raise TypeError("'NoneType' object is not iterable")    # reference behaviour at s_cube.py:855
+                _all_cells = set(touching)
+                _global_min_level += 1
+
+        level = self._topo.level
+        leaves = np.fromiter(self._leaf_cells, dtype=np.int64, count=len(self._leaf_cells))
+        self._current_max_level = int(level[leaves].max())
+        logger.info("Finished geometry refinement.")
+
+    # -- final assembly: s_cube.py:734-772 ------------------------------------------------------------------------
+    def _resort_nodes_and_indices_of_grid(self) -> None:
+        logger.info("Starting renumbering final mesh.")
+        self._times["t_start_renumber"] = time()
+        dtype = np.int32 if self._n_cells < pt.iinfo(pt.int32).max else np.int64
+        faces, nodes = self._topo.finalize()
+        self.face_ids = pt.from_numpy(faces.astype(dtype))
+        self.all_nodes = pt.from_numpy(nodes)
+        leaves = np.fromiter(self._leaf_cells, dtype=np.int64, count=len(self._leaf_cells))
+        self.all_centers = pt.from_numpy(self._topo.center[leaves].copy())
+        self.all_levels = pt.from_numpy(self._topo.level[leaves].astype(np.int64)).unsqueeze(-1)
+        self._times["t_end_renumber"] = time()
+
+    def _create_mesh_info(self, counter: int) -> None:
+        """same keys as the reference (s_cube.py:1567-1584)"""
+        t = self._times
+        self.data_final_mesh["size_initial_cell"] = self._width
+        self.data_final_mesh["n_cells_orig"] = self._n_cells_orig
+        self.data_final_mesh["n_cells"] = len(self._leaf_cells)
+        self.data_final_mesh["iterations"] = counter
+        self.data_final_mesh["min_level"] = self._current_min_level
+        self.data_final_mesh["max_level"] = self._current_max_level
+        self.data_final_mesh["metric_per_iter"] = self._metric
+        self.data_final_mesh["cells_per_iter"] = self._n_cells_log
+        self.data_final_mesh["t_total"] = t["t_end_renumber"] - t["t_start_uniform"]
+        self.data_final_mesh["t_uniform"] = t["t_end_uniform"] - t["t_start_uniform"]
+        self.data_final_mesh["t_renumbering"] = t["t_end_renumber"] - t["t_start_renumber"]
+        if t["t_end_geometry"] > 0:
+            self.data_final_mesh["t_geometry"] = t["t_end_geometry"] - t["t_start_geometry"]
+            self.data_final_mesh["t_adaptive"] = t["t_start_geometry"] - t["t_start_adaptive"]
+        else:
+            self.data_final_mesh["t_geometry"] = None
+            self.data_final_mesh["t_adaptive"] = t["t_start_renumber"] - t["t_start_adaptive"]
+
+    def __len__(self):
+        return self._n_cells
+
+    def __str__(self) -> str:
+        info = self.data_final_mesh
+        message = [f"Finished refinement in {info['t_total']:2.4f} s ", f"({info['iterations']} iterations).",
+                   f"Time for uniform refinement: {info['t_uniform']:2.4f} s",
+                   f"Time for metric-based refinement: {info['t_adaptive']:2.4f} s"]
+        if info['t_geometry'] is not None:
+            message += [f"Time for geometry refinement: {info['t_geometry']:2.4f} s"]
+        message += ["Time for renumbering the final mesh: {:2.4f} s".format(info['t_renumbering'])]
+        message += ["""
+                                    Number of cells: {:d}
+                                    Minimum ref. level: {:d}
+                                    Maximum ref. level: {:d}
+                                    Captured metric of original grid: {:.2f} %
+                  """.format(len(self._leaf_cells), self._current_min_level, self._current_max_level,
+                             self._metric[-1] * 100)]
+        return "\n\t\t\t\t\t\t\t\t".join(message)
+
+    @property
+    def n_dimensions(self) -> int:
+        return self._n_dimensions
+
+    @property
+    def width(self):
+        return self._width
+
+    @property
+    def geometry(self) -> list:
+        return self._geometry
+
+    def _print_settings(self) -> None:
+        if self._n_cells_max is not None:
+            logger.info("Selecting max. number of cells as stopping criterion.")
+        else:
+            logger.info("Selecting min. approximation of the metric as stopping criterion.")
+        shown = {"pre_select": self._pre_select, "n_jobs": self._n_jobs, "max_delta_level": self._max_delta_level,
+                 "geometry": [g.name for g in self._geometry], "min_level": self._min_level,
+                 "cells_per_iter_start": self._cells_per_iter_start, "cells_per_iter_end": self._cells_per_iter_end,
+                 "reach_at_least": self._reach_at_least, "n_dimensions": self._n_dimensions,
+                 "n_cells_orig": self._n_cells_orig, "relTol": self._relTol, "backend": "MI355X / libs3hip.so"}
+        if self._n_cells_max is not None:
+            shown["n_cells_max"] = self._n_cells_max
+        else:
+            shown["min_metric"] = self._min_metric
+        width = max(len(k) for k in shown)
+        logger.info("\n".join(["\n\tSelected settings:"] + [f"\t\t{k:<{width}}:\t{v}" for k, v in shown.items()]))
+
+
+def _directions(n_dims: int) -> np.ndarray:
+    """offsets of the 2^d children / nodes relative to a cell centre (s_cube.py:188-194)"""
+    if n_dims == 2:
+        return np.array([[-1, -1], [-1, 1], [1, 1], [1, -1]], dtype=np.float64)
+    return np.array([[-1, -1, 1], [-1, 1, 1], [1, 1, 1], [1, -1, 1],
+                     [-1, -1, -1], [-1, 1, -1], [1, 1, -1], [1, -1, -1]], dtype=np.float64)
+
+
+def _initialize_time_dict() -> dict:
+    return {"t_start_uniform": 0.0, "t_end_uniform": 0.0, "t_start_adaptive": 0.0,
+            "t_start_geometry": 0.0, "t_end_geometry": 0.0, "t_start_renumber": 0.0, "t_end_renumber": 0.0}

@@ -1,0 +1,142 @@
+"""
+Device side of the S^3 sampling tree: the structure-of-arrays image of the reference's ``Cell`` objects
+(s_cube.py:32-83) lives in HBM and every numerical step of ``SamplingTree.refine`` is one libs3hip.so call.
+
+HBM-resident arrays (capacity grows geometrically; sized for 288 GB, one cell costs 8*dim + 4 + 8 + 8 + 1 bytes):
+    center [cap, dim] f64, level [cap] i32, metric [cap] f64, gain [cap] f64, leaf [cap] u8
+plus the bucket-grid KNN index over the original points and the metric in bucket order (hipops.KnnIndex).
+
+Per refine batch the host sends the ordered parent ids (4 B each) and receives the invalid flags of the new cells
+(1 B each); per iteration it receives the ordered top-N ids and one double (sum of metric^2 over the leaves).
+"""
+import numpy as np
+import torch as pt
+
+from . import hipops
+
+
+def _level_factor_table(width, n_dims, n_levels=64):
+    """1/2^d * (width/2^level)^d, the reference's Python expression at s_cube.py:1859, evaluated on the host so the
+    device multiplies by bit-identical factors."""
+    return np.array([1 / (2 ** n_dims) * ((width / (2 ** lv)) ** n_dims) for lv in range(n_levels)], dtype=np.float64)
+
+
+class HipTreeBackend:
+    name = "hip"
+
+    def __init__(self, vertices, target, k):
+        self.dev = hipops.device()
+        self.k = int(k)
+        self.knn = hipops.KnnIndex(vertices)
+        self.knn.set_values(target)
+        self.dim = self.knn.dim
+        self.nch = 2 ** self.dim
+        self.cap = 0
+        self.center = self.level = self.metric = self.gain = self.leaf = None
+        self._parents = None
+        self._poly_cache = {}
+
+    # -- plain KNN regression at arbitrary points (root cell, s_cube.py:372) ------------------------------------
+    def predict(self, q):
+        return self.knn.predict(np.ascontiguousarray(q, dtype=np.float64), self.k).cpu().numpy()
+
+    # -- cell arrays -------------------------------------------------------------------------------------------
+    def _grow(self, need):
+        if need <= self.cap:
+            return
+        cap = max(4096, self.cap)
+        while cap < need:
+            cap *= 2
+        new = dict(center=pt.empty((cap, self.dim), dtype=pt.float64, device=self.dev),
+                   level=pt.zeros(cap, dtype=pt.int32, device=self.dev),
+                   metric=pt.zeros(cap, dtype=pt.float64, device=self.dev),
+                   gain=pt.zeros(cap, dtype=pt.float64, device=self.dev),
+                   leaf=pt.zeros(cap, dtype=pt.uint8, device=self.dev))
+        if self.cap:
+            for name, t in new.items():
+                t[:self.cap].copy_(getattr(self, name)[:self.cap])
+        for name, t in new.items():
+            setattr(self, name, t)
+        self.cap = cap
+        self._sumsq_scratch = pt.empty(1024, dtype=pt.float64, device=self.dev)
+        self._sumsq_out = pt.empty(1, dtype=pt.float64, device=self.dev)
+
+    def start(self, root_center, width, gain0, root_metric, root_gain):
+        self.width = width
+        self.gain0 = float(gain0)
+        self.level_factor = hipops.to_device(_level_factor_table(width, self.dim))
+        self._grow(4096)
+        self.center[0].copy_(pt.from_numpy(np.asarray(root_center, dtype=np.float64)))
+        self.level[0] = 0
+        self.metric[0] = float(root_metric)
+        self.gain[0] = float(root_gain)
+        self.leaf[0] = 1
+
+    def refine_batch(self, parents, first):
+        """children of the ordered ``parents`` become cells first..first+len*2^d-1; their metric and gain are
+        evaluated (s_cube.py:875-900 -> a3 + a4)."""
+        n_par = len(parents)
+        n_new = n_par * self.nch
+        self._grow(first + n_new)
+        self._parents = hipops.to_device(np.ascontiguousarray(parents, dtype=np.int32))
+        hipops.make_children(self.center, self.level, self._parents, first, float(self.width))
+        scratch = pt.empty(n_new * (self.nch + 1), dtype=pt.float64, device=self.dev)
+        hipops.child_gain(self.knn, self.k, self.center, self.level, first, n_new, float(self.width),
+                          self.level_factor, self.gain0, self.metric, self.gain, scratch)
+        return n_new
+
+    def mask(self, geometries, refine_mode, cells=None, first=0, n=None):
+        """OR of the geometry verdicts (s_cube.py:1831-1837) for the cells ``cells`` (ordered id array) or the id
+        range first..first+n-1 -> numpy bool [n]."""
+        d_cells = None
+        if cells is not None:
+            n = len(cells)
+            d_cells = hipops.to_device(np.ascontiguousarray(cells, dtype=np.int32))
+        invalid = pt.zeros(max(n, 1), dtype=pt.uint8, device=self.dev)
+        w = float(self.width)
+        for g in geometries:
+            spec = g.kernel_spec()
+            ki = int(g.keep_inside)
+            if spec[0] == "box":
+                hipops.mask_box(self.center, self.level, d_cells, first, n, w, spec[1], spec[2], refine_mode, ki, invalid)
+            elif spec[0] == "sphere":
+                hipops.mask_sphere(self.center, self.level, d_cells, first, n, w, spec[1], spec[2], refine_mode, ki,
+                                   invalid)
+            elif spec[0] == "cylinder":
+                hipops.mask_cylinder(self.center, self.level, d_cells, first, n, w, *spec[1:], refine_mode, ki, invalid)
+            elif spec[0] == "polygon":
+                key = id(g)
+                if key not in self._poly_cache:
+                    self._poly_cache[key] = hipops.to_device(np.ascontiguousarray(spec[1], dtype=np.float64))
+                hipops.mask_polygon(self.center, self.level, d_cells, first, n, w, self._poly_cache[key], refine_mode,
+                                    ki, invalid)
+            else:
+                raise NotImplementedError(f"geometry kind {spec[0]!r} has no device kernel")
+        self._last_invalid = invalid
+        return invalid[:n].cpu().numpy().astype(bool)
+
+    def commit(self, first, n_new, use_invalid):
+        """leaf/gain bookkeeping of the batch created by the last ``refine_batch`` (s_cube.py:250-251, 721-723)."""
+        hipops.commit_batch(self.leaf, self.gain, self._parents, first, n_new,
+                            self._last_invalid if use_invalid else None)
+
+    def sumsq(self, n_cells):
+        hipops.sumsq_leaf(self.metric, self.leaf, 0, n_cells, self._sumsq_out, self._sumsq_scratch)
+        return float(self._sumsq_out.item())
+
+    def sumsq_range(self, begin, end):
+        """partial captured-metric numerator over cell ids [begin, end) as a 1-element device tensor (multi-GPU)"""
+        out = pt.empty(1, dtype=pt.float64, device=self.dev)
+        hipops.sumsq_leaf(self.metric, self.leaf, begin, end, out, self._sumsq_scratch)
+        return out
+
+    def topn(self, n_cells, n_top):
+        scratch = hipops.topn_scratch(n_cells, n_top, self.dev)
+        return hipops.topn_leaf(self.gain, self.leaf, n_cells, n_top, scratch).astype(np.int64)
+
+    def download(self, n_cells):
+        return dict(metric=self.metric[:n_cells].cpu().numpy(), gain=self.gain[:n_cells].cpu().numpy(),
+                    center=self.center[:n_cells].cpu().numpy(), level=self.level[:n_cells].cpu().numpy())
+
+    def close(self):
+        self.knn.close()

@@ -1,0 +1,98 @@
+"""
+Host logic of SamplingTree (CPython set ordering, native topology engine, stopping rules) against the golden outputs
+of the REAL reference.  The numerical kernels are supplied by the CPU oracle through tests/oracle_backend.py (test-only
+injection), so this runs without a GPU; tests/test_gpu_refine.py repeats the same comparisons with the HIP backend.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch as pt
+
+import sparsespatialsampling_amd.s_cube as s_cube
+from sparsespatialsampling_amd import geometry
+from inputs import cloud, refine_inputs, sha, wake_metric
+from tests.oracle_backend import OracleTreeBackend
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture
+def oracle_backend(monkeypatch):
+    monkeypatch.setattr(s_cube, "_make_backend", lambda v, t, k: OracleTreeBackend(v, t, k))
+
+
+def load(name):
+    return np.load(os.path.join(G, name + ".npz"))
+
+
+def check_tree_against_golden(tree, z, exact_values=True):
+    topo = tree._topo
+    n = topo.n_cells
+    assert n == len(z["level"])
+    assert np.array_equal(topo.level, z["level"])
+    assert np.array_equal(topo.parent, z["parent"])
+    state = np.where(topo.first_child == -1, 0, np.where(topo.first_child == -2, 2, 1))
+    assert np.array_equal(state, z["state"])
+    assert np.array_equal(topo.center, z["center"])
+    assert np.array_equal(topo.nb, z["nb"])
+    assert np.array_equal(topo.node_idx, z["node_idx"])
+    assert np.array_equal(np.fromiter(tree._leaf_cells, dtype=np.int64), z["leaf_order"])
+    vals = tree._cell_values()
+    if exact_values:
+        assert np.array_equal(vals["metric"][1:], z["metric"][1:])
+        assert np.array_equal(vals["gain"][1:], z["gain"][1:])
+
+
+def check_outputs_against_golden(tree, z):
+    assert np.array_equal(tree.all_centers.numpy(), z["all_centers"])
+    assert tree.all_levels.dtype == pt.int64 and np.array_equal(tree.all_levels.numpy(), z["all_levels"])
+    assert tree.face_ids.dtype == pt.int32 and np.array_equal(tree.face_ids.numpy(), z["face_ids"])
+    assert np.array_equal(tree.all_nodes.numpy(), z["all_nodes"])
+    assert np.array_equal(np.array(tree._n_cells_log), z["n_cells_log"])
+    # captured-metric history: the only non bit-exact quantity (summation order of ||.||_2), see DESIGN.md
+    np.testing.assert_allclose(np.array(tree._metric), z["metric_hist"], rtol=1e-12, atol=0)
+    info = tree.data_final_mesh
+    assert info["iterations"] == int(z["iterations"])
+    assert info["min_level"] == int(z["min_level"]) and info["max_level"] == int(z["max_level"])
+    assert info["n_cells"] == len(z["all_levels"])
+
+
+@pytest.mark.parametrize("d", [2, 3])
+def test_uniform_tables(oracle_backend, d):
+    z = load(f"uniform_{d}d")
+    x = cloud(61 + d, 500, [0.0] * d, [10.0] * d)
+    y = wake_metric(x / 10.0, [0.3, 0.4, 0.0][:d])
+    assert np.array_equal(x, z["x"]) and np.array_equal(y, z["y"])
+    tree = s_cube.SamplingTree(pt.from_numpy(x), pt.from_numpy(y), uniform_level=3,
+                               geometry_obj=[geometry.CubeGeometry("domain", True, [0] * d, [10] * d)])
+    tree._refine_uniform()
+    check_tree_against_golden(tree, z)
+    assert np.array_equal(tree._topo.nodes, z["all_nodes"])
+    assert tree._topo.n_nodes == (2 ** 3 + 1) ** d            # perfect sharing on a uniform grid: 81 / 729
+
+
+@pytest.mark.parametrize("name", ["refine_2d_metric", "refine_2d_ncells", "refine_2d_delta", "refine_3d_metric"])
+def test_refine_matches_reference(oracle_backend, name):
+    z = load(name)
+    x, y, geos, kw = refine_inputs(name, geometry)
+    assert sha(x, y) == str(z["input_sha"])
+    trace = []
+    orig = s_cube.SamplingTree._refine_cells
+
+    def traced(self, to_refine):
+        trace.append(np.fromiter(to_refine, dtype=np.int64))
+        return orig(self, to_refine)
+
+    s_cube.SamplingTree._refine_cells = traced
+    try:
+        tree = s_cube.SamplingTree(pt.from_numpy(x), pt.from_numpy(y), geometry_obj=geos, **kw)
+        tree.refine()
+    finally:
+        s_cube.SamplingTree._refine_cells = orig
+    assert float(tree._width) == float(z["width"]) and tree._gain0 == float(z["gain0"])
+    # which cells were split, in which order, in every iteration (incl. geometry refinement)
+    assert np.array_equal(np.array([len(t) for t in trace]), z["trace_len"])
+    assert np.array_equal(np.concatenate(trace), z["trace"])
+    check_tree_against_golden(tree, z)
+    check_outputs_against_golden(tree, z)

@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""
+bench.py -- S^3 hot path on MI355X: snapshot interpolation throughput (+ refine wall-clock) on the synthetic
+cylinder3D_Re3900 workload of BASELINE.json / SURVEY.md 8(d).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+A *step* is one pass of the interpolation hot path (`export.interpolate_data` -> s3_interp) over one batch of synthetic
+snapshots: data [N_points, 1, T_batch] fp32 already resident in HBM -> out [N_cells, 1, T_batch] f64 in HBM, with the
+KNN indices/weights of the generated grid resident as well.  The grid itself comes from `SamplingTree.refine()` run on
+the GPU before the timed region; its wall-clock is reported as `refine_wall_s` in the same JSON line.
+
+Multi-GPU (one process per GPU, launched by torch.distributed.run): the path shards over the snapshot axis -- every
+rank holds the (replicated) grid + KNN cache and interpolates its own snapshot batches, no data-path collective
+("scaling": "weak").  refine() runs replicated on every rank with the captured-metric reduction split across ranks
+(one 8-byte RCCL all-reduce per refine iteration).
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch as pt
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (n_points, T_batch, uniform_levels, min_metric)
+    "cylinder3D_Re3900": dict(n=5_000_000, lo=[0.0, 0.0, 0.0], hi=[2.4, 2.0, 0.1 * np.pi], t_batch=250,
+                              uniform_levels=5, min_metric=0.75, seed=2),
+    "cylinder3D_small": dict(n=300_000, lo=[0.0, 0.0, 0.0], hi=[2.4, 2.0, 0.1 * np.pi], t_batch=250,
+                             uniform_levels=4, min_metric=0.6, seed=2),
+}
+
+
+def synthetic_cylinder3d(cfg):
+    """uniform random centroids in the cylinder3D box minus the cylinder; TKE-like metric with a wake"""
+    rng = np.random.default_rng(cfg["seed"])
+    lo, hi = np.asarray(cfg["lo"]), np.asarray(cfg["hi"])
+    x = lo + rng.random((cfg["n"], 3)) * (hi - lo)
+    dx, dy = x[:, 0] - 0.8, x[:, 1] - 1.0
+    keep = dx * dx + dy * dy > 0.05 ** 2
+    x, dx, dy = np.ascontiguousarray(x[keep]), dx[keep], dy[keep]
+    r = np.sqrt(dx * dx + dy * dy)
+    wake = np.exp(-(dy / 0.12) ** 2) * np.where(dx > 0, np.exp(-0.8 * dx), 0.0)
+    metric = 0.02 + np.exp(-8.0 * r) + 0.9 * wake * (1 + 0.3 * np.sin(11.0 * dx)) * (1.0 + 0.1 * np.cos(40.0 * x[:, 2]))
+    return x, metric
+
+
+def cpu_baseline(x_host, centers, k, t_sample, seconds=12.0):
+    """the CPU oracle (C + OpenMP restatement of export.py:446-468) on a bounded sample of the same workload"""
+    from oracle import s3_oracle as orc
+    nc = min(len(centers), 10_000)
+    n_src = min(len(x_host), 200_000)          # brute-force KNN in the oracle: keep the index build of the sample cheap
+    idx, dist = orc.knn(x_host[:n_src], centers[:nc], k)
+    w = orc.idw_weights(dist)
+    data = np.random.default_rng(0).standard_normal((n_src, 1, t_sample)).astype(np.float32)
+    orc.interp(w, idx, data)                   # warm
+    reps, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        orc.interp(w, idx, data)
+        reps += 1
+    dt = time.perf_counter() - t0
+    return dict(value=nc * t_sample * reps / dt / 1e6, unit="Mcells*snapshots/s", cores=orc.num_threads(), kind="port",
+                sample=f"oracle/s3_oracle.c s3o_interp (OpenMP), {nc} cells x {t_sample} snapshots x {reps} passes, "
+                       f"k={k}, fp32 in / f64 out, {n_src} source points")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cylinder3D_Re3900", choices=sorted(WORKLOADS))
+    ap.add_argument("--t-batch", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    pt.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=pt.device("cuda", local_rank))
+
+    from sparsespatialsampling_amd import geometry, hipops
+    from sparsespatialsampling_amd.s_cube import SamplingTree
+    import logging
+    logging.getLogger().setLevel(logging.WARNING)
+
+    cfg = dict(WORKLOADS[args.workload])
+    if args.t_batch:
+        cfg["t_batch"] = args.t_batch
+    k = 26
+    x, metric = synthetic_cylinder3d(cfg)
+    geos = [geometry.CubeGeometry("domain", True, cfg["lo"], [float(v) for v in cfg["hi"]]),
+            geometry.CylinderGeometry3D("cylinder", False, [(0.8, 1.0, -1.0), (0.8, 1.0, 1.0)], 0.05, refine=True)]
+
+    # ---- refine (grid generation), timed separately -----------------------------------------------------------
+    pt.cuda.synchronize()
+    t0 = time.perf_counter()
+    tree = SamplingTree(pt.from_numpy(x), pt.from_numpy(metric), geos, uniform_level=cfg["uniform_levels"],
+                        min_metric=cfg["min_metric"])
+    tree.refine()
+    pt.cuda.synchronize()
+    refine_s = time.perf_counter() - t0
+    centers = tree.all_centers.numpy()
+    info = dict(tree.data_final_mesh)
+    n_cells_total = tree._topo.n_cells
+    tree._backend.close()
+    del tree
+
+    # ---- KNN cache (once) -------------------------------------------------------------------------------------
+    t0 = time.perf_counter()
+    knn = hipops.KnnIndex(x)
+    idx, dist_ = knn.query(centers, k)
+    w = hipops.idw_weights(dist_)
+    pt.cuda.synchronize()
+    knn_cache_s = time.perf_counter() - t0
+    knn.close()
+    del dist_
+    nc, n_src, t_b = len(centers), len(x), cfg["t_batch"]
+    n_unique = int(pt.unique(idx).numel())          # plumbing: only used for the algorithmic byte count
+
+    # ---- synthetic snapshot batch resident in HBM ---------------------------------------------------------------
+    gen = pt.Generator(device="cuda").manual_seed(1234 + rank)
+    data = pt.randn((n_src, 1, t_b), dtype=pt.float32, device="cuda", generator=gen)
+    out = pt.empty((nc, 1, t_b), dtype=pt.float64, device="cuda")
+
+    def step():
+        hipops.interp(w, idx, data, out=out)
+
+    for _ in range(args.warmup):
+        step()
+    pt.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    ev = [(pt.cuda.Event(enable_timing=True), pt.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record()
+        step()
+        b.record()
+    pt.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = pt.tensor([elapsed], dtype=pt.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))       # HIP events on the launch stream
+
+    if rank == 0:
+        units = nc * 1 * t_b * args.steps * world
+        value = units / elapsed / 1e6
+        # algorithmic HBM bytes of one launch: every referenced source row once + every output once +
+        # idx (int32) / weights (f64) once
+        b_alg = n_unique * t_b * 4 + nc * t_b * 8 + nc * k * (4 + 8)
+        achieved = b_alg / (kernel_ms * 1e-3) / 1e9
+        res = {
+            "metric": "Mcells*snapshots/s interpolated", "value": value, "unit": "Mcells*snapshots/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.workload} (synthetic, SURVEY 8(d) C3): {n_src} points x {t_b} snapshots "
+                                   f"per step, {nc} generated cells, k={k}, fp32 in / f64 out",
+                       "n_points": n_src, "n_cells": nc, "t_batch": t_b, "k": k, "n_comp": 1,
+                       "parallelism": f"snapshot-axis shards x{world}"},
+            "refine_wall_s": refine_s, "refine_iterations": info["iterations"], "refine_cells_created": n_cells_total,
+            "refine_leaves_per_s": nc / refine_s, "knn_cache_s": knn_cache_s,
+            "captured_metric": info["metric_per_iter"][-1],
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                         "traffic": None, "kernel": "interp_kernel<float,4>", "kernel_ms": kernel_ms,
+                         "algorithmic_bytes": b_alg, "unique_source_rows": n_unique,
+                         "gather_upper_bound_bytes": nc * k * t_b * 4 + nc * t_b * 8},
+        }
+        if not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(x, centers, k, min(t_b, 64))
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,233 @@
+"""
+Parity of the HIP kernels (through the C ABI) with the CPU oracle and the reference's golden vectors.  GPU only.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch as pt
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(G, name + ".npz"))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from sparsespatialsampling_amd import hipops
+    hipops.device()
+    return hipops
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import s3_oracle
+    return s3_oracle
+
+
+def dev(a, dtype=None):
+    t = pt.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+# ---- interpolation (a17) -------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["interp_k8_c1_f32", "interp_k8_c3_f64", "interp_k26_c1_f32", "interp_k26_c3_f32",
+                                  "interp_k26_c1_f64"])
+def test_interp_golden(ops, name):
+    z = load(name)
+    out = ops.interp(dev(z["w"]), dev(z["idx"], pt.int32), dev(z["data"])).cpu().numpy()
+    assert out.shape == z["out"].shape
+    assert np.abs(out - z["out"]).max() <= 1e-13 * np.abs(z["out"]).max()       # contract: 1e-5 relative
+
+
+@pytest.mark.parametrize("k,ncomp,t,dtype", [(8, 1, 400, np.float32), (26, 1, 1000, np.float32), (26, 3, 25, np.float32),
+                                             (26, 1, 25, np.float32), (26, 1, 1, np.float64), (8, 2, 7, np.float64),
+                                             (26, 1, 6, np.float32), (5, 1, 64, np.float32)])
+def test_interp_vs_oracle_shapes(ops, orc, k, ncomp, t, dtype):
+    """every vector width / tile shape of s3_interp incl. ragged tiles (nc not a multiple of the tile height)"""
+    rng = np.random.default_rng(k * 1000 + t)
+    n, nc = 5000, 1237
+    w = rng.random((nc, k))
+    w /= w.sum(1, keepdims=True)
+    idx = rng.integers(0, n, (nc, k))
+    data = rng.standard_normal((n, ncomp, t)).astype(dtype)
+    out = ops.interp(dev(w), dev(idx, pt.int32), dev(data)).cpu().numpy()
+    ref = orc.interp(w, idx, data)
+    assert np.abs(out - ref).max() <= 1e-13 * np.abs(ref).max()
+
+
+def test_interp_linearity_and_constant_full_size(ops):
+    """size-independent properties at a size the oracle would not finish quickly: weights sum to one -> a constant
+    field is reproduced; interpolation is linear in the data"""
+    rng = np.random.default_rng(1)
+    n, nc, k, t = 400_000, 150_000, 26, 200
+    w = rng.random((nc, k))
+    w /= w.sum(1, keepdims=True)
+    idx = dev(rng.integers(0, n, (nc, k)), pt.int32)
+    w = dev(w)
+    a = pt.randn((n, 1, t), dtype=pt.float32, device="cuda")
+    b = pt.randn((n, 1, t), dtype=pt.float32, device="cuda")
+    const = pt.full((n, 1, t), 3.25, dtype=pt.float32, device="cuda")
+    assert pt.allclose(ops.interp(w, idx, const), pt.full((nc, 1, t), 3.25, dtype=pt.float64, device="cuda"),
+                       rtol=1e-13, atol=0)
+    lhs = ops.interp(w, idx, (a.double() + 2 * b.double()))
+    rhs = ops.interp(w, idx, a) + 2 * ops.interp(w, idx, b)
+    assert pt.allclose(lhs, rhs, rtol=1e-12, atol=1e-12)
+
+
+def test_interp_empty_and_errors(ops):
+    from sparsespatialsampling_amd._lib import S3HipError
+    w = pt.zeros((0, 8), dtype=pt.float64, device="cuda")
+    idx = pt.zeros((0, 8), dtype=pt.int32, device="cuda")
+    data = pt.zeros((10, 1, 4), dtype=pt.float32, device="cuda")
+    assert ops.interp(w, idx, data).shape == (0, 1, 4)
+    with pytest.raises(S3HipError):
+        ops.interp(pt.zeros((4, 65), dtype=pt.float64, device="cuda"), pt.zeros((4, 65), dtype=pt.int32, device="cuda"),
+                   data)
+
+
+# ---- KNN cache (a16) -----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,k", [("knncache_2d", 8), ("knncache_3d", 26)])
+def test_knn_cache_golden(ops, name, k):
+    z = load(name)
+    knn = ops.KnnIndex(z["coords"])
+    for q, idx_ref, w_ref in ((z["centers"], z["idx_c"], z["w_c"]), (z["vertices"], z["idx_v"], z["w_v"])):
+        idx, dist = knn.query(q, k)
+        assert np.array_equal(idx.cpu().numpy(), idx_ref)                     # bit-exact indices
+        assert np.array_equal(ops.idw_weights(dist).cpu().numpy(), w_ref)      # bit-exact weights (clamp rows incl.)
+    _, dist = knn.query(z["centers"], k)
+    assert np.array_equal(dist.cpu().numpy(), z["dist_c"])
+    knn.close()
+
+
+@pytest.mark.parametrize("d,k,occ", [(2, 8, 0.0), (3, 26, 0.0), (3, 26, 1.0), (2, 8, 40.0), (3, 5, 0.0)])
+def test_knn_vs_oracle(ops, orc, d, k, occ):
+    """random clouds, clustered clouds, queries far outside the cloud, several bucket occupancies"""
+    rng = np.random.default_rng(d * 10 + k)
+    x = np.concatenate([rng.random((20000, d)), 0.5 + 0.01 * rng.standard_normal((5000, d))])      # uniform + cluster
+    q = np.concatenate([rng.random((3000, d)), rng.random((500, d)) * 4 - 1.5, x[:50]])              # inside/outside/hits
+    knn = ops.KnnIndex(x, target_occupancy=occ)
+    idx, dist = knn.query(q, k)
+    idx_o, dist_o = orc.knn(x, q, k)
+    assert np.array_equal(idx.cpu().numpy(), idx_o)
+    assert np.array_equal(dist.cpu().numpy(), dist_o)
+    knn.close()
+
+
+def test_knn_ties_structured_grid(ops, orc):
+    """structured grid queried at cell corners: many exactly equidistant neighbours -> (dist, idx) tie rule"""
+    g = np.stack(np.meshgrid(np.arange(30.0), np.arange(30.0), indexing="ij"), -1).reshape(-1, 2)
+    q = g[:400] + 0.5
+    knn = ops.KnnIndex(g)
+    idx, dist = knn.query(q, 8)
+    idx_o, dist_o = orc.knn(g, q, 8)
+    assert np.array_equal(idx.cpu().numpy(), idx_o) and np.array_equal(dist.cpu().numpy(), dist_o)
+    knn.close()
+
+
+def test_knn_small_and_degenerate(ops, orc):
+    from sparsespatialsampling_amd._lib import S3HipError
+    rng = np.random.default_rng(3)
+    x = rng.random((30, 3))
+    x[:, 2] = 0.25                                   # flat cloud: zero extent in z
+    knn = ops.KnnIndex(x)
+    idx, dist = knn.query(rng.random((40, 3)), 26)
+    idx_o, dist_o = orc.knn(x, np.random.default_rng(3).random((30 + 40, 3))[30:], 26)
+    assert idx.shape == (40, 26)
+    with pytest.raises(S3HipError):
+        knn.query(rng.random((4, 3)), 31)            # k > n
+    knn.close()
+
+
+# ---- KNN regression (a5) -------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,k", [("predict_2d", 8), ("predict_3d", 26)])
+def test_predict_golden(ops, name, k):
+    z = load(name)
+    knn = ops.KnnIndex(z["x"])
+    knn.set_values(z["y"])
+    pred = knn.predict(z["q"], k).cpu().numpy()
+    assert np.array_equal(pred, z["pred"])           # bit-exact incl. exact-hit rows (indicator weights)
+    knn.close()
+
+
+# ---- geometry predicates (a12) ---------------------------------------------------------------------------------
+def test_masks_golden(ops):
+    from inputs import mask_cells
+    z = load("masks")
+    rng = np.random.default_rng(7)
+    c2, h2 = mask_cells(2, 400, rng)
+    c3, h3 = mask_cells(3, 400, rng)
+
+    # the kernels take (centre, level, width) with node offset (0.5*width)/2^level: encode the fixture's arbitrary
+    # half widths as level 0 cells of width 2h -> one launch per cell would be slow, so group: all cells share the
+    # launch, width differs -> use level=0 and a per-cell launch only where h differs (400 tiny launches, fine)
+    def run(fn, c, h, *args):
+        out = np.zeros(len(c), dtype=bool)
+        center = dev(c)
+        level = pt.zeros(len(c), dtype=pt.int32, device="cuda")
+        for i in range(len(c)):
+            inv = pt.zeros(1, dtype=pt.uint8, device="cuda")
+            fn(center, level, None, i, 1, 2.0 * h[i], *args, inv)
+            out[i] = bool(inv.item())
+        return out
+
+    from tests.oracle_backend import orc as o
+    cyl = o.cylinder_params([(0.2, 0.3, -0.1), (0.9, 0.6, 0.8)], 0.35)
+    cone = o.cylinder_params([(0.8, 1.0, -1.0), (0.8, 1.0, 1.0)], [0.5, 0.1])
+    poly = dev(z["poly"])
+    for ki in (1, 0):
+        for rm in (0, 1):
+            sfx = f"_{ki}_r{rm}"
+            assert np.array_equal(run(ops.mask_box, c2, h2, [0.0, 0.1], [1.0, 0.9], rm, ki), z["cube2" + sfx])
+            assert np.array_equal(run(ops.mask_box, c3, h3, [0.0, 0.1, -0.2], [1.0, 0.9, 0.7], rm, ki), z["cube3" + sfx])
+            assert np.array_equal(run(ops.mask_sphere, c2, h2, [0.4, 0.5], 0.45, rm, ki), z["sphere2" + sfx])
+            assert np.array_equal(run(ops.mask_sphere, c3, h3, [0.4, 0.5, 0.3], 0.6, rm, ki), z["sphere3" + sfx])
+            assert np.array_equal(run(ops.mask_cylinder, c3, h3, *cyl, rm, ki), z["cyl3" + sfx])
+            assert np.array_equal(run(ops.mask_cylinder, c3, h3, *cone, rm, ki), z["cone3" + sfx])
+            assert np.array_equal(run(ops.mask_polygon, c2, h2, poly, rm, ki), z["poly2" + sfx])
+
+
+# ---- selection + reduction (a6, a8) -----------------------------------------------------------------------------
+@pytest.mark.parametrize("n,n_top,ties", [(50_000, 37, False), (50_000, 5000, True), (300, 1000, False), (200_000, 1, True),
+                                          (70_000, 69_000, True)])
+def test_topn_vs_oracle(ops, orc, n, n_top, ties):
+    rng = np.random.default_rng(n + n_top)
+    gain = rng.random(n) ** 4
+    if ties:
+        gain = np.round(gain, 3)                     # many exact ties incl. zeros -> the -id tie rule decides
+    leaf = rng.random(n) < 0.7
+    got = ops.topn_leaf(dev(gain), dev(leaf.astype(np.uint8)), n, n_top, ops.topn_scratch(n, n_top, "cuda"))
+    ids = np.flatnonzero(leaf)
+    assert np.array_equal(got, orc.topn(gain[ids], ids, n_top))
+
+
+def test_topn_all_equal(ops, orc):
+    n = 10_000
+    gain = np.zeros(n)
+    leaf = np.ones(n, dtype=np.uint8)
+    got = ops.topn_leaf(dev(gain), dev(leaf), n, 25, ops.topn_scratch(n, 25, "cuda"))
+    assert np.array_equal(got, np.arange(25))
+
+
+def test_sumsq_leaf(ops):
+    rng = np.random.default_rng(9)
+    for n in (1, 1000, 1_234_567):
+        m = rng.standard_normal(n)
+        leaf = rng.random(n) < 0.6
+        out = pt.zeros(1, dtype=pt.float64, device="cuda")
+        scratch = pt.zeros(1024, dtype=pt.float64, device="cuda")
+        ops.sumsq_leaf(dev(m), dev(leaf.astype(np.uint8)), 0, n, out, scratch)
+        ref = float((m[leaf] ** 2).sum())
+        assert abs(out.item() - ref) <= 1e-12 * max(ref, 1e-300)
+        # split ranges add up (multi-GPU partition)
+        a = pt.zeros(1, dtype=pt.float64, device="cuda")
+        b = pt.zeros(1, dtype=pt.float64, device="cuda")
+        ops.sumsq_leaf(dev(m), dev(leaf.astype(np.uint8)), 0, n // 2, a, scratch)
+        ops.sumsq_leaf(dev(m), dev(leaf.astype(np.uint8)), n // 2, n, b, scratch)
+        assert abs(a.item() + b.item() - ref) <= 1e-12 * max(ref, 1e-300)

@@ -1,0 +1,98 @@
+"""
+SamplingTree.refine() on the MI355X (HIP backend) against the reference's golden vectors and the oracle backend.
+GPU only.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch as pt
+
+pytestmark = pytest.mark.gpu
+
+from inputs import cloud, refine_inputs, sha, wake_metric                      # noqa: E402
+from tests.test_tree_host_logic import check_outputs_against_golden, check_tree_against_golden, load  # noqa: E402
+
+
+@pytest.mark.parametrize("d", [2, 3])
+def test_uniform_tables_gpu(d):
+    import sparsespatialsampling_amd.s_cube as s_cube
+    from sparsespatialsampling_amd import geometry
+    z = load(f"uniform_{d}d")
+    tree = s_cube.SamplingTree(pt.from_numpy(z["x"]), pt.from_numpy(z["y"]), uniform_level=3,
+                               geometry_obj=[geometry.CubeGeometry("domain", True, [0] * d, [10] * d)])
+    assert tree._backend.name == "hip"
+    tree._refine_uniform()
+    check_tree_against_golden(tree, z)
+
+
+@pytest.mark.parametrize("name", ["refine_2d_metric", "refine_2d_ncells", "refine_2d_delta", "refine_3d_metric"])
+def test_refine_matches_reference_gpu(name):
+    """cell ids / levels / centres / faces / vertices / per-cell metric + gain: bit-exact vs the real reference"""
+    import sparsespatialsampling_amd.s_cube as s_cube
+    from sparsespatialsampling_amd import geometry
+    z = load(name)
+    x, y, geos, kw = refine_inputs(name, geometry)
+    assert sha(x, y) == str(z["input_sha"])
+    tree = s_cube.SamplingTree(pt.from_numpy(x), pt.from_numpy(y), geometry_obj=geos, **kw)
+    assert tree._backend.name == "hip"
+    tree.refine()
+    check_tree_against_golden(tree, z)
+    check_outputs_against_golden(tree, z)
+
+
+def test_refine_larger_vs_oracle_backend(monkeypatch):
+    """a case well beyond the golden sizes (3-D, 60k points): HIP backend vs oracle backend on the same inputs"""
+    import sparsespatialsampling_amd.s_cube as s_cube
+    from sparsespatialsampling_amd import geometry
+    from tests.oracle_backend import OracleTreeBackend
+    x = cloud(123, 60000, [0, 0, 0], [2.4, 2.0, 0.4])
+    y = wake_metric(x, [0.8, 1.0, 0.0], decay=2.5)
+
+    def geos():
+        return [geometry.CubeGeometry("domain", True, [0, 0, 0], [2.4, 2.0, 0.4]),
+                geometry.CylinderGeometry3D("cyl", False, [(0.8, 1.0, -1.0), (0.8, 1.0, 1.0)], 0.12, refine=True)]
+
+    kw = dict(uniform_level=4, min_metric=0.5)
+    t_hip = s_cube.SamplingTree(pt.from_numpy(x), pt.from_numpy(y), geometry_obj=geos(), **kw)
+    t_hip.refine()
+    monkeypatch.setattr(s_cube, "_make_backend", lambda v, t, k: OracleTreeBackend(v, t, k))
+    t_orc = s_cube.SamplingTree(pt.from_numpy(x), pt.from_numpy(y), geometry_obj=geos(), **kw)
+    t_orc.refine()
+    assert pt.equal(t_hip.all_centers, t_orc.all_centers) and pt.equal(t_hip.all_levels, t_orc.all_levels)
+    assert pt.equal(t_hip.face_ids, t_orc.face_ids) and pt.equal(t_hip.all_nodes, t_orc.all_nodes)
+    vh, vo = t_hip._cell_values(), t_orc._cell_values()
+    assert np.array_equal(vh["metric"], vo["metric"]) and np.array_equal(vh["gain"], vo["gain"])
+    np.testing.assert_allclose(t_hip._metric, t_orc._metric, rtol=1e-12)
+    assert t_hip._n_cells_log == t_orc._n_cells_log
+    # geometric sanity of the output: every centre is the mean of its vertices
+    c = t_hip.all_nodes[t_hip.face_ids.long()].mean(1)
+    assert pt.allclose(c, t_hip.all_centers, rtol=0, atol=1e-12)
+
+
+def test_export_pipeline_gpu(tmp_path):
+    """SparseSpatialSampling -> pickled s_cube object -> ExportData KNN cache + interpolation (HDF5 sink stubbed)"""
+    from sparsespatialsampling_amd import geometry
+    from sparsespatialsampling_amd.export import ExportData
+    from sparsespatialsampling_amd.sparse_spatial_sampling import SparseSpatialSampling
+    from oracle import s3_oracle as orc
+    x, y, geos, kw = refine_inputs("refine_2d_metric", geometry)
+    s3 = SparseSpatialSampling(pt.from_numpy(x), pt.from_numpy(y), geos, str(tmp_path), "case", uniform_levels=4,
+                               min_metric=0.6)
+    s3.execute_grid_generation()
+    z = load("refine_2d_metric")
+    assert np.array_equal(s3.centers.numpy(), z["all_centers"]) and np.array_equal(s3.levels.numpy(), z["all_levels"])
+    loaded = pt.load(os.path.join(str(tmp_path), "s_cube_case.pt"), weights_only=False)
+    assert pt.equal(loaded.centers, s3.centers)
+
+    ex = ExportData(loaded, write_times=[str(i) for i in range(6)])
+    rng = np.random.default_rng(5)
+    data = rng.standard_normal((len(x), 2, 6)).astype(np.float32)
+    ex._fit_data(pt.from_numpy(x), pt.from_numpy(data), "U", None)
+    idx_o, dist_o = orc.knn(x, z["all_centers"], 8)
+    ref = orc.interp(orc.idw_weights(dist_o), idx_o, data)
+    got = ex._interpolated_fields.centers.numpy()
+    assert got.shape == ref.shape and np.abs(got - ref).max() <= 1e-13 * np.abs(ref).max()
+    assert np.array_equal(ex._knn_idx_centers.cpu().numpy(), idx_o)
+    ref_metric = orc.interp(orc.idw_weights(dist_o), idx_o, y)
+    assert np.abs(ex._metric.numpy() - ref_metric).max() <= 1e-13 * np.abs(ref_metric).max()

@@ -95,6 +95,10 @@ def hip_lib():
     """Load libs3hip.so (no device is touched by loading)."""
     global _hip
     if _hip is None:
+        # torch bundles its own HIP runtime (soname libamdhip64.so.7, the same soname libs3hip.so needs).  It must be
+        # in the process first so that the loader binds libs3hip.so to that one copy: two HIP/HSA runtimes in one
+        # process cannot both own the device, and device pointers / streams must come from the runtime torch uses.
+        import torch  # noqa: F401
         if not os.path.exists(HIP_SO):
             raise HipUnavailableError(f"{HIP_SO} not found -- build it with `python -c 'import __graft_entry__ as g; "
                                       f"g.build()'`.  This package has no CPU fallback.")

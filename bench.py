@@ -33,7 +33,7 @@ if ROOT not in sys.path:
 
 WORKLOADS = {
     # name: (n_points, T_batch, uniform_levels, min_metric)
-    "cylinder3D_Re3900": dict(n=5_000_000, lo=[0.0, 0.0, 0.0], hi=[2.4, 2.0, 0.1 * np.pi], t_batch=250,
+    "cylinder3D_Re3900": dict(n=5_000_000, lo=[0.0, 0.0, 0.0], hi=[2.4, 2.0, 0.1 * np.pi], t_batch=1000,
                               uniform_levels=5, min_metric=0.75, seed=2),
     "cylinder3D_small": dict(n=300_000, lo=[0.0, 0.0, 0.0], hi=[2.4, 2.0, 0.1 * np.pi], t_batch=250,
                              uniform_levels=4, min_metric=0.6, seed=2),
@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--workload", default="cylinder3D_Re3900", choices=sorted(WORKLOADS))
     ap.add_argument("--t-batch", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--direct", action="store_true", help="time the direct gather kernel (s3_interp) instead of the "
+                    "planned LDS-tiled kernel (s3_interp_planned)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -126,16 +128,29 @@ def main():
     knn_cache_s = time.perf_counter() - t0
     knn.close()
     del dist_
+    plan = None
+    if not args.direct:
+        plan = hipops.InterpPlan(idx, len(x), centers, tile_cells=int(os.environ.get("S3_TILE_CELLS", "0")))
+        pt.cuda.synchronize()
+    knn_cache_s = time.perf_counter() - t0
     nc, n_src, t_b = len(centers), len(x), cfg["t_batch"]
     n_unique = int(pt.unique(idx).numel())          # plumbing: only used for the algorithmic byte count
 
     # ---- synthetic snapshot batch resident in HBM ---------------------------------------------------------------
     gen = pt.Generator(device="cuda").manual_seed(1234 + rank)
-    data = pt.randn((n_src, 1, t_b), dtype=pt.float32, device="cuda", generator=gen)
-    out = pt.empty((nc, 1, t_b), dtype=pt.float64, device="cuda")
+    if plan is not None:
+        # same layout the export path uploads into: [N, n_comp*T] with the row pitch padded to a multiple of 128 bytes
+        data = hipops.padded_rows(n_src, t_b, pt.float32, "cuda")
+        data.normal_(generator=gen)
+    else:
+        data = pt.randn((n_src, 1, t_b), dtype=pt.float32, device="cuda", generator=gen)
+    out = pt.empty((nc, t_b) if plan is not None else (nc, 1, t_b), dtype=pt.float64, device="cuda")
 
     def step():
-        hipops.interp(w, idx, data, out=out)
+        if plan is not None:
+            plan.interp(w, data, out=out)
+        else:
+            hipops.interp(w, idx, data, out=out)
 
     for _ in range(args.warmup):
         step()
@@ -177,7 +192,8 @@ def main():
             "refine_leaves_per_s": nc / refine_s, "knn_cache_s": knn_cache_s,
             "captured_metric": info["metric_per_iter"][-1],
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": None, "kernel": "interp_kernel<float,4>", "kernel_ms": kernel_ms,
+                         "traffic": None, "kernel": "interp_kernel<float,4>" if plan is None else "interp_planned_kernel<float>",
+                         "staged_rows_per_launch": None if plan is None else plan.total_rows, "kernel_ms": kernel_ms,
                          "algorithmic_bytes": b_alg, "unique_source_rows": n_unique,
                          "gather_upper_bound_bytes": nc * k * t_b * 4 + nc * t_b * 8},
         }

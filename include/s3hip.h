@@ -134,6 +134,21 @@ int s3_idw_weights(const double *d_dist /*[nc,k]*/, int64_t nc, int k, double *d
 int s3_interp(const double *d_w /*[nc,k]*/, const int32_t *d_idx /*[nc,k]*/, int64_t nc, int k, const void *d_data,
               int dtype, int64_t n_src, int64_t row_len, double *d_out /*[nc,row_len]*/, s3_stream stream);
 
+/* Planned form of a17 for a static neighbour table (the table ExportData caches at export.py:431-432 and reuses for
+ * every snapshot batch and field): the plan de-duplicates the source rows of spatially adjacent cells once (host side,
+ * Morton order of d_centers[nc,dim] when given), the kernel then stages each distinct row once per tile in LDS.
+ * Same results as s3_interp.  Rows must be 16-byte aligned (row_len % 4 == 0 for f32, % 2 == 0 for f64). */
+typedef struct s3_interp_plan s3_interp_plan;
+int s3_interp_plan_create(const int32_t *d_idx /*[nc,k]*/, int64_t nc, int k, int64_t n_src,
+                          const double *d_centers /*[nc,dim] or NULL*/, int dim, int tile_cells /*0 (=64), 64 or 128*/,
+                          s3_stream stream, s3_interp_plan **out);
+void s3_interp_plan_destroy(s3_interp_plan *plan);
+int s3_interp_plan_info(const s3_interp_plan *plan, int64_t *h_n_tiles, int64_t *h_total_rows);
+/* in_stride: elements between consecutive source rows of d_data (>= row_len; 0 = row_len).  Rows padded to a multiple
+ * of 128 bytes keep every staged segment on one cache line. */
+int s3_interp_planned(const s3_interp_plan *plan, const double *d_w /*[nc,k]*/, const void *d_data, int dtype,
+                      int64_t row_len, int64_t in_stride, double *d_out /*[nc,row_len]*/, s3_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -240,6 +240,14 @@ __device__ void knn_search(const Grid<DIM> &g, const double *__restrict__ pts, c
         rmax = max(rmax, max(c[j], g.res[j] - 1 - c[j]));
         hmin = fmin(hmin, g.h[j]);
     }
+    // how far q lies outside the grid along each axis (0 inside), shrunk a little to stay conservative
+    double out[DIM], out2 = 0.0;
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) {
+        const double hi = g.lo[j] + (double)g.res[j] * g.h[j];
+        out[j] = fmax(0.0, fmax(g.lo[j] - q[j], q[j] - hi)) * (1.0 - 1e-9);
+        out2 += out[j] * out[j];
+    }
     const int c2 = DIM == 3 ? c[DIM - 1] : 0;
     const int res2 = DIM == 3 ? g.res[DIM - 1] : 1;
 
@@ -262,16 +270,24 @@ __device__ void knn_search(const Grid<DIM> &g, const double *__restrict__ pts, c
             }
         }
         if (b.cnt == b.k) {
-            // distance from q to the nearest face of the visited box that still has buckets behind it
-            double bound = DBL_MAX;
+            // lower bound on the squared distance from q to any point in a bucket that has not been visited: such a
+            // point lies beyond at least one face j of the visited box (distance >= face_j along j) and, like every
+            // point, inside the grid (distance >= out_i along every other axis i on which q lies outside the grid)
+            double bound2 = DBL_MAX;
 #pragma unroll
             for (int j = 0; j < DIM; ++j) {
-                if (c[j] - r > 0) bound = fmin(bound, q[j] - (g.lo[j] + (double)(c[j] - r) * g.h[j]));
-                if (c[j] + r < g.res[j] - 1) bound = fmin(bound, (g.lo[j] + (double)(c[j] + r + 1) * g.h[j]) - q[j]);
+                const double rest = fmax(0.0, out2 - out[j] * out[j]);
+                if (c[j] - r > 0) {
+                    double f = q[j] - (g.lo[j] + (double)(c[j] - r) * g.h[j]) - 1e-9 * hmin;
+                    if (f > 0.0) bound2 = fmin(bound2, f * f + rest); else bound2 = fmin(bound2, rest);
+                }
+                if (c[j] + r < g.res[j] - 1) {
+                    double f = (g.lo[j] + (double)(c[j] + r + 1) * g.h[j]) - q[j] - 1e-9 * hmin;
+                    if (f > 0.0) bound2 = fmin(bound2, f * f + rest); else bound2 = fmin(bound2, rest);
+                }
             }
-            if (bound == DBL_MAX) break;          // the box covers the whole grid
-            bound -= 1e-9 * hmin;                 // bucket assignment rounds; stay conservative
-            if (bound > 0.0 && b.worst < bound * bound) break;
+            if (bound2 == DBL_MAX) break;         // the box covers the whole grid
+            if (b.worst < bound2) break;
         }
     }
 }

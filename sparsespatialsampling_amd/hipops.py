@@ -69,7 +69,11 @@ class KnnIndex:
             _lib.hip_lib().s3_knn_destroy(self._handle)
             self._handle = C.c_void_p(0)
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # interpreter shutdown
+            pass
 
     def set_values(self, y):
         y = to_device(y, pt.float64)
@@ -119,6 +123,67 @@ def interp(w, idx, data, out=None):
     check(_lib.hip_lib().s3_interp(_ptr(w), _ptr(idx), nc, k, _ptr(data), DTYPE_CODE[data.dtype], n_src, row_len,
                                    _ptr(out), _stream()), "s3_interp")
     return out
+
+
+class InterpPlan:
+    """De-duplicated, LDS-tiled form of a static neighbour table (s3_interp_plan_*): build once per KNN cache, reuse for
+    every snapshot batch.  ``centers`` (cell centres, [nc, dim]) gives the Morton processing order."""
+
+    def __init__(self, idx, n_src, centers=None, tile_cells=0):
+        assert idx.is_cuda and idx.dtype == pt.int32 and idx.is_contiguous()
+        self.nc, self.k = int(idx.shape[0]), int(idx.shape[1])
+        self.n_src = int(n_src)
+        ctr = to_device(centers, pt.float64) if centers is not None else None
+        dim = int(ctr.shape[1]) if ctr is not None else 0
+        self._handle = C.c_void_p(0)
+        check(_lib.hip_lib().s3_interp_plan_create(_ptr(idx), self.nc, self.k, self.n_src, _ptr(ctr), dim, int(tile_cells), _stream(),
+                                                   C.byref(self._handle)), "s3_interp_plan_create")
+        nt, nr = C.c_int64(0), C.c_int64(0)
+        check(_lib.hip_lib().s3_interp_plan_info(self._handle, C.byref(nt), C.byref(nr)), "s3_interp_plan_info")
+        self.n_tiles, self.total_rows = nt.value, nr.value
+
+    @staticmethod
+    def supports(k, data):
+        """the planned kernel needs 16-byte aligned rows"""
+        row_len = int(np.prod(data.shape[1:])) if data.dim() > 1 else 1
+        return k <= 64 and data.dtype in DTYPE_CODE and row_len % (4 if data.dtype == pt.float32 else 2) == 0
+
+    def close(self):
+        if getattr(self, "_handle", None) is not None and self._handle.value:
+            _lib.hip_lib().s3_interp_plan_destroy(self._handle)
+            self._handle = C.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # interpreter shutdown
+            pass
+
+    def interp(self, w, data, out=None):
+        """``data`` [n_src, ...]: contiguous, or a column slice ``buf[:, :L]`` of a wider 2-D buffer (rows padded to a
+        multiple of 128 bytes keep every staged segment on one cache line, see ``padded_rows``)."""
+        assert w.dtype == pt.float64 and tuple(w.shape) == (self.nc, self.k) and int(data.shape[0]) == self.n_src
+        row_len = int(np.prod(data.shape[1:])) if data.dim() > 1 else 1
+        if data.is_contiguous():
+            in_stride = row_len
+        else:
+            assert data.dim() == 2 and data.stride(1) == 1 and data.stride(0) >= row_len, "unsupported data layout"
+            in_stride = int(data.stride(0))
+        if out is None:
+            out = pt.empty((self.nc,) + tuple(data.shape[1:]), dtype=pt.float64, device=data.device)
+        assert data.is_cuda and out.is_cuda and out.is_contiguous()
+        check(_lib.hip_lib().s3_interp_planned(self._handle, _ptr(w), C.c_void_p(data.data_ptr()),
+                                               DTYPE_CODE[data.dtype], row_len, in_stride, _ptr(out), _stream()),
+              "s3_interp_planned")
+        return out
+
+
+def padded_rows(n_rows, row_len, dtype, dev):
+    """[n_rows, row_len] view of a device buffer whose row pitch is a multiple of 128 bytes (upload target for
+    snapshot batches: every 128-B segment the planned kernel stages then sits on exactly one cache line)"""
+    per_line = 128 // pt.empty((), dtype=dtype).element_size()
+    pitch = (row_len + per_line - 1) // per_line * per_line
+    return pt.empty((n_rows, pitch), dtype=dtype, device=dev)[:, :row_len]
 
 
 # ---- refine kernels on the device-resident cell arrays ----------------------------------------------------------

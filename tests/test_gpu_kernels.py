@@ -92,6 +92,46 @@ def test_interp_empty_and_errors(ops):
                    data)
 
 
+# ---- planned (LDS-tiled) interpolation: same results as the direct kernel -------------------------------------------
+@pytest.mark.parametrize("d,k,ncomp,t,dtype", [(3, 26, 1, 1000, np.float32), (3, 26, 1, 36, np.float32), (2, 8, 3, 28, np.float32),
+                                               (3, 26, 1, 50, np.float64), (2, 5, 1, 64, np.float32), (3, 40, 1, 8, np.float32)])
+def test_interp_planned_vs_oracle(ops, orc, d, k, ncomp, t, dtype):
+    """real neighbour tables (spatially coherent -> shared rows), Morton-ordered tiles, ragged last chunk"""
+    rng = np.random.default_rng(100 * d + k + t)
+    x = rng.random((30000, d))
+    centers = rng.random((4111, d))
+    knn = ops.KnnIndex(x)
+    idx, dist = knn.query(centers, k)
+    w = ops.idw_weights(dist)
+    data = rng.standard_normal((len(x), ncomp, t)).astype(dtype)
+    plan = ops.InterpPlan(idx, len(x), centers)
+    assert plan.n_tiles >= 4111 // 64 and plan.total_rows <= 4111 * k
+    out = plan.interp(w, dev(data)).cpu().numpy()
+    ref = orc.interp(w.cpu().numpy(), idx.cpu().numpy(), data)
+    assert out.shape == ref.shape and np.abs(out - ref).max() <= 1e-13 * np.abs(ref).max()
+    direct = ops.interp(w, idx, dev(data)).cpu().numpy()
+    assert np.abs(out - direct).max() <= 1e-13 * np.abs(ref).max()
+    plan.close(); knn.close()
+
+
+def test_interp_planned_random_table_no_centers(ops, orc):
+    """worst case for de-duplication: random neighbour ids (with repeats inside a row), identity order"""
+    rng = np.random.default_rng(77)
+    n, nc, k, t = 3000, 777, 26, 24
+    w = rng.random((nc, k)); w /= w.sum(1, keepdims=True)
+    idx = rng.integers(0, n, (nc, k)); idx[:, 3] = idx[:, 2]
+    data = rng.standard_normal((n, 1, t)).astype(np.float32)
+    plan = ops.InterpPlan(dev(idx, pt.int32), n)
+    out = plan.interp(dev(w), dev(data)).cpu().numpy()
+    ref = orc.interp(w, idx, data)
+    assert np.abs(out - ref).max() <= 1e-13 * np.abs(ref).max()
+    from sparsespatialsampling_amd._lib import S3HipError
+    with pytest.raises(S3HipError):
+        plan.interp(dev(w), dev(rng.standard_normal((n, 1, 25)).astype(np.float32)))     # ragged rows -> s3_interp
+    with pytest.raises(S3HipError):
+        ops.InterpPlan(dev(np.full((4, 8), n), pt.int32), n)                              # index out of range
+
+
 # ---- KNN cache (a16) -----------------------------------------------------------------------------------------
 @pytest.mark.parametrize("name,k", [("knncache_2d", 8), ("knncache_3d", 26)])
 def test_knn_cache_golden(ops, name, k):

@@ -292,7 +292,8 @@ __device__ void knn_search(const Grid<DIM> &g, const double *__restrict__ pts, c
     }
 }
 
-// numpy pairwise sum of f(m), m = 0..k-1 (see oracle/s3_oracle.c numpy_pairwise_sum)
+// numpy's pairwise summation of f(m), m = 0..k-1, for k <= 128 (numpy/_core/src/umath/loops_utils.h.src): eight
+// interleaved accumulators combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), tail added sequentially
 template <typename F>
 __device__ __forceinline__ double numpy_pairwise(int k, F f) {
     if (k < 8) {
@@ -396,7 +397,8 @@ child_metric_kernel(Grid<DIM> g, const double *__restrict__ pts, const int32_t *
     metric_all[t] = idw_from_list(b, y);
 }
 
-// torch CPU inner-dimension sum order (oracle/s3_oracle.c torch_inner_sum), n <= 64
+// summation order of torch's CPU sum over a contiguous inner dimension of n <= 64 doubles (ATen SumKernel.cpp,
+// vectorized_inner_sum with 4-wide vectors and 4 interleaved vector accumulators)
 template <typename F>
 __device__ __forceinline__ double torch_inner_sum(int n, F f) {
     const int nv = n / 4;

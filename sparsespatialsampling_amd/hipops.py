@@ -42,6 +42,10 @@ def device():
     return pt.device("cuda", pt.cuda.current_device())
 
 
+def synchronize():
+    pt.cuda.current_stream().synchronize()
+
+
 def to_device(x, dtype=None):
     """numpy / CPU tensor / CUDA tensor -> contiguous CUDA tensor (optionally cast)."""
     if isinstance(x, np.ndarray):

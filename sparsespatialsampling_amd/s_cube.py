@@ -304,7 +304,7 @@ class SamplingTree(object):
         self._leaf_cells.add(0)
 
     def _cell_values(self):
-        """metric / gain of all cells on the host (lazy download; used by the ``Cell`` views and the oracle tests)"""
+        """metric / gain of all cells on the host (lazy download; used by the ``Cell`` views and the parity tests)"""
         if self._values is None or len(self._values["metric"]) != self._topo.n_cells:
             self._values = self._backend.download(self._topo.n_cells)
         return self._values

@@ -1,0 +1,60 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/s3hip.h declares (no compute calls)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "s3hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(s3_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported_and_bound():
+    from sparsespatialsampling_amd import _lib
+    lib = _lib.hip_lib()
+    names = declared_symbols()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), f"libs3hip.so does not export {n}"
+        assert n in _lib.HIP_SIGNATURES, f"{n} has no ctypes prototype in _lib.py"
+    assert set(_lib.HIP_SIGNATURES) == set(names)
+    assert lib.s3_abi_version() == 1
+
+
+def test_no_torch_types_in_abi():
+    text = open(os.path.join(ROOT, "include", "s3hip.h")).read()
+    code = re.sub(r"/\*.*?\*/", "", text, flags=re.S)                # declarations only, comments stripped
+    assert "torch" not in code.lower() and "at::" not in code and "std::" not in code and "Tensor" not in code
+
+
+def test_fails_loudly_without_device():
+    """no GPU here: every path into the hot path must raise, never fall back to a CPU computation"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from sparsespatialsampling_amd import _lib, geometry, hipops
+    from sparsespatialsampling_amd.s_cube import SamplingTree
+    with pytest.raises(_lib.HipUnavailableError):
+        hipops.device()
+    x = torch.rand(100, 2)
+    with pytest.raises(_lib.HipUnavailableError):
+        SamplingTree(x, torch.ones(100), [geometry.CubeGeometry("d", True, [0, 0], [1, 1])], uniform_level=1)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "sparsespatialsampling_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src and "oracle" not in src.lower(), f
+
+
+def test_topology_tables_selfcheck():
+    from sparsespatialsampling_amd import _lib
+    assert _lib.topo_lib().s3t_selfcheck(2) == 0 and _lib.topo_lib().s3t_selfcheck(3) == 0

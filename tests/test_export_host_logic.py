@@ -1,0 +1,139 @@
+"""
+Host logic of ExportData (batching state machine, HDF5 layout, XDMF text) on CPU.  The GPU entry points are replaced by
+oracle-backed stand-ins (test-only monkeypatch) and h5py by tests/fake_h5py.py; tests/test_gpu_refine.py runs the same
+class with the real kernels.
+"""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch as pt
+
+from oracle import s3_oracle as orc
+from tests import fake_h5py
+
+
+class _CpuKnn:
+    def __init__(self, pts, target_occupancy=0.0):
+        self.pts = pts.numpy() if isinstance(pts, pt.Tensor) else np.asarray(pts)
+        self.n, self.dim = self.pts.shape
+
+    def query(self, q, k):
+        q = q.numpy() if isinstance(q, pt.Tensor) else np.asarray(q)
+        idx, dist = orc.knn(self.pts, q, k)
+        return pt.from_numpy(idx.astype(np.int32)), pt.from_numpy(dist)
+
+    def close(self):
+        pass
+
+
+def _cpu_ops():
+    ops = types.SimpleNamespace()
+    ops.KnnIndex = _CpuKnn
+    ops.device = lambda: pt.device("cpu")
+    ops.synchronize = lambda: None
+    ops.to_device = lambda x, dtype=None: (pt.from_numpy(np.ascontiguousarray(x)) if isinstance(x, np.ndarray) else x).to(
+        dtype if dtype is not None else x.dtype).contiguous()
+    ops.idw_weights = lambda dist: pt.from_numpy(orc.idw_weights(dist.numpy()))
+    ops.interp = lambda w, idx, data, out=None: pt.from_numpy(orc.interp(w.numpy(), idx.numpy().astype(np.int64),
+                                                                          data.numpy()))
+    ops.InterpPlan = type("InterpPlan", (), {"__init__": lambda self, *a, **k: None,
+                                            "supports": staticmethod(lambda k, d: False)})
+    return ops
+
+
+@pytest.fixture
+def export_mod(monkeypatch):
+    fake_h5py.install()
+    import sparsespatialsampling_amd.export as export
+    monkeypatch.setattr(export, "hipops", _cpu_ops())
+    yield export
+    import sys
+    sys.modules.pop("h5py", None)
+
+
+def _scube(tmp_path, d=2, nc=40):
+    rng = np.random.default_rng(d)
+    centers = rng.random((nc, d))
+    return types.SimpleNamespace(n_dimensions=d, faces=pt.arange(nc * 2 ** d, dtype=pt.int32).reshape(nc, 2 ** d),
+                                 centers=pt.from_numpy(centers), vertices=pt.from_numpy(rng.random((nc * 2 ** d, d))),
+                                 levels=pt.ones((nc, 1), dtype=pt.int64), metric=None, size_initial_cell=2.5,
+                                 save_path=str(tmp_path), save_name="case", grid_name="grid_s_cube")
+
+
+def test_export_batches_layout_and_xdmf(export_mod, tmp_path):
+    rng = np.random.default_rng(0)
+    n, t_total = 500, 5
+    coords = rng.random((n, 2))
+    s = _scube(tmp_path)
+    metric0 = rng.random(n)
+    s.metric = pt.from_numpy(metric0)
+    ex = export_mod.ExportData(s, write_times=[str(0.1 * i) for i in range(t_total)])
+    p = rng.standard_normal((n, 1, t_total)).astype(np.float32)
+    u = rng.standard_normal((n, 2, t_total)).astype(np.float32)
+    # scalar field in two batches (3 + 2 snapshots), then a vector field at once
+    ex.export(pt.from_numpy(coords), pt.from_numpy(p[:, :, :3]), "p", n_snapshots_total=t_total)
+    assert ex._snapshot_counter == 3
+    ex.export(pt.from_numpy(coords), pt.from_numpy(p[:, :, 3:]), "p", n_snapshots_total=t_total)
+    assert ex._snapshot_counter == 0                       # finished -> state reset (reference export.py:302-319)
+    ex.export(pt.from_numpy(coords), pt.from_numpy(u), "U")
+
+    h5 = fake_h5py.dump(os.path.join(str(tmp_path), "case.h5"))
+    idx, dist = orc.knn(coords, s.centers.numpy(), 8)
+    w = orc.idw_weights(dist)
+    assert set(k for k in h5 if k.startswith("grid/")) == {"grid/faces", "grid/vertices", "grid/centers"}
+    assert set(k for k in h5 if k.startswith("constant/")) == {"constant/levels", "constant/metric",
+                                                               "constant/size_initial_cell"}
+    np.testing.assert_allclose(h5["constant/metric"], orc.interp(w, idx, metric0), rtol=1e-13)
+    ref_p, ref_u = orc.interp(w, idx, p), orc.interp(w, idx, u)
+    for i in range(t_total):
+        t = str(0.1 * i)
+        assert h5[f"data/{t}/p_center"].shape == (40,)                       # scalars are squeezed (export.py:285-287)
+        assert h5[f"data/{t}/U_center"].shape == (40, 2)
+        np.testing.assert_allclose(h5[f"data/{t}/p_center"], ref_p[:, 0, i], rtol=1e-13)
+        np.testing.assert_allclose(h5[f"data/{t}/U_center"], ref_u[:, :, i], rtol=1e-13)
+
+    xdmf = open(os.path.join(str(tmp_path), "case.xdmf")).read()
+    assert xdmf.startswith('<?xml version="1.0"?>\n<!DOCTYPE Xdmf SYSTEM "Xdmf.dtd" []>\n<Xdmf Version="2.0">\n<Domain>\n'
+                           '<Grid Name="grid_s_cube" GridType="Collection" CollectionType="temporal">\n')
+    assert xdmf.count('<Time Value=') == t_total and xdmf.endswith('</Grid>\n</Domain>\n</Xdmf>')
+    assert '<Topology TopologyType="Quadrilateral" NumberOfElements="40">\n<DataItem Format="HDF" DataType="Int" ' \
+           'Dimensions="40 4">\ncase.h5:/grid/faces\n' in xdmf
+    assert xdmf.count('<Attribute Name="levels" AttributeType="Vector" Center="Cell">') == 1     # only in the first step
+    assert '<Attribute Name="U" AttributeType="Vector" Center="Cell">\n<DataItem NumberType="Float" Precision="8" ' \
+           'Format="HDF" Dimensions="40 2">\ncase.h5:/data/0.0/U_center\n</DataItem>\n</Attribute>\n' in xdmf
+
+
+def test_export_errors(export_mod, tmp_path):
+    s = _scube(tmp_path)
+    s.metric = pt.zeros(10)
+    ex = export_mod.ExportData(s)                         # write_times=None -> warning now, ValueError on export
+    with pytest.raises(ValueError):
+        ex.export(pt.zeros((10, 2)), pt.zeros((10, 1, 2)), "p")
+    ex.write_times = "0.5"
+    assert ex.write_times == ["0.5"]
+    with pytest.raises(ValueError):
+        ex.export(pt.rand((10, 2)), pt.zeros(10), "p")     # rank-1 data
+
+
+def test_dataloader_roundtrip(export_mod, tmp_path):
+    from sparsespatialsampling_amd.data import Dataloader, Datawriter
+    rng = np.random.default_rng(1)
+    wr = Datawriter(str(tmp_path), "g.h5")
+    wr.write_data("centers", group="grid", data=rng.random((7, 3)))
+    wr.write_data("vertices", group="grid", data=rng.random((20, 3)))
+    wr.write_data("faces", group="grid", data=np.arange(56).reshape(7, 8))
+    wr.write_data("levels", group="constant", data=np.array([[1], [2], [2], [3], [1], [1], [2]]))
+    wr.write_data("size_initial_cell", group="constant", data=2.0)
+    wr.n_cells = 7
+    for t in ("0.1", "0.2"):
+        wr.write_data("p", group="data", time_step=t, data=rng.random(7))          # suffix added: p_center
+        wr.write_data("U", group="data", time_step=t, data=rng.random((7, 3)))
+    wr.write_data("p", group="data", time_step="0.1", data=rng.random(7))          # duplicate -> warning, no crash
+    wr.write_xdmf_file()
+    ld = Dataloader(str(tmp_path), "g.h5")
+    assert ld.write_times == ["0.1", "0.2"] and ld.field_names["0.1"] == ["p", "U"]
+    assert ld.load_snapshot("p").shape == (7, 2) and ld.load_snapshot("U").shape == (7, 3, 2)
+    assert pt.allclose(ld.weights, (2.0 / 2.0 ** ld.levels.double()) ** 3)
+    assert 'TopologyType="Hexahedron"' in open(os.path.join(str(tmp_path), "g.xdmf")).read()

@@ -1,0 +1,68 @@
+"""N>1 path on CPU: world_size-2 gloo run of the refine reduction split + shard helpers (no GPU)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch as pt
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    for p in (ROOT, os.path.join(ROOT, "tests", "golden")):
+        sys.path.insert(0, p) if p not in sys.path else None
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sparsespatialsampling_amd.s_cube as s_cube
+    from sparsespatialsampling_amd import geometry, parallel
+    from inputs import refine_inputs
+    from tests.oracle_backend import OracleTreeBackend
+    import logging
+    logging.getLogger().setLevel(logging.WARNING)
+    s_cube._make_backend = lambda v, t, k: OracleTreeBackend(v, t, k)          # test-only injection (no GPU here)
+    assert parallel.world() == (rank, world)
+    x, y, geos, kw = refine_inputs("refine_2d_delta", geometry)
+    tree = s_cube.SamplingTree(pt.from_numpy(x), pt.from_numpy(y), geometry_obj=geos, **kw)
+    tree.refine()                                    # every captured-metric evaluation went through all_reduce
+    res = dict(metric=np.array(tree._metric), centers=tree.all_centers.numpy(), levels=tree.all_levels.numpy(),
+               shard=parallel.shard_range(1001))
+    gathered = [None] * world
+    dist.all_gather_object(gathered, res)
+    if rank == 0:
+        pt.save(gathered, out)
+    dist.destroy_process_group()
+
+
+def test_refine_two_ranks_gloo(tmp_path):
+    out = str(tmp_path / "res.pt")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = pt.load(out, weights_only=False)
+    z = np.load(os.path.join(ROOT, "tests", "golden", "refine_2d_delta.npz"))
+    for r in (r0, r1):                                # both ranks reproduce the reference grid
+        assert np.array_equal(r["centers"], z["all_centers"]) and np.array_equal(r["levels"], z["all_levels"])
+        np.testing.assert_allclose(r["metric"], z["metric_hist"], rtol=1e-12)
+    assert np.array_equal(r0["metric"], r1["metric"])  # identical on all ranks (all_reduce)
+    assert r0["shard"] == (0, 501) and r1["shard"] == (501, 1001)
+
+
+def test_shard_range_covers_everything():
+    from sparsespatialsampling_amd.parallel import shard_range
+    for n in (0, 1, 7, 8, 1000, 461130):
+        for w in (1, 2, 3, 8):
+            parts = [shard_range(n, r, w) for r in range(w)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+            sizes = [b - a for a, b in parts]
+            assert max(sizes) - min(sizes) <= 1

@@ -246,7 +246,7 @@ class SamplingTree(object):
         self._leaf_cells = set()
         self._n_cells_after_uniform = None
         self._N_cells_per_iter = []
-        self.all_nodes = []
+        self._final_nodes = None
         self.all_centers = []
         self.all_levels = None
         self.face_ids = None
@@ -567,7 +567,7 @@ class SamplingTree(object):
         dtype = np.int32 if self._n_cells < pt.iinfo(pt.int32).max else np.int64
         faces, nodes = self._topo.finalize()
         self.face_ids = pt.from_numpy(faces.astype(dtype))
-        self.all_nodes = pt.from_numpy(nodes)
+        self._final_nodes = pt.from_numpy(nodes)
         leaves = np.fromiter(self._leaf_cells, dtype=np.int64, count=len(self._leaf_cells))
         self.all_centers = pt.from_numpy(self._topo.center[leaves].copy())
         self.all_levels = pt.from_numpy(self._topo.level[leaves].astype(np.int64)).unsqueeze(-1)
@@ -613,6 +613,14 @@ class SamplingTree(object):
                   """.format(len(self._leaf_cells), self._current_min_level, self._current_max_level,
                              self._metric[-1] * 100)]
         return "\n\t\t\t\t\t\t\t\t".join(message)
+
+    @property
+    def all_nodes(self):
+        """node coordinates: every node created so far while the tree is being refined (the reference keeps a growing
+        list, s_cube.py:168,1225), the renumbered ``[n_nodes, d]`` tensor once the grid is assembled (s_cube.py:769)"""
+        if self._final_nodes is not None:
+            return self._final_nodes
+        return pt.from_numpy(self._topo.nodes.copy()) if self._topo is not None else []
 
     @property
     def n_dimensions(self) -> int:

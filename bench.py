@@ -73,6 +73,21 @@ def cpu_baseline(x_host, centers, k, t_sample, seconds=12.0):
                        f"k={k}, fp32 in / f64 out, {n_src} source points")
 
 
+def recorded_traffic(workload):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/rNN/summary.json:
+    FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE, separate rocprofv3 --pmc runs of this very
+    command); None when no pass was recorded for this workload string"""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "summary.json")), reverse=True):
+        try:
+            rec = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        if rec.get("workload") == workload and "traffic_bytes_per_launch" in rec:
+            return rec["traffic_bytes_per_launch"]
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -180,19 +195,19 @@ def main():
         # idx (int32) / weights (f64) once
         b_alg = n_unique * t_b * 4 + nc * t_b * 8 + nc * k * (4 + 8)
         achieved = b_alg / (kernel_ms * 1e-3) / 1e9
+        workload = (f"{args.workload} (synthetic, SURVEY 8(d) C3): {n_src} points x {t_b} snapshots "
+                    f"per step, {nc} generated cells, k={k}, fp32 in / f64 out")
         res = {
             "metric": "Mcells*snapshots/s interpolated", "value": value, "unit": "Mcells*snapshots/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.workload} (synthetic, SURVEY 8(d) C3): {n_src} points x {t_b} snapshots "
-                                   f"per step, {nc} generated cells, k={k}, fp32 in / f64 out",
-                       "n_points": n_src, "n_cells": nc, "t_batch": t_b, "k": k, "n_comp": 1,
+            "config": {"workload": workload, "n_points": n_src, "n_cells": nc, "t_batch": t_b, "k": k, "n_comp": 1,
                        "parallelism": f"snapshot-axis shards x{world}"},
             "refine_wall_s": refine_s, "refine_iterations": info["iterations"], "refine_cells_created": n_cells_total,
             "refine_leaves_per_s": nc / refine_s, "knn_cache_s": knn_cache_s,
             "captured_metric": info["metric_per_iter"][-1],
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": None, "kernel": "interp_kernel<float,4>" if plan is None else "interp_planned_kernel<float>",
+                         "traffic": recorded_traffic(workload) if plan is not None else None, "kernel": "interp_kernel<float,4>" if plan is None else "interp_planned_kernel<float>",
                          "staged_rows_per_launch": None if plan is None else plan.total_rows, "kernel_ms": kernel_ms,
                          "algorithmic_bytes": b_alg, "unique_source_rows": n_unique,
                          "gather_upper_bound_bytes": nc * k * t_b * 4 + nc * t_b * 8},

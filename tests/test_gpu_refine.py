@@ -96,3 +96,54 @@ def test_export_pipeline_gpu(tmp_path):
     assert np.array_equal(ex._knn_idx_centers.cpu().numpy(), idx_o)
     ref_metric = orc.interp(orc.idw_weights(dist_o), idx_o, y)
     assert np.abs(ex._metric.numpy() - ref_metric).max() <= 1e-13 * np.abs(ref_metric).max()
+
+
+def _naca_polygon(n=120, chord=1.0, t=0.12):
+    """closed NACA-00xx outline (the OAT15-like body of BASELINE config C2)"""
+    xs = 0.5 * (1 - np.cos(np.linspace(0, np.pi, n // 2)))
+    yt = 5 * t * (0.2969 * np.sqrt(xs) - 0.126 * xs - 0.3516 * xs ** 2 + 0.2843 * xs ** 3 - 0.1036 * xs ** 4)
+    upper = np.stack([xs, yt], 1)
+    lower = np.stack([xs[::-1], -yt[::-1]], 1)[1:-1]
+    return np.concatenate([upper, lower]) * chord
+
+
+def test_refine_polygon_body_2d_vs_oracle_backend(monkeypatch):
+    """C2-like: 2-D, polygon body (GeometryCoordinates2D, refined), n_cells_max stopping: HIP backend == oracle backend"""
+    import sparsespatialsampling_amd.s_cube as s_cube
+    from sparsespatialsampling_amd import geometry
+    from tests.oracle_backend import OracleTreeBackend
+    rng = np.random.default_rng(11)
+    poly = _naca_polygon()
+    x = np.concatenate([rng.random((30000, 2)) * [1.4, 1.0] + [-0.2, -0.5],
+                        poly[rng.integers(0, len(poly), 10000)] + 0.03 * rng.standard_normal((10000, 2))])
+    y = 0.05 + np.exp(-8 * np.abs(x[:, 1])) * (1 + np.sin(6 * x[:, 0]) ** 2)
+
+    def geos():
+        return [geometry.CubeGeometry("domain", True, [-0.2, -0.5], [1.2, 0.5]),
+                geometry.GeometryCoordinates2D("airfoil", False, poly, refine=True, min_refinement_level=8)]
+
+    kw = dict(uniform_level=4, n_cells=6000)
+    t_hip = s_cube.SamplingTree(pt.from_numpy(x), pt.from_numpy(y), geometry_obj=geos(), **kw)
+    t_hip.refine()
+    monkeypatch.setattr(s_cube, "_make_backend", lambda v, t, k: OracleTreeBackend(v, t, k))
+    t_orc = s_cube.SamplingTree(pt.from_numpy(x), pt.from_numpy(y), geometry_obj=geos(), **kw)
+    t_orc.refine()
+    assert pt.equal(t_hip.all_centers, t_orc.all_centers) and pt.equal(t_hip.all_levels, t_orc.all_levels)
+    assert pt.equal(t_hip.face_ids, t_orc.face_ids) and pt.equal(t_hip.all_nodes, t_orc.all_nodes)
+    assert np.array_equal(t_hip._cell_values()["gain"], t_orc._cell_values()["gain"])
+    assert int(t_hip.all_levels.max()) >= 8 and len(t_hip.all_levels) > 6000      # geometry refinement overshoots the cap
+    # no generated cell lies completely inside the airfoil
+    inside = np.array([geos()[1].check_cell(t_hip.all_nodes[f.long()]) for f in t_hip.face_ids[:2000]])
+    assert not inside.any()
+
+
+def test_pre_select_quirk_gpu():
+    """reference quirk (s_cube.py:1832-1836): with pre_select=True no cell is ever removed"""
+    import sparsespatialsampling_amd.s_cube as s_cube
+    from sparsespatialsampling_amd import geometry
+    x = cloud(5, 3000, [0, 0], [1, 1])
+    y = wake_metric(x, [0.3, 0.5])
+    geos = [geometry.CubeGeometry("domain", True, [0, 0], [1, 1]), geometry.SphereGeometry("hole", False, [0.5, 0.5], 0.3)]
+    tree = s_cube.SamplingTree(pt.from_numpy(x), pt.from_numpy(y), geometry_obj=geos, uniform_level=3, pre_select=True)
+    tree._refine_uniform()
+    assert len(tree._leaf_cells) == 64 and (tree._topo.first_child != -2).all()

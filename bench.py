@@ -35,7 +35,7 @@ WORKLOADS = {
     # name: (n_points, T_batch, uniform_levels, min_metric)
     "cylinder3D_Re3900": dict(n=5_000_000, lo=[0.0, 0.0, 0.0], hi=[2.4, 2.0, 0.1 * np.pi], t_batch=1000,
                               uniform_levels=5, min_metric=0.75, seed=2),
-    "cylinder3D_small": dict(n=300_000, lo=[0.0, 0.0, 0.0], hi=[2.4, 2.0, 0.1 * np.pi], t_batch=250,
+    "cylinder3D_small": dict(n=300_000, lo=[0.0, 0.0, 0.0], hi=[2.4, 2.0, 0.1 * np.pi], t_batch=256,
                              uniform_levels=4, min_metric=0.6, seed=2),
 }
 
@@ -103,9 +103,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    pt.cuda.set_device(local_rank)
+    # S3_BENCH_SHARE_GPU=1 + S3_DIST_BACKEND=gloo: rehearsal of the N>1 code path on a box with a single GPU
+    share = os.environ.get("S3_BENCH_SHARE_GPU") == "1"
+    pt.cuda.set_device(0 if share else local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=pt.device("cuda", local_rank))
+        backend = os.environ.get("S3_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=pt.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from sparsespatialsampling_amd import geometry, hipops
     from sparsespatialsampling_amd.s_cube import SamplingTree
@@ -144,7 +150,7 @@ def main():
     knn.close()
     del dist_
     plan = None
-    if not args.direct:
+    if not args.direct and cfg["t_batch"] % 4 == 0:      # the tiled kernel needs 16-byte aligned fp32 rows
         plan = hipops.InterpPlan(idx, len(x), centers, tile_cells=int(os.environ.get("S3_TILE_CELLS", "0")))
         pt.cuda.synchronize()
     knn_cache_s = time.perf_counter() - t0

@@ -38,6 +38,8 @@ def allreduce_sumsq(backend, n_cells):
     if size == 1:
         return backend.sumsq(n_cells)
     begin, end = shard_range(n_cells, rank, size)
-    part = backend.sumsq_range(begin, end)          # device tensor (nccl) or CPU tensor (gloo tests)
+    part = backend.sumsq_range(begin, end)          # 1-element device tensor (RCCL) or CPU tensor (gloo tests)
+    if part.is_cuda and dist.get_backend() == "gloo":
+        part = part.cpu()                           # single-GPU rehearsal of the multi-rank path
     dist.all_reduce(part, op=dist.ReduceOp.SUM)
     return float(part.item())

@@ -123,6 +123,17 @@ def main():
         cfg["t_batch"] = args.t_batch
     k = 26
     x, metric = synthetic_cylinder3d(cfg)
+    if os.environ.get("S3_BENCH_MESH_ORDER") == "1":
+        # experiment: points stored in a spatially coherent order (as a CFD mesh numbering would be) instead of random
+        q = ((x - x.min(0)) / (x.max(0) - x.min(0)).max() * 1023).astype(np.int64)
+
+        def spread(v):
+            v = (v | (v << 16)) & 0x030000FF
+            v = (v | (v << 8)) & 0x0300F00F
+            v = (v | (v << 4)) & 0x030C30C3
+            return (v | (v << 2)) & 0x09249249
+        order = np.argsort(spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2), kind="stable")
+        x, metric = np.ascontiguousarray(x[order]), np.ascontiguousarray(metric[order])
     geos = [geometry.CubeGeometry("domain", True, cfg["lo"], [float(v) for v in cfg["hi"]]),
             geometry.CylinderGeometry3D("cylinder", False, [(0.8, 1.0, -1.0), (0.8, 1.0, 1.0)], 0.05, refine=True)]
 

@@ -22,7 +22,6 @@
 #include "common.h"
 
 #include <algorithm>
-#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <vector>
@@ -90,66 +89,82 @@ interp_planned_kernel(const int32_t *__restrict__ perm, const int32_t *__restric
     // are loaded once per tile; the segment loads of chunk c+1 are issued (into registers) before chunk c is accumulated
     // from LDS, so HBM latency overlaps the LDS/FMA phase.
     const int srow = threadIdx.x >> 3, svec = threadIdx.x & 7;
-    // sixteen named registers per lane instead of an array: a loop-carried local array ends up in scratch memory
+    // 2 x sixteen named registers per lane (sets A and B) instead of arrays: a loop-carried local array ends up in
+    // scratch memory.  Two chunks are kept in flight: while chunk c is accumulated from LDS, the segments of chunk c+1
+    // (other set) and c+2 (the set just emptied into LDS) are on their way.
 #define S3_REP16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
     static_assert(PL_NP == 16, "S3_REP16 expands PL_NP staging passes");
-#define S3_DECL(P) const int64_t rbase##P = (int64_t)rows[r_begin + min(P * RPP + srow, n_r - 1)] * in_stride; V pre##P;
+#define S3_DECL(P) const int64_t rbase##P = (int64_t)rows[r_begin + min(P * RPP + srow, n_r - 1)] * in_stride; V preA##P, preB##P;
     S3_REP16(S3_DECL)
     // (row ids are clamped to the tile's last row and the column to the row: every load is in bounds, unconditional)
-#define S3_LOAD(P) pre##P = *reinterpret_cast<const V *>(seg_ + rbase##P);
-#define S3_ISSUE(CH)                                                 \
+#define S3_LOAD_A(P) preA##P = *reinterpret_cast<const V *>(seg_ + rbase##P);
+#define S3_LOAD_B(P) preB##P = *reinterpret_cast<const V *>(seg_ + rbase##P);
+#define S3_ISSUE(SET, CH)                                            \
     do {                                                             \
         const int64_t c0_ = (int64_t)(CH) * EPC;                     \
         const bool ok_ = c0_ + (int64_t)(svec + 1) * EPV <= row_len; \
         const T *seg_ = data + c0_ + (ok_ ? svec : 0) * EPV;         \
-        S3_REP16(S3_LOAD)                                            \
+        S3_REP16(S3_LOAD_##SET)                                      \
     } while (0)
-#define S3_STORE(P) if (P * RPP + srow < n_r) s_data[(P * RPP + srow) * 8 + svec] = pre##P;
-    if (chunk0 < chunk1) S3_ISSUE(chunk0);
+#define S3_STORE_A(P) if (P * RPP + srow < n_r) s_data[(P * RPP + srow) * 8 + svec] = preA##P;
+#define S3_STORE_B(P) if (P * RPP + srow < n_r) s_data[(P * RPP + srow) * 8 + svec] = preB##P;
 
-    for (int chunk = chunk0; chunk < chunk1; ++chunk) {
+    // accumulate the k neighbours of this thread's cell from LDS and write its 2 x 32 B of the output row
+    auto accumulate = [&](int chunk) {
+        if (!has_cell) return;
         const int64_t col0 = (int64_t)chunk * EPC;
-        S3_REP16(S3_STORE)
-        __syncthreads();
-        if (chunk + 1 < chunk1) S3_ISSUE(chunk + 1);
-        // ---- accumulate the k neighbours of this thread's cell from LDS ---------------------------------------------
-        if (has_cell) {
-            double acc0[EPV], acc1[EPV];
+        double acc0[EPV], acc1[EPV];
 #pragma unroll
-            for (int i = 0; i < EPV; ++i) acc0[i] = acc1[i] = 0.0;
+        for (int i = 0; i < EPV; ++i) acc0[i] = acc1[i] = 0.0;
 #pragma unroll 4
-            for (int m = 0; m < k; ++m) {
-                const int pos = s_loc[m * TC + cl];
-                const double wm = s_w[m * TC + cl];
-                const V a = s_data[pos * 8 + v0];
-                const V c = s_data[pos * 8 + v0 + 4];
-                const T *ae = reinterpret_cast<const T *>(&a);
-                const T *ce = reinterpret_cast<const T *>(&c);
+        for (int m = 0; m < k; ++m) {
+            const int pos = s_loc[m * TC + cl];
+            const double wm = s_w[m * TC + cl];
+            const V a = s_data[pos * 8 + v0];
+            const V c = s_data[pos * 8 + v0 + 4];
+            const T *ae = reinterpret_cast<const T *>(&a);
+            const T *ce = reinterpret_cast<const T *>(&c);
 #pragma unroll
-                for (int i = 0; i < EPV; ++i) {
-                    acc0[i] = fma(wm, (double)ae[i], acc0[i]);
-                    acc1[i] = fma(wm, (double)ce[i], acc1[i]);
-                }
-            }
-            double *o = out + cell * row_len + col0;
-            if (col0 + (int64_t)(v0 + 1) * EPV <= row_len) {
-#pragma unroll
-                for (int i = 0; i < EPV; i += 2)
-                    *reinterpret_cast<double2 *>(o + v0 * EPV + i) = make_double2(acc0[i], acc0[i + 1]);
-            }
-            if (col0 + (int64_t)(v0 + 5) * EPV <= row_len) {
-#pragma unroll
-                for (int i = 0; i < EPV; i += 2)
-                    *reinterpret_cast<double2 *>(o + (v0 + 4) * EPV + i) = make_double2(acc1[i], acc1[i + 1]);
+            for (int i = 0; i < EPV; ++i) {
+                acc0[i] = fma(wm, (double)ae[i], acc0[i]);
+                acc1[i] = fma(wm, (double)ce[i], acc1[i]);
             }
         }
+        double *o = out + cell * row_len + col0;
+        if (col0 + (int64_t)(v0 + 1) * EPV <= row_len) {
+#pragma unroll
+            for (int i = 0; i < EPV; i += 2)
+                *reinterpret_cast<double2 *>(o + v0 * EPV + i) = make_double2(acc0[i], acc0[i + 1]);
+        }
+        if (col0 + (int64_t)(v0 + 5) * EPV <= row_len) {
+#pragma unroll
+            for (int i = 0; i < EPV; i += 2)
+                *reinterpret_cast<double2 *>(o + (v0 + 4) * EPV + i) = make_double2(acc1[i], acc1[i + 1]);
+        }
+    };
+
+    if (chunk0 < chunk1) S3_ISSUE(A, chunk0);
+    if (chunk0 + 1 < chunk1) S3_ISSUE(B, chunk0 + 1);
+    for (int chunk = chunk0; chunk < chunk1; chunk += 2) {
+        S3_REP16(S3_STORE_A)
+        __syncthreads();
+        if (chunk + 2 < chunk1) S3_ISSUE(A, chunk + 2);
+        accumulate(chunk);
+        __syncthreads();
+        if (chunk + 1 >= chunk1) break;
+        S3_REP16(S3_STORE_B)
+        __syncthreads();
+        if (chunk + 3 < chunk1) S3_ISSUE(B, chunk + 3);
+        accumulate(chunk + 1);
         __syncthreads();
     }
 }
 
 #undef S3_ISSUE
-#undef S3_LOAD
-#undef S3_STORE
+#undef S3_LOAD_A
+#undef S3_LOAD_B
+#undef S3_STORE_A
+#undef S3_STORE_B
 #undef S3_DECL
 #undef S3_REP16
 
@@ -199,7 +214,6 @@ static int launch_planned(const s3_interp_plan *p, const double *w, const void *
     // (measured on MI355X: one workgroup per tile over ALL chunks is fastest -- 3.7 ms vs 4.4 ms with 4 chunks per
     //  workgroup on the cylinder3D workload -- so the split is only used when there are too few tiles to fill the chip)
     int gy = 1;
-    if (const char *e = getenv("S3_PLAN_CHUNKS_PER_BLOCK")) gy = (n_chunks + atoi(e) - 1) / std::max(1, atoi(e));
     while (gx * gy < 2048 && gy < n_chunks) gy *= 2;
     if (gy > n_chunks) gy = n_chunks;
     if (gy < 1) gy = 1;

@@ -530,17 +530,24 @@ class SamplingTree(object):
                 logger.info(f"\r\t\t\t\t\t\t\t\t\tRefining level {_global_min_level+1} / {_global_max_level}.")
                 to_refine, checked = set(), set()
                 level = self._topo.level
-                for i in _all_cells:
-                    if i in checked:
-                        continue
-                    if int(level[i]) < _global_max_level:
-                        to_refine.add(i)
-                        self._topo.relink_parent_of([i])
-                    if self._max_delta_level:
+                if self._max_delta_level:
+                    for i in _all_cells:
+                        if i in checked:
+                            continue
+                        if int(level[i]) < _global_max_level:
+                            to_refine.add(i)
+                            self._topo.relink_parent_of([i])
                         nb_to_refine_as_well = set(self._check_nb(i))
                         nb_to_refine_as_well.update(self._check_constraint(nb_to_refine_as_well))
                         to_refine.update(nb_to_refine_as_well)
                         checked.update(nb_to_refine_as_well)
+                else:
+                    # same insertion sequence as the loop above, neighbour refresh batched into one native call (the
+                    # refresh of one parent does not depend on the refresh of another)
+                    cells = np.fromiter(_all_cells, dtype=np.int64, count=len(_all_cells))
+                    cells = cells[level[cells] < _global_max_level]
+                    to_refine.update(cells.tolist())
+                    self._topo.relink_parent_of(cells)
 
                 first, n_new = self._refine_cells(to_refine)
                 _idx_new = set(range(first, first + n_new))

@@ -1,7 +1,7 @@
 """dev helper: neighbour-sharing statistics of consecutive-cell tiles (creation order vs Morton order)"""
 import sys, time, logging
 import numpy as np, torch as pt
-sys.path.insert(0, ".")
+sys.path.insert(0, ".")  # run from the repo root
 import bench
 from sparsespatialsampling_amd import geometry, hipops
 from sparsespatialsampling_amd.s_cube import SamplingTree

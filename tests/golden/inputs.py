@@ -44,6 +44,12 @@ REFINE_CASES = {
     # 3-D: cube + cylinder body (refined), metric stopping
     "refine_3d_metric": dict(d=3, seed=74, n=20000, lo=[0.0, 0.0, 0.0], hi=[2.4, 2.0, 0.3], body="cylinder",
                              kw=dict(uniform_level=3, min_metric=0.45)),
+    # 3-D with 2:1 balance: exercises the 26-slot neighbour walks of _check_nb / _check_constraint
+    "refine_3d_delta": dict(d=3, seed=75, n=9000, lo=[0.0, 0.0, 0.0], hi=[1.0, 1.0, 1.0], body="sphere3d",
+                            kw=dict(uniform_level=2, min_metric=0.4, max_delta_level=True)),
+    # 3-D, n_cells_max stopping, cone body (two radii) refined to a fixed level
+    "refine_3d_ncells_cone": dict(d=3, seed=76, n=12000, lo=[0.0, 0.0, 0.0], hi=[2.0, 1.0, 1.0], body="cone",
+                                  kw=dict(uniform_level=3, n_cells=3000, n_cells_iter_start=20, n_cells_iter_end=5)),
 }
 
 
@@ -61,6 +67,17 @@ def refine_inputs(name, geometry):
         else:
             body = geometry.SphereGeometry("cylinder", False, centre, rad)
         y = wake_metric(x, centre)
+    elif case["body"] == "sphere3d":
+        centre, rad = [0.4, 0.5, 0.5], 0.12
+        keep = ((x - np.asarray(centre)) ** 2).sum(1) > rad ** 2
+        x = np.ascontiguousarray(x[keep])
+        body = geometry.SphereGeometry("ball", False, centre, rad, refine=True)
+        y = wake_metric(x, centre, decay=4.0)
+    elif case["body"] == "cone":
+        centre = [0.6, 0.5, 0.5]
+        body = geometry.CylinderGeometry3D("cone", False, [(0.4, 0.5, 0.5), (0.9, 0.5, 0.5)], [0.2, 0.05], refine=True,
+                                           min_refinement_level=5)
+        y = wake_metric(x, centre, decay=3.0)
     else:
         centre, rad = [0.8, 1.0, 0.0], 0.15
         keep = ((x[:, :2] - np.asarray(centre[:2])) ** 2).sum(1) > rad ** 2

@@ -26,7 +26,8 @@ def test_uniform_tables_gpu(d):
     check_tree_against_golden(tree, z)
 
 
-@pytest.mark.parametrize("name", ["refine_2d_metric", "refine_2d_ncells", "refine_2d_delta", "refine_3d_metric"])
+@pytest.mark.parametrize("name", ["refine_2d_metric", "refine_2d_ncells", "refine_2d_delta", "refine_3d_metric",
+                                  "refine_3d_delta", "refine_3d_ncells_cone"])
 def test_refine_matches_reference_gpu(name):
     """cell ids / levels / centres / faces / vertices / per-cell metric + gain: bit-exact vs the real reference"""
     import sparsespatialsampling_amd.s_cube as s_cube

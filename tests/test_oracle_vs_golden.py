@@ -90,7 +90,8 @@ def test_masks():
     assert 0 < z["cyl3_0_r0"].sum() < 400 and 0 < z["poly2_1_r1"].sum() < 400     # non-trivial truth tables
 
 
-@pytest.mark.parametrize("name,k", [("refine_2d_metric", 8), ("refine_2d_delta", 8), ("refine_3d_metric", 26)])
+@pytest.mark.parametrize("name,k", [("refine_2d_metric", 8), ("refine_2d_delta", 8), ("refine_3d_metric", 26),
+                                    ("refine_3d_delta", 26), ("refine_3d_ncells_cone", 26)])
 def test_child_gain_trace(name, k):
     """metric + gain of every cell the reference created (s_cube.py:207-241,1859) -- bit exact."""
     z = load(name)

@@ -72,7 +72,8 @@ def test_uniform_tables(oracle_backend, d):
     assert tree._topo.n_nodes == (2 ** 3 + 1) ** d            # perfect sharing on a uniform grid: 81 / 729
 
 
-@pytest.mark.parametrize("name", ["refine_2d_metric", "refine_2d_ncells", "refine_2d_delta", "refine_3d_metric"])
+@pytest.mark.parametrize("name", ["refine_2d_metric", "refine_2d_ncells", "refine_2d_delta", "refine_3d_metric",
+                                  "refine_3d_delta", "refine_3d_ncells_cone"])
 def test_refine_matches_reference(oracle_backend, name):
     z = load(name)
     x, y, geos, kw = refine_inputs(name, geometry)

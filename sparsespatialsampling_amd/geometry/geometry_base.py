@@ -1,12 +1,12 @@
 """
-Base class of the geometry objects that bound the numerical domain (``keep_inside=True``) or cut bodies out of it
-(``keep_inside=False``).
+Common behaviour of the geometry objects: the numerical domain (``keep_inside=True``: everything outside is discarded) and
+bodies cut out of it (``keep_inside=False``: everything inside is discarded).
 
-API mirror of the reference's ``geometry/geometry_base.py`` (GeometryObject: ``_apply_mask`` :40-76, common argument
-checks :78-107, abstract interface :109-222).  In this package the per-cell predicate on the hot path runs on the GPU:
-every in-scope geometry describes itself through ``kernel_spec()`` and the refine loop hands that description to the
-matching ``s3_mask_*`` kernel (include/s3hip.h).  ``check_cell`` remains as the host-side, single-cell entry point
-with the reference's signature and truth table.
+API mirror of the reference's ``geometry/geometry_base.py`` (``GeometryObject``: verdict policy ``_apply_mask`` at
+reference lines 40-76, common argument checks 78-107, abstract interface 109-222).  On the hot path the per-cell
+predicate runs on the GPU: every in-scope geometry describes itself through ``kernel_spec()`` and the refine loop hands
+that description to the matching ``s3_mask_*`` kernel (include/s3hip.h).  ``check_cell`` is the host-side, single-cell
+entry point with the reference's signature and truth table.
 """
 import logging
 from abc import ABC, abstractmethod
@@ -18,86 +18,72 @@ logger = logging.getLogger(__name__)
 
 class GeometryObject(ABC):
     def __init__(self, name: str, keep_inside: bool, refine: bool = False, min_refinement_level: int = None):
-        self._name = name
-        self._keep_inside = keep_inside
-        self._refine = refine
-        self._min_refinement_level = min_refinement_level
+        self._name, self._keep_inside = name, keep_inside
+        self._refine, self._min_refinement_level = refine, min_refinement_level
         self._check_common_arguments()
 
+    # -- verdict ---------------------------------------------------------------------------------------------------
     def _apply_mask(self, mask: Tensor, refine_geometry: bool) -> bool:
-        """Cell verdict from the per-node inside mask (truth table of reference geometry_base.py:40-76):
+        """Cell verdict from the per-node "inside the geometry" mask:
 
         ===============  ===========================  ==========================
         mode             keep_inside=True (domain)    keep_inside=False (body)
         ===============  ===========================  ==========================
-        remove cells     no node inside               all nodes inside
-        refine geometry  not all nodes inside         any node inside
+        remove cell?     no node inside               all nodes inside
+        refine here?     not all nodes inside         any node inside
         ===============  ===========================  ==========================
         """
-        n_in, n = int(mask.sum()), mask.numel()
-        if not refine_geometry:
-            verdict = (n_in == 0) if self._keep_inside else (n_in == n)
-        else:
-            verdict = (n_in != n) if self._keep_inside else (n_in > 0)
-        return bool(verdict)
+        inside, total = int(mask.sum()), mask.numel()
+        if refine_geometry:
+            return inside != total if self._keep_inside else inside > 0
+        return inside == 0 if self._keep_inside else inside == total
 
     def _check_common_arguments(self) -> None:
-        assert self._name != "", "Found empty string for the geometry object name. Please provide a name."
-        assert isinstance(self._keep_inside, bool), (f"Invalid type for argument keep_inside. Expected bool but "
-                                                     f"{type(self._keep_inside)} was given.")
-        # a refinement level without refine=True means the user wants the geometry refined
-        if not self._refine and self._min_refinement_level is not None:
-            logger.warning(f"Found value refine={self._refine} while a min_refinement_level of "
-                           f"{self._min_refinement_level} was provided for geometry {self._name}. Changing refine from"
-                           f" {self._refine} to refine=True.")
-            self._refine = True
-        if self._refine and self._min_refinement_level is not None:
-            assert self._min_refinement_level > 0, (f"Expected min_refinement_level > 0 but found "
-                                                    f"min_refinement_level={self.min_refinement_level}.")
+        assert self._name != "", "A geometry object needs a non-empty name."
+        assert isinstance(self._keep_inside, bool), f"keep_inside has to be a bool, got {type(self._keep_inside)}."
+        if self._min_refinement_level is not None:
+            if not self._refine:
+                # a target level only makes sense for a refined geometry
+                logger.warning(f"Geometry {self._name}: min_refinement_level={self._min_refinement_level} was given "
+                               f"with refine=False; switching refine on.")
+                self._refine = True
+            assert self._min_refinement_level > 0, (f"min_refinement_level has to be positive, got "
+                                                    f"{self._min_refinement_level}.")
 
-    @property
-    def keep_inside(self):
-        return self._keep_inside
+    # -- read-only attributes --------------------------------------------------------------------------------------
+    name = property(lambda self: self._name)
+    keep_inside = property(lambda self: self._keep_inside)
+    refine = property(lambda self: self._refine)
+    min_refinement_level = property(lambda self: self._min_refinement_level)
 
-    @property
-    def name(self):
-        return self._name
-
-    @property
-    def refine(self):
-        return self._refine
-
-    @property
-    def min_refinement_level(self):
-        return self._min_refinement_level
-
+    # -- interface of the concrete geometries --------------------------------------------------------------------------
     @abstractmethod
     def check_cell(self, cell_nodes: Tensor, refine_geometry: bool = False) -> bool:
-        pass
+        """verdict for one cell given its ``[2^d, d]`` node coordinates"""
 
     @abstractmethod
     def kernel_spec(self) -> tuple:
         """``(kind, params...)`` consumed by the device mask kernels: ``("box", lo, hi)``, ``("sphere", pos, r)``,
-        ``("cylinder", p0, axis, norm, r0, r1, is_cone)`` or ``("polygon", xy[nv,2])``."""
+        ``("cylinder", p0, axis, norm, r0, r1, is_cone)`` or ``("polygon", xy[nv,2])``"""
 
     @abstractmethod
     def _check_geometry(self) -> None:
-        pass
+        """validate the constructor arguments of the concrete geometry"""
 
     @property
     @abstractmethod
     def type(self) -> str:
-        pass
+        """short type tag (``"cube"``, ``"sphere"``, ``"cylinder"``, ``"coord_2D"``)"""
 
     @property
     @abstractmethod
     def main_width(self) -> float:
-        pass
+        """largest extent; the width of the root cell if this geometry is the domain"""
 
     @property
     @abstractmethod
     def center(self) -> Tensor:
-        pass
+        """centre; the centre of the root cell if this geometry is the domain"""
 
     @abstractmethod
     def _compute_main_width(self) -> float:

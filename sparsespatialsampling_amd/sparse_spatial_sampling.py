@@ -1,15 +1,18 @@
 """
-User-facing entry point of S^3 grid generation -- drop-in for the reference's
-``sparseSpatialSampling/sparse_spatial_sampling.py`` (``SparseSpatialSampling`` :20-186, ``list_geometries`` :190-212).
+User-facing entry point of S^3 grid generation.
 
-The object stays picklable after ``execute_grid_generation()`` (reference :146 saves it with ``torch.save`` and the
-examples reload it): the GPU-backed ``SamplingTree`` is dropped before saving and only CPU tensors remain.
+Drop-in for ``sparseSpatialSampling.sparse_spatial_sampling`` of the reference (class ``SparseSpatialSampling`` at
+reference lines 20-186, ``list_geometries`` at 190-212): same constructor signature, same public attributes
+(``coordinates, metric, save_path, save_name, grid_name, centers, vertices, faces, levels, n_dimensions,
+size_initial_cell, n_jobs``), same side effects of ``execute_grid_generation`` (``mesh_info_<name>.pt`` and the pickled
+``s_cube_<name>.pt``) and the same exception types for invalid input.  The work itself is done by
+``s_cube.SamplingTree`` on the GPU; after grid generation the tree (and with it every device handle) is dropped, so the
+object that gets pickled holds CPU tensors only.
 """
 import inspect
 import logging
+import os
 import textwrap
-from os import makedirs, path
-from os.path import join
 from typing import Union
 
 import torch as pt
@@ -19,91 +22,92 @@ from .s_cube import SamplingTree
 logger = logging.getLogger(__name__)
 
 
+def _opt_int(value):
+    return None if value is None else int(value)
+
+
 class SparseSpatialSampling:
     def __init__(self, coordinates: pt.Tensor, metric: pt.Tensor, geometry_objects: list, save_path: str,
                  save_name: str, grid_name: str = "grid_s_cube", uniform_levels: int = 5,
                  n_cells_max: Union[int, float] = None, min_metric: float = 0.75, max_delta_level: bool = False,
                  n_cells_iter_start: int = None, n_cells_iter_end: int = None, n_jobs: int = 1,
                  relTol: Union[int, float] = 1e-3, reach_at_least: float = 0.75, pre_select_cells: bool = False):
-        """Arguments as in the reference (sparse_spatial_sampling.py:21-77)."""
+        """Arguments, defaults and meaning as in the reference constructor (sparse_spatial_sampling.py:21-77):
+        original cell centres ``[N, d]`` + per-cell metric ``[N]``, the geometry objects (one of them with
+        ``keep_inside=True``), where to save, and the refinement controls handed on to ``SamplingTree``.  ``n_jobs`` is
+        accepted for compatibility; the GPU path starts no worker processes."""
+        # public state read by ExportData (reference export.py:74-83) and by user scripts
         self.n_jobs = n_jobs
-        self.coordinates = coordinates
-        self.metric = metric
-        self.save_path = save_path
-        self.save_name = save_name
-        self.grid_name = grid_name
-        self.centers = None
-        self.vertices = None
-        self.faces = None
+        self.coordinates, self.metric = coordinates, metric
+        self.save_path, self.save_name, self.grid_name = save_path, save_name, grid_name
         self.n_dimensions = coordinates.squeeze().size(-1)
+        self.centers = self.vertices = self.faces = self.levels = None
         self.size_initial_cell = None
-        self.levels = None
 
         self._geometries = geometry_objects
         self._pre_select_cells = pre_select_cells
         self._level_bounds = int(uniform_levels)
-        self._n_cells_max = n_cells_max if n_cells_max is None else int(n_cells_max)
+        self._n_cells_max = _opt_int(n_cells_max)
         self._min_metric = min_metric
         self._max_delta_level = max_delta_level
-        self._n_cells_iter_start = n_cells_iter_start if n_cells_iter_start is None else int(n_cells_iter_start)
-        self._n_cells_iter_end = n_cells_iter_end if n_cells_iter_end is None else int(n_cells_iter_end)
+        self._n_cells_iter_start = _opt_int(n_cells_iter_start)
+        self._n_cells_iter_end = _opt_int(n_cells_iter_end)
         self._relTol = relTol
         self._reach_at_least = reach_at_least
 
         self._check_input()
-        self._sampling = SamplingTree(self.coordinates, self.metric, self._geometries, n_cells=self._n_cells_max,
-                                      uniform_level=self._level_bounds, min_metric=self._min_metric,
-                                      max_delta_level=self._max_delta_level, n_cells_iter_end=self._n_cells_iter_end,
-                                      n_cells_iter_start=self._n_cells_iter_start, n_jobs=self.n_jobs,
-                                      relTol=self._relTol, reach_at_least=self._reach_at_least,
-                                      pre_select=self._pre_select_cells)
+        self._sampling = SamplingTree(
+            self.coordinates, self.metric, self._geometries,
+            n_cells=self._n_cells_max, uniform_level=self._level_bounds, min_metric=self._min_metric,
+            max_delta_level=self._max_delta_level, n_cells_iter_start=self._n_cells_iter_start,
+            n_cells_iter_end=self._n_cells_iter_end, n_jobs=self.n_jobs, relTol=self._relTol,
+            reach_at_least=self._reach_at_least, pre_select=self._pre_select_cells)
 
     def execute_grid_generation(self) -> None:
-        """run S^3, keep the grid, persist ``mesh_info_<name>.pt`` and ``s_cube_<name>.pt`` (reference :116-146)"""
-        if not path.exists(self.save_path):
-            makedirs(self.save_path)
-        self._sampling.refine()
-        pt.save(self._sampling.data_final_mesh, join(self.save_path, f"mesh_info_{self.save_name}.pt"))
-        self.levels = self._sampling.all_levels
-        self.centers = self._sampling.all_centers
-        self.vertices = self._sampling.all_nodes
-        self.faces = self._sampling.face_ids
-        self.size_initial_cell = self._sampling.data_final_mesh["size_initial_cell"]
-        self._sampling = None          # releases the device arrays; what is left is CPU-only and picklable
-        pt.save(self, join(self.save_path, f"s_cube_{self.save_name}.pt"))
+        """Run S^3, take over the grid and persist the mesh info and this object (reference lines 116-146)."""
+        os.makedirs(self.save_path, exist_ok=True)
+        tree = self._sampling
+        tree.refine()
+        pt.save(tree.data_final_mesh, os.path.join(self.save_path, f"mesh_info_{self.save_name}.pt"))
+
+        self.centers, self.levels = tree.all_centers, tree.all_levels
+        self.vertices, self.faces = tree.all_nodes, tree.face_ids
+        self.size_initial_cell = tree.data_final_mesh["size_initial_cell"]
+
+        # drop the tree: frees the device arrays and leaves a CPU-only, picklable object
+        self._sampling = None
+        pt.save(self, os.path.join(self.save_path, f"s_cube_{self.save_name}.pt"))
 
     def _check_input(self) -> None:
-        assert len(self.metric.size()) == 1, (f"The size of the metric must be a 1D tensor of the length "
-                                              f"{self.coordinates.size(0)}. The size of the metric given is "
-                                              f"{self.metric.size()}.")
-        if self._n_cells_max is None:
-            if self._min_metric > 1:
-                logger.warning("A value of min_metric > 1 is invalid. Changed min_metric to 1.")
-                self._min_metric = self._min_metric if self._min_metric < 1 else 1
-        assert self._geometries, ("No geometries are provided. Please provide at least one geometry for the "
-                                  "numerical domain.")
-        assert any([g.keep_inside for g in self._geometries]), ("No geometry for the domain provided. At least one "
-                                                                "geometry object must have 'keep_inside = True' "
-                                                                "representing the numerical domain.")
+        """Validate / repair the user input (same conditions and exception types as reference lines 148-186)."""
+        shape = tuple(self.metric.size())
+        assert len(shape) == 1, (f"The metric has to be one value per original cell, i.e. a 1D tensor of length "
+                                 f"{self.coordinates.size(0)}; got a tensor of size {shape}.")
+        assert self._geometries, "At least one geometry object (the numerical domain) is required, none was given."
+        assert any(g.keep_inside for g in self._geometries), (
+            "None of the geometry objects has 'keep_inside = True'. Exactly the numerical domain must be marked that way.")
+
+        if self._n_cells_max is None and self._min_metric > 1:
+            logger.warning("min_metric > 1 cannot be reached, using min_metric = 1 instead.")
+            self._min_metric = 1
         if self._level_bounds <= 0:
-            logger.warning(f"Lower level bound of {self._level_bounds} is invalid. Changed lower level bound to 1.")
+            logger.warning(f"uniform_levels = {self._level_bounds} is invalid, using one uniform refinement cycle.")
             self._level_bounds = 1
         if self._n_cells_max is not None:
-            logger.warning("Detected stopping criterion 'n_cells_max'. Passing this stopping criterion deactivates the"
-                           " 'min_metric' stopping criterion. To use 'min_metric' as stopping criterion, remove "
-                           "'n_cells_max' or set 'n_cells_max = None'.")
+            logger.warning("'n_cells_max' is set: it replaces 'min_metric' as stopping criterion. Pass "
+                           "'n_cells_max = None' to stop on the captured metric instead.")
 
 
 def list_geometries() -> None:
-    """log the available geometry classes with their one-line description (reference :190-212)"""
+    """Log every available geometry class with its one-line description (reference lines 190-212)."""
     from . import geometry
-    from .geometry.geometry_base import GeometryObject
-    classes = sorted((obj for _, obj in inspect.getmembers(geometry, inspect.isclass)
-                      if issubclass(obj, GeometryObject) and obj is not GeometryObject), key=lambda c: c.__name__)
-    pad = max(len(cls.__name__) for cls in classes)
-    msg = ["\n\tAvailable geometry objects:", "\t---------------------------"]
-    for cls in classes:
-        desc = textwrap.shorten(getattr(cls, "__short_description__", ""), width=100, placeholder="…")
-        msg.append(f"\t\t- {cls.__name__.ljust(pad)} : {desc}")
-    msg.append("\n\tFor a more detailed description check out the documentation.")
-    logger.info("\n".join(msg))
+    base = geometry.GeometryObject
+    found = {name: cls for name, cls in inspect.getmembers(geometry, inspect.isclass)
+             if cls is not base and issubclass(cls, base)}
+    width = max(map(len, found))
+    lines = ["\n\tAvailable geometry objects:", "\t---------------------------"]
+    for name in sorted(found):
+        summary = textwrap.shorten(getattr(found[name], "__short_description__", ""), width=100, placeholder="…")
+        lines.append(f"\t\t- {name.ljust(width)} : {summary}")
+    lines.append("\n\tFor a more detailed description check out the documentation.")
+    logger.info("\n".join(lines))

@@ -40,6 +40,7 @@ def _cpu_ops():
                                                                           data.numpy()))
     ops.InterpPlan = type("InterpPlan", (), {"__init__": lambda self, *a, **k: None,
                                             "supports": staticmethod(lambda k, d: False)})
+    ops.padded_rows = None      # never reached: supports() is False on the CPU stand-in
     return ops
 
 

@@ -94,7 +94,7 @@ def test_export_pipeline_gpu(tmp_path):
     ref = orc.interp(orc.idw_weights(dist_o), idx_o, data)
     got = ex._interpolated_fields.centers.numpy()
     assert got.shape == ref.shape and np.abs(got - ref).max() <= 1e-13 * np.abs(ref).max()
-    assert np.array_equal(ex._knn_idx_centers.cpu().numpy(), idx_o)
+    assert np.array_equal(ex._table_centers.idx.cpu().numpy(), idx_o)
     ref_metric = orc.interp(orc.idw_weights(dist_o), idx_o, y)
     assert np.abs(ex._metric.numpy() - ref_metric).max() <= 1e-13 * np.abs(ref_metric).max()
 

@@ -148,3 +148,20 @@ def test_pre_select_quirk_gpu():
     tree = s_cube.SamplingTree(pt.from_numpy(x), pt.from_numpy(y), geometry_obj=geos, uniform_level=3, pre_select=True)
     tree._refine_uniform()
     assert len(tree._leaf_cells) == 64 and (tree._topo.first_child != -2).all()
+
+
+def test_bench_small_workload_matches_reference():
+    """the reduced bench workload (299 502 points, 3-D, cylinder): leaf centres bit-exact against the real reference
+    (tools/reference_timing.py, run in the dev container: 12.3 s there for refine())"""
+    import bench
+    import sparsespatialsampling_amd.s_cube as s_cube
+    from sparsespatialsampling_amd import geometry
+    cfg = dict(bench.WORKLOADS["cylinder3D_small"])
+    x, metric = bench.synthetic_cylinder3d(cfg)
+    geos = [geometry.CubeGeometry("domain", True, cfg["lo"], [float(v) for v in cfg["hi"]]),
+            geometry.CylinderGeometry3D("cylinder", False, [(0.8, 1.0, -1.0), (0.8, 1.0, 1.0)], 0.05, refine=True)]
+    tree = s_cube.SamplingTree(pt.from_numpy(x), pt.from_numpy(metric), geos, uniform_level=cfg["uniform_levels"],
+                               min_metric=cfg["min_metric"])
+    tree.refine()
+    z = load("bench_small_centers")
+    assert np.array_equal(tree.all_centers.numpy(), z["all_centers"])

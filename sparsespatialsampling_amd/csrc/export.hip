@@ -86,6 +86,19 @@ interp_kernel(const double *__restrict__ w, const int32_t *__restrict__ idx, int
 #pragma unroll
         for (int i = 0; i < VEC; ++i) acc[i] = 0.0;
         int m = 0;
+        // eight independent row reads in flight per lane before the first FMA (the kernel is bound by gather latency /
+        // Infinity-Cache bandwidth, not by arithmetic)
+        for (; m + 8 <= k; m += 8) {
+            double v[8][VEC];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) load_vec<T, VEC>(col + (int64_t)ip[m + u] * row_len, v[u]);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const double wu = wp[m + u];
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) acc[i] = fma(wu, v[u][i], acc[i]);
+            }
+        }
         for (; m + 4 <= k; m += 4) {
             double v0[VEC], v1[VEC], v2[VEC], v3[VEC];
             const int64_t r0 = ip[m], r1 = ip[m + 1], r2 = ip[m + 2], r3 = ip[m + 3];

@@ -134,6 +134,10 @@ int s3_idw_weights(const double *d_dist /*[nc,k]*/, int64_t nc, int k, double *d
 int s3_interp(const double *d_w /*[nc,k]*/, const int32_t *d_idx /*[nc,k]*/, int64_t nc, int k, const void *d_data,
               int dtype, int64_t n_src, int64_t row_len, double *d_out /*[nc,row_len]*/, s3_stream stream);
 
+/* a19 hand-over: [nc][n_comp][T] -> [T][nc][n_comp], the snapshot-major image of an interpolated batch, so that the HDF5
+ * sink (one dataset per snapshot, export.py:283-299) gets contiguous snapshots instead of slicing out[:, :, i] on the host. */
+int s3_snapshot_major(const double *d_in, int64_t nc, int n_comp, int64_t n_snapshots, double *d_out, s3_stream stream);
+
 /* Planned form of a17 for a static neighbour table (the table ExportData caches at export.py:431-432 and reuses for
  * every snapshot batch and field): the plan de-duplicates the source rows of spatially adjacent cells once (host side,
  * Morton order of d_centers[nc,dim] when given), the kernel then stages each distinct row once per tile in LDS.

@@ -58,6 +58,7 @@ HIP_SIGNATURES = {
     "s3_topn_leaf": (c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, C.POINTER(c_i64), c_vp, c_vp]),
     "s3_idw_weights": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp]),
     "s3_interp": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_int, c_i64, c_i64, c_vp, c_vp]),
+    "s3_snapshot_major": (c_int, [c_vp, c_i64, c_int, c_i64, c_vp, c_vp]),
     "s3_interp_plan_create": (c_int, [c_vp, c_i64, c_int, c_i64, c_vp, c_int, c_int, c_vp, C.POINTER(c_vp)]),
     "s3_interp_plan_destroy": (None, [c_vp]),
     "s3_interp_plan_info": (c_int, [c_vp, C.POINTER(c_i64), C.POINTER(c_i64)]),

@@ -126,6 +126,26 @@ interp_kernel(const double *__restrict__ w, const int32_t *__restrict__ idx, int
     }
 }
 
+// [nc][n_comp][T] -> [T][nc][n_comp]: snapshot-major image of an interpolated batch for the HDF5 sink, which writes one
+// dataset per snapshot (reference export.py:283-299 slices out[:, :, i] on the host).  32x32 tiles through LDS: reads run
+// along t, writes along the cell axis.
+__global__ void __launch_bounds__(256)
+snapshot_major_kernel(const double *__restrict__ in, int64_t nc, int n_comp, int64_t T, double *__restrict__ out) {
+    __shared__ double tile[32][33];
+    const int j = blockIdx.z;
+    const int64_t c0 = (int64_t)blockIdx.x * 32, t0 = (int64_t)blockIdx.y * 32;   // cells on x: up to 2^31 tiles
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;            // 32 x 8 threads
+    for (int r = ty; r < 32; r += 8) {
+        const int64_t c = c0 + r, t = t0 + tx;
+        if (c < nc && t < T) tile[r][tx] = in[(c * n_comp + j) * T + t];
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int64_t t = t0 + r, c = c0 + tx;
+        if (c < nc && t < T) out[(t * nc + c) * n_comp + j] = tile[tx][r];
+    }
+}
+
 template <typename T, int VEC>
 static int launch_interp(const double *w, const int32_t *idx, int64_t nc, int k, const void *data, int64_t row_len,
                          double *out, hipStream_t st) {
@@ -174,6 +194,18 @@ int s3_interp(const double *d_w, const int32_t *d_idx, int64_t nc, int k, const 
     if (row_len % 2 == 0 && a_in % 16 == 0 && a_out % 16 == 0)
         return launch_interp<double, 2>(d_w, d_idx, nc, k, d_data, row_len, d_out, st);
     return launch_interp<double, 1>(d_w, d_idx, nc, k, d_data, row_len, d_out, st);
+}
+
+int s3_snapshot_major(const double *d_in, int64_t nc, int n_comp, int64_t n_snapshots, double *d_out, s3_stream stream) {
+    S3_REQUIRE(nc >= 0 && n_comp >= 1 && n_snapshots >= 0, "s3_snapshot_major: bad shape");
+    if (nc == 0 || n_snapshots == 0) return S3_OK;
+    S3_REQUIRE(d_in && d_out && d_in != d_out, "s3_snapshot_major: null or aliased array");
+    const int64_t gx = (nc + 31) / 32, gy = (n_snapshots + 31) / 32;
+    S3_REQUIRE(gx < ((int64_t)1 << 31) && gy <= 65535 && n_comp <= 65535, "s3_snapshot_major: shape too large for one launch");
+    snapshot_major_kernel<<<dim3((unsigned)gx, (unsigned)gy, (unsigned)n_comp), 256, 0, as_stream(stream)>>>(
+        d_in, nc, n_comp, n_snapshots, d_out);
+    S3_LAUNCH_CHECK();
+    return S3_OK;
 }
 
 }  // extern "C"

@@ -129,6 +129,15 @@ def interp(w, idx, data, out=None):
     return out
 
 
+def snapshot_major(values, n_comp, n_snapshots):
+    """device [nc, n_comp*T] (or [nc, n_comp, T]) f64 -> device [T, nc, n_comp]: contiguous snapshots for the HDF5 sink"""
+    nc = int(values.shape[0])
+    out = pt.empty((int(n_snapshots), nc, int(n_comp)), dtype=pt.float64, device=values.device)
+    check(_lib.hip_lib().s3_snapshot_major(_ptr(values), nc, int(n_comp), int(n_snapshots), _ptr(out), _stream()),
+          "s3_snapshot_major")
+    return out
+
+
 class InterpPlan:
     """De-duplicated, LDS-tiled form of a static neighbour table (s3_interp_plan_*): build once per KNN cache, reuse for
     every snapshot batch.  ``centers`` (cell centres, [nc, dim]) gives the Morton processing order."""

@@ -132,6 +132,13 @@ def test_interp_planned_random_table_no_centers(ops, orc):
         ops.InterpPlan(dev(np.full((4, 8), n), pt.int32), n)                              # index out of range
 
 
+@pytest.mark.parametrize("nc,ncomp,t", [(1000, 1, 25), (777, 3, 40), (33, 2, 1), (5, 1, 70)])
+def test_snapshot_major(ops, nc, ncomp, t):
+    a = pt.randn((nc, ncomp, t), dtype=pt.float64, device="cuda")
+    b = ops.snapshot_major(a.reshape(nc, ncomp * t), ncomp, t)
+    assert b.shape == (t, nc, ncomp) and pt.equal(b, a.permute(2, 0, 1))
+
+
 # ---- KNN cache (a16) -----------------------------------------------------------------------------------------
 @pytest.mark.parametrize("name,k", [("knncache_2d", 8), ("knncache_3d", 26)])
 def test_knn_cache_golden(ops, name, k):

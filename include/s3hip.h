@@ -55,11 +55,14 @@ int s3_stream_synchronize(s3_stream stream);
 /* ---- KNN index over the original CFD points -------------------------------------------------------------------
  * Replaces KNeighborsRegressor(...).fit(vertices, target)           s_cube.py:161-163
  *      and NearestNeighbors(...).fit(coordinates)                   export.py:120,423
- * Builds a uniform-grid bucket index (bounding box, counting sort) on the device.  Synchronous (returns after the
- * build finished).  `target_occupancy` <= 0 selects the default (3 points per grid cell in 2-D, 8 in 3-D). */
+ * Builds a two-level bucket index on the device (bounding box, counting sort into a uniform grid; buckets holding more
+ * than 8x the target occupancy get their own sub-lattice, which keeps strongly graded clouds fast).  Synchronous
+ * (returns after the build finished).  `target_occupancy` <= 0 selects the default (3 points per bucket in 2-D, 8 in
+ * 3-D). */
 int s3_knn_create(const double *d_pts /*[n,dim]*/, int64_t n, int dim, double target_occupancy, s3_stream stream,
                   s3_knn **out);
 void s3_knn_destroy(s3_knn *knn);
+int s3_knn_info(const s3_knn *knn, int64_t *h_n_buckets, int64_t *h_n_refined);
 /* attach the regression target y[n] (the S^3 metric, original point order); permuted into grid order */
 int s3_knn_set_values(s3_knn *knn, const double *d_y /*[n]*/, s3_stream stream);
 

@@ -42,6 +42,7 @@ HIP_SIGNATURES = {
     "s3_stream_synchronize": (c_int, [c_vp]),
     "s3_knn_create": (c_int, [c_vp, c_i64, c_int, c_dbl, c_vp, C.POINTER(c_vp)]),
     "s3_knn_destroy": (None, [c_vp]),
+    "s3_knn_info": (c_int, [c_vp, C.POINTER(c_i64), C.POINTER(c_i64)]),
     "s3_knn_set_values": (c_int, [c_vp, c_vp, c_vp]),
     "s3_knn_query": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp]),
     "s3_idw_predict": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_vp]),

@@ -21,6 +21,7 @@
 
 #include <cfloat>
 #include <cmath>
+#include <utility>
 #include <vector>
 
 struct s3_knn {
@@ -34,6 +35,11 @@ struct s3_knn {
     int32_t *orig = nullptr;       // [n]
     int32_t *cell_start = nullptr; // [ncell+1]
     double *y = nullptr;           // [n] bucket order (optional)
+    // second level: buckets holding more than `split` points carry their own r x r (x r) sub-lattice
+    uint8_t *sub_res = nullptr;    // [ncell] 0 = plain bucket, else r
+    int32_t *sub_off = nullptr;    // [ncell] offset of the bucket's table in sub_start
+    int32_t *sub_start = nullptr;  // pooled tables, r^dim + 1 absolute positions each
+    int64_t n_refined = 0;
 };
 
 namespace s3 {
@@ -44,7 +50,12 @@ template <int DIM>
 struct Grid {
     double lo[DIM], h[DIM], inv_h[DIM];
     int res[DIM];
+    const uint8_t *sub_res;     // nullptr when no bucket is refined
+    const int32_t *sub_off;
+    const int32_t *sub_start;
 };
+
+constexpr int SUB_RES_MAX = 32;
 
 template <int DIM>
 static Grid<DIM> make_grid(const s3_knn *k) {
@@ -55,6 +66,9 @@ static Grid<DIM> make_grid(const s3_knn *k) {
         g.inv_h[j] = k->inv_h[j];
         g.res[j] = k->res[j];
     }
+    g.sub_res = k->n_refined > 0 ? k->sub_res : nullptr;
+    g.sub_off = k->sub_off;
+    g.sub_start = k->sub_start;
     return g;
 }
 
@@ -176,6 +190,107 @@ __global__ void scatter_kernel(const double *__restrict__ pts, int64_t n, const 
     orig[pos] = (int32_t)i;
 }
 
+// ---- second level ---------------------------------------------------------------------------------------------
+template <int DIM>
+__device__ __forceinline__ int64_t top_cell_of(const Grid<DIM> &g, const double *__restrict__ x, int (&cc)[3]) {
+    int64_t c = 0;
+    cc[0] = cc[1] = cc[2] = 0;
+    for (int j = DIM - 1; j >= 0; --j) {
+        cc[j] = cell_coord<DIM>(g, x[j], j);
+        c = c * g.res[j] + cc[j];
+    }
+    return c;
+}
+
+template <int DIM>
+__device__ __forceinline__ int sub_cell_of(const Grid<DIM> &g, const int (&cc)[3], int r, const double *__restrict__ x) {
+    int s = 0;
+    for (int j = DIM - 1; j >= 0; --j) {
+        double t = (x[j] - (g.lo[j] + (double)cc[j] * g.h[j])) * ((double)r * g.inv_h[j]);
+        t = fmin(fmax(t, 0.0), (double)(r - 1));
+        s = s * r + (int)t;
+    }
+    return s;
+}
+
+// which buckets get a sub-lattice, and how fine: r = ceil((count / occupancy)^(1/dim)), capped
+__global__ void sub_plan_kernel(const int32_t *__restrict__ cell_start, int64_t ncell, int split, double occ, int dim,
+                                uint8_t *__restrict__ sub_res, int32_t *__restrict__ sub_size,
+                                unsigned long long *__restrict__ n_refined) {
+    int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (c > ncell) return;
+    if (c == ncell) { sub_size[c] = 0; return; }
+    const int cnt = cell_start[c + 1] - cell_start[c];
+    int r = 0;
+    if (cnt > split) {
+        r = (int)ceil(pow((double)cnt / occ, 1.0 / dim));
+        r = min(max(r, 2), SUB_RES_MAX);
+        atomicAdd(n_refined, 1ull);
+    }
+    sub_res[c] = (uint8_t)r;
+    int sz = 0;
+    if (r > 0) sz = (dim == 2 ? r * r : r * r * r) + 1;
+    sub_size[c] = sz;
+}
+
+template <int DIM>
+__global__ void sub_count_kernel(Grid<DIM> g, const double *__restrict__ pts, int64_t n, const uint8_t *__restrict__ sub_res,
+                                 const int32_t *__restrict__ sub_off, int32_t *__restrict__ sub_start,
+                                 int32_t *__restrict__ sid) {
+    int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    int cc[3];
+    const int64_t c = top_cell_of<DIM>(g, pts + p * DIM, cc);
+    const int r = sub_res[c];
+    if (r == 0) { sid[p] = -1; return; }
+    const int sc = sub_cell_of<DIM>(g, cc, r, pts + p * DIM);
+    sid[p] = sc;
+    atomicAdd(&sub_start[sub_off[c] + sc], 1);
+}
+
+// per refined bucket: counts -> absolute start positions (exclusive scan + bucket base), closing entry = bucket end
+__global__ void __launch_bounds__(64)
+sub_scan_kernel(const int32_t *__restrict__ cell_start, const uint8_t *__restrict__ sub_res,
+                const int32_t *__restrict__ sub_off, int32_t *__restrict__ sub_start, int dim) {
+    const int64_t c = blockIdx.x;
+    const int r = sub_res[c];
+    if (r == 0) return;
+    const int n = dim == 2 ? r * r : r * r * r;
+    int32_t *t = sub_start + sub_off[c];
+    int32_t carry = cell_start[c];
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + threadIdx.x;
+        const int32_t v = i < n ? t[i] : 0;
+        int32_t incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int32_t u = __shfl_up(incl, off, 64);
+            if ((int)threadIdx.x >= off) incl += u;
+        }
+        if (i < n) t[i] = carry + incl - v;
+        carry += __shfl(incl, 63, 64);
+    }
+    if (threadIdx.x == 0) t[n] = cell_start[c + 1];
+}
+
+template <int DIM>
+__global__ void sub_scatter_kernel(Grid<DIM> g, const double *__restrict__ pts, const int32_t *__restrict__ orig, int64_t n,
+                                   const int32_t *__restrict__ sid, const uint8_t *__restrict__ sub_res,
+                                   const int32_t *__restrict__ sub_off, const int32_t *__restrict__ sub_start,
+                                   int32_t *__restrict__ cursor, double *__restrict__ out_pts, int32_t *__restrict__ out_orig) {
+    int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    int64_t dst = p;
+    const int sc = sid[p];
+    if (sc >= 0) {
+        int cc[3];
+        const int64_t c = top_cell_of<DIM>(g, pts + p * DIM, cc);
+        dst = sub_start[sub_off[c] + sc] + atomicAdd(&cursor[sub_off[c] + sc], 1);
+    }
+    for (int j = 0; j < DIM; ++j) out_pts[dst * DIM + j] = pts[p * DIM + j];
+    out_orig[dst] = orig[p];
+}
+
 __global__ void permute_values_kernel(const double *__restrict__ y, const int32_t *__restrict__ orig, int64_t n,
                                       double *__restrict__ out) {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -228,68 +343,133 @@ __device__ __forceinline__ void scan_range(KBest &b, const double *__restrict__ 
     }
 }
 
+// a uniform lattice of buckets: the top-level grid, or the sub-lattice of one refined bucket
 template <int DIM>
-__device__ void knn_search(const Grid<DIM> &g, const double *__restrict__ pts, const int32_t *__restrict__ orig,
-                           const int32_t *__restrict__ cs, const double (&q)[DIM], KBest &b) {
+struct Lattice {
+    double lo[DIM], h[DIM], inv_h[DIM];
+    int res[DIM];
+};
+
+// Visit the buckets of a lattice in Chebyshev rings around the bucket of q until the k-best list is full and its worst
+// squared distance is below the squared distance to everything not yet visited (or the lattice is exhausted).
+// run(row, y, z, xa, xb) is called for runs of buckets [xa, xb] of one lattice row (linear index row + x).
+template <int DIM, typename RunFn>
+__device__ __forceinline__ void ring_search(const Lattice<DIM> &L, const double (&q)[DIM], KBest &b, RunFn &&run) {
     int c[DIM];
     int rmax = 0;
     double hmin = DBL_MAX;
-#pragma unroll
-    for (int j = 0; j < DIM; ++j) {
-        c[j] = cell_coord<DIM>(g, q[j], j);
-        rmax = max(rmax, max(c[j], g.res[j] - 1 - c[j]));
-        hmin = fmin(hmin, g.h[j]);
-    }
-    // how far q lies outside the grid along each axis (0 inside), shrunk a little to stay conservative
+    // how far q lies outside the lattice along each axis (0 inside), shrunk a little to stay conservative
     double out[DIM], out2 = 0.0;
 #pragma unroll
     for (int j = 0; j < DIM; ++j) {
-        const double hi = g.lo[j] + (double)g.res[j] * g.h[j];
-        out[j] = fmax(0.0, fmax(g.lo[j] - q[j], q[j] - hi)) * (1.0 - 1e-9);
+        double t = (q[j] - L.lo[j]) * L.inv_h[j];
+        t = fmin(fmax(t, 0.0), (double)(L.res[j] - 1));   // also maps NaN to 0
+        c[j] = (int)t;
+        rmax = max(rmax, max(c[j], L.res[j] - 1 - c[j]));
+        hmin = fmin(hmin, L.h[j]);
+        const double hi = L.lo[j] + (double)L.res[j] * L.h[j];
+        out[j] = fmax(0.0, fmax(L.lo[j] - q[j], q[j] - hi)) * (1.0 - 1e-9);
         out2 += out[j] * out[j];
     }
     const int c2 = DIM == 3 ? c[DIM - 1] : 0;
-    const int res2 = DIM == 3 ? g.res[DIM - 1] : 1;
+    const int res2 = DIM == 3 ? L.res[DIM - 1] : 1;
 
     for (int r = 0; r <= rmax; ++r) {
-        const int x0 = max(c[0] - r, 0), x1 = min(c[0] + r, g.res[0] - 1);
-        const int y0 = max(c[1] - r, 0), y1 = min(c[1] + r, g.res[1] - 1);
+        const int x0 = max(c[0] - r, 0), x1 = min(c[0] + r, L.res[0] - 1);
+        const int y0 = max(c[1] - r, 0), y1 = min(c[1] + r, L.res[1] - 1);
         const int z0 = DIM == 3 ? max(c2 - r, 0) : 0, z1 = DIM == 3 ? min(c2 + r, res2 - 1) : 0;
         for (int z = z0; z <= z1; ++z) {
             const int dz = DIM == 3 ? abs(z - c2) : 0;
             for (int y = y0; y <= y1; ++y) {
                 const int dy = abs(y - c[1]);
-                const int64_t row = ((int64_t)z * g.res[1] + y) * g.res[0];
+                const int64_t row = ((int64_t)z * L.res[1] + y) * L.res[0];
                 if (max(dz, dy) == r) {
-                    // whole x-run of this row belongs to the ring: buckets are consecutive in memory
-                    scan_range<DIM>(b, pts, orig, q, cs[row + x0], cs[row + x1 + 1]);
+                    run(row, y, z, x0, x1);            // the whole x-run of this row belongs to the ring
                 } else {
-                    if (c[0] - r >= 0) scan_range<DIM>(b, pts, orig, q, cs[row + c[0] - r], cs[row + c[0] - r + 1]);
-                    if (c[0] + r < g.res[0]) scan_range<DIM>(b, pts, orig, q, cs[row + c[0] + r], cs[row + c[0] + r + 1]);
+                    if (c[0] - r >= 0) run(row, y, z, c[0] - r, c[0] - r);
+                    if (c[0] + r < L.res[0]) run(row, y, z, c[0] + r, c[0] + r);
                 }
             }
         }
         if (b.cnt == b.k) {
             // lower bound on the squared distance from q to any point in a bucket that has not been visited: such a
             // point lies beyond at least one face j of the visited box (distance >= face_j along j) and, like every
-            // point, inside the grid (distance >= out_i along every other axis i on which q lies outside the grid)
+            // point of this lattice, inside it (distance >= out_i along every other axis i on which q lies outside)
             double bound2 = DBL_MAX;
 #pragma unroll
             for (int j = 0; j < DIM; ++j) {
                 const double rest = fmax(0.0, out2 - out[j] * out[j]);
                 if (c[j] - r > 0) {
-                    double f = q[j] - (g.lo[j] + (double)(c[j] - r) * g.h[j]) - 1e-9 * hmin;
+                    double f = q[j] - (L.lo[j] + (double)(c[j] - r) * L.h[j]) - 1e-9 * hmin;
                     if (f > 0.0) bound2 = fmin(bound2, f * f + rest); else bound2 = fmin(bound2, rest);
                 }
-                if (c[j] + r < g.res[j] - 1) {
-                    double f = (g.lo[j] + (double)(c[j] + r + 1) * g.h[j]) - q[j] - 1e-9 * hmin;
+                if (c[j] + r < L.res[j] - 1) {
+                    double f = (L.lo[j] + (double)(c[j] + r + 1) * L.h[j]) - q[j] - 1e-9 * hmin;
                     if (f > 0.0) bound2 = fmin(bound2, f * f + rest); else bound2 = fmin(bound2, rest);
                 }
             }
-            if (bound2 == DBL_MAX) break;         // the box covers the whole grid
+            if (bound2 == DBL_MAX) break;         // the box covers the whole lattice
             if (b.worst < bound2) break;
         }
     }
+}
+
+// sub-lattice of the refined top-level bucket with integer coordinates (x, y, z): r x r (x r) buckets over its box
+template <int DIM>
+__device__ __forceinline__ Lattice<DIM> sub_lattice(const Grid<DIM> &g, int x, int y, int z, int r) {
+    Lattice<DIM> L;
+    const int cc[3] = {x, y, z};
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) {
+        L.lo[j] = g.lo[j] + (double)cc[j] * g.h[j];
+        L.h[j] = g.h[j] / (double)r;
+        L.inv_h[j] = (double)r * g.inv_h[j];
+        L.res[j] = r;
+    }
+    return L;
+}
+
+template <int DIM>
+__device__ void knn_search(const Grid<DIM> &g, const double *__restrict__ pts, const int32_t *__restrict__ orig,
+                           const int32_t *__restrict__ cs, const double (&q)[DIM], KBest &b) {
+    Lattice<DIM> top;
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) {
+        top.lo[j] = g.lo[j];
+        top.h[j] = g.h[j];
+        top.inv_h[j] = g.inv_h[j];
+        top.res[j] = g.res[j];
+    }
+    if (g.sub_res == nullptr) {
+        // no refined bucket: a run of buckets is one contiguous range of points
+        ring_search<DIM>(top, q, b, [&](int64_t row, int, int, int xa, int xb) {
+            scan_range<DIM>(b, pts, orig, q, cs[row + xa], cs[row + xb + 1]);
+        });
+        return;
+    }
+    ring_search<DIM>(top, q, b, [&](int64_t row, int y, int z, int xa, int xb) {
+        int64_t pending = -1;                       // first bucket of a run of plain buckets not scanned yet
+        for (int x = xa; x <= xb; ++x) {
+            const int64_t cell = row + x;
+            const int r = g.sub_res[cell];
+            if (r == 0) {
+                if (pending < 0) pending = cell;
+                continue;
+            }
+            if (pending >= 0) {
+                scan_range<DIM>(b, pts, orig, q, cs[pending], cs[cell]);
+                pending = -1;
+            }
+            // refined bucket: the same ring search on its sub-lattice; it stops as soon as nothing left in this bucket
+            // can improve the list, the outer search then carries on with the next bucket
+            const int32_t *st = g.sub_start + g.sub_off[cell];
+            const Lattice<DIM> sub = sub_lattice<DIM>(g, x, y, z, r);
+            ring_search<DIM>(sub, q, b, [&](int64_t srow, int, int, int sa, int sb) {
+                scan_range<DIM>(b, pts, orig, q, st[srow + sa], st[srow + sb + 1]);
+            });
+        }
+        if (pending >= 0) scan_range<DIM>(b, pts, orig, q, cs[pending], cs[row + xb + 1]);
+    });
 }
 
 // numpy's pairwise summation of f(m), m = 0..k-1, for k <= 128 (numpy/_core/src/umath/loops_utils.h.src): eight
@@ -574,6 +754,74 @@ int s3_knn_create(const double *d_pts, int64_t n, int dim, double target_occupan
     (void)hipFree(cursor);
     (void)hipFree(block_sums);
 #undef S3_TRY
+    // ---- second level: buckets with more than 8x the target occupancy get their own sub-lattice, so that strongly graded
+    //      point clouds (boundary-layer meshes) do not degenerate into scanning thousands of points per bucket --------
+    {
+        const int split = (int)std::ceil(8.0 * occ);
+        int32_t *sub_size = nullptr, *bsum = nullptr, *sid = nullptr, *cur2 = nullptr, *orig2 = nullptr;
+        double *pts2 = nullptr;
+        unsigned long long *d_nref = nullptr;
+        auto fail2 = [&](int rc) {
+            for (void *q : {(void *)sub_size, (void *)bsum, (void *)sid, (void *)cur2, (void *)orig2, (void *)pts2, (void *)d_nref})
+                if (q) (void)hipFree(q);
+            s3_knn_destroy(k);
+            return rc;
+        };
+#define S3_TRY2(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess) {                                                                        \
+            s3::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__);  \
+            return fail2(_e == hipErrorOutOfMemory ? S3_ENOMEM : S3_EHIP);                             \
+        }                                                                                              \
+    } while (0)
+        const int64_t nscan2 = ncell + 1, nblk2 = (nscan2 + 1023) / 1024;
+        S3_TRY2(hipMalloc(&k->sub_res, ncell));
+        S3_TRY2(hipMalloc(&sub_size, sizeof(int32_t) * nscan2));
+        S3_TRY2(hipMalloc(&bsum, sizeof(int32_t) * nblk2));
+        S3_TRY2(hipMalloc(&d_nref, sizeof(unsigned long long)));
+        S3_TRY2(hipMemsetAsync(d_nref, 0, sizeof(unsigned long long), st));
+        sub_plan_kernel<<<grid_for(nscan2, 256), 256, 0, st>>>(k->cell_start, ncell, split, occ, dim, k->sub_res, sub_size, d_nref);
+        scan_block_kernel<<<(unsigned)nblk2, 256, 0, st>>>(sub_size, nscan2, bsum);
+        scan_sums_kernel<<<1, 256, 0, st>>>(bsum, nblk2);
+        scan_add_kernel<<<(unsigned)nblk2, 256, 0, st>>>(sub_size, nscan2, bsum);
+        S3_TRY2(hipGetLastError());
+        unsigned long long nref = 0;
+        int32_t pool = 0;
+        S3_TRY2(hipMemcpyAsync(&nref, d_nref, sizeof(nref), hipMemcpyDeviceToHost, st));
+        S3_TRY2(hipMemcpyAsync(&pool, sub_size + ncell, sizeof(pool), hipMemcpyDeviceToHost, st));
+        S3_TRY2(hipStreamSynchronize(st));
+        k->n_refined = (int64_t)nref;
+        k->sub_off = sub_size;           // the scanned sizes are the table offsets
+        sub_size = nullptr;
+        if (nref > 0) {
+            S3_TRY2(hipMalloc(&k->sub_start, sizeof(int32_t) * (size_t)pool));
+            S3_TRY2(hipMalloc(&cur2, sizeof(int32_t) * (size_t)pool));
+            S3_TRY2(hipMalloc(&sid, sizeof(int32_t) * n));
+            S3_TRY2(hipMalloc(&pts2, sizeof(double) * n * dim));
+            S3_TRY2(hipMalloc(&orig2, sizeof(int32_t) * n));
+            S3_TRY2(hipMemsetAsync(k->sub_start, 0, sizeof(int32_t) * (size_t)pool, st));
+            S3_TRY2(hipMemsetAsync(cur2, 0, sizeof(int32_t) * (size_t)pool, st));
+            if (dim == 2) {
+                sub_count_kernel<2><<<grid_for(n, 256), 256, 0, st>>>(make_grid<2>(k), k->pts, n, k->sub_res, k->sub_off, k->sub_start, sid);
+                sub_scan_kernel<<<(unsigned)ncell, 64, 0, st>>>(k->cell_start, k->sub_res, k->sub_off, k->sub_start, dim);
+                sub_scatter_kernel<2><<<grid_for(n, 256), 256, 0, st>>>(make_grid<2>(k), k->pts, k->orig, n, sid, k->sub_res, k->sub_off,
+                                                                       k->sub_start, cur2, pts2, orig2);
+            } else {
+                sub_count_kernel<3><<<grid_for(n, 256), 256, 0, st>>>(make_grid<3>(k), k->pts, n, k->sub_res, k->sub_off, k->sub_start, sid);
+                sub_scan_kernel<<<(unsigned)ncell, 64, 0, st>>>(k->cell_start, k->sub_res, k->sub_off, k->sub_start, dim);
+                sub_scatter_kernel<3><<<grid_for(n, 256), 256, 0, st>>>(make_grid<3>(k), k->pts, k->orig, n, sid, k->sub_res, k->sub_off,
+                                                                       k->sub_start, cur2, pts2, orig2);
+            }
+            S3_TRY2(hipGetLastError());
+            S3_TRY2(hipStreamSynchronize(st));
+            std::swap(k->pts, pts2);
+            std::swap(k->orig, orig2);
+        }
+        for (void *q : {(void *)bsum, (void *)sid, (void *)cur2, (void *)orig2, (void *)pts2, (void *)d_nref})
+            if (q) (void)hipFree(q);
+#undef S3_TRY2
+    }
     *out = k;
     return S3_OK;
 }
@@ -584,7 +832,17 @@ void s3_knn_destroy(s3_knn *knn) {
     if (knn->orig) (void)hipFree(knn->orig);
     if (knn->cell_start) (void)hipFree(knn->cell_start);
     if (knn->y) (void)hipFree(knn->y);
+    if (knn->sub_res) (void)hipFree(knn->sub_res);
+    if (knn->sub_off) (void)hipFree(knn->sub_off);
+    if (knn->sub_start) (void)hipFree(knn->sub_start);
     delete knn;
+}
+
+int s3_knn_info(const s3_knn *knn, int64_t *h_n_buckets, int64_t *h_n_refined) {
+    S3_REQUIRE(knn != nullptr, "s3_knn_info: null index");
+    if (h_n_buckets) *h_n_buckets = knn->ncell;
+    if (h_n_refined) *h_n_refined = knn->n_refined;
+    return S3_OK;
 }
 
 int s3_knn_set_values(s3_knn *knn, const double *d_y, s3_stream stream) {

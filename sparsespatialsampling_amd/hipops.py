@@ -67,6 +67,9 @@ class KnnIndex:
         check(_lib.hip_lib().s3_knn_create(_ptr(pts), self.n, self.dim, float(target_occupancy), _stream(),
                                            C.byref(self._handle)), "s3_knn_create")
         self._has_values = False
+        nb, nr = C.c_int64(0), C.c_int64(0)
+        check(_lib.hip_lib().s3_knn_info(self._handle, C.byref(nb), C.byref(nr)), "s3_knn_info")
+        self.n_buckets, self.n_refined_buckets = nb.value, nr.value
 
     def close(self):
         if getattr(self, "_handle", None) is not None and self._handle.value:

@@ -167,6 +167,28 @@ def test_knn_vs_oracle(ops, orc, d, k, occ):
     knn.close()
 
 
+@pytest.mark.parametrize("d,k", [(2, 8), (3, 26)])
+def test_knn_graded_cloud_two_level(ops, orc, d, k):
+    """boundary-layer like cloud (log-uniform wall distance over 5 decades): the overfull buckets are refined into
+    sub-lattices; results stay exact, prediction stays bit-identical"""
+    rng = np.random.default_rng(31 + d)
+    n = 60000
+    r = 10 ** rng.uniform(-5, 0, n)
+    v = rng.standard_normal((n, d))
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    x = v * (0.1 + r)[:, None]
+    y = np.cos(7 * x[:, 0]) + r
+    q = np.concatenate([x[rng.integers(0, n, 1500)] * (1 + 1e-6), rng.random((500, d)) * 2.4 - 1.2, np.zeros((1, d))])
+    knn = ops.KnnIndex(x)
+    assert knn.n_refined_buckets > 0
+    idx, dist = knn.query(q, k)
+    idx_o, dist_o = orc.knn(x, q, k)
+    assert np.array_equal(idx.cpu().numpy(), idx_o) and np.array_equal(dist.cpu().numpy(), dist_o)
+    knn.set_values(y)
+    assert np.array_equal(knn.predict(q, k).cpu().numpy(), orc.idw_predict(x, y, q, k))
+    knn.close()
+
+
 def test_knn_ties_structured_grid(ops, orc):
     """structured grid queried at cell corners: many exactly equidistant neighbours -> (dist, idx) tie rule"""
     g = np.stack(np.meshgrid(np.arange(30.0), np.arange(30.0), indexing="ij"), -1).reshape(-1, 2)

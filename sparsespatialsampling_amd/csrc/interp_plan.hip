@@ -47,7 +47,7 @@ template <> struct Vec16<float> { using type = float4; static constexpr int N = 
 template <> struct Vec16<double> { using type = double2; static constexpr int N = 2; };
 
 template <typename T, int TC>
-__global__ void __launch_bounds__(TC * 4, 2)
+__global__ void __launch_bounds__(TC * 4, 2)  // 226 VGPRs: two waves per SIMD
 interp_planned_kernel(const int32_t *__restrict__ perm, const int32_t *__restrict__ tile_cell_begin,
                       const int32_t *__restrict__ tile_row_begin, const int32_t *__restrict__ rows,
                       const uint16_t *__restrict__ loc, const double *__restrict__ w, int k, int ucap,
@@ -301,7 +301,7 @@ int s3_interp_plan_create(const int32_t *d_idx, int64_t nc, int k, int64_t n_src
 
     // greedy packing into tiles
     const int ucap = plan_ucap(k, PL_TC);
-    std::vector<int32_t> stamp(n_src, -1), local(n_src, 0);
+    std::vector<int32_t> stamp(n_src, -1), seen(n_src, -1), local(n_src, 0);
     std::vector<int32_t> tile_cell_begin{0}, tile_row_begin{0}, rows;
     std::vector<uint16_t> loc((size_t)nc * k);
     rows.reserve((size_t)nc * k / 2);
@@ -324,11 +324,13 @@ int s3_interp_plan_create(const int32_t *d_idx, int64_t nc, int k, int64_t n_src
     for (int64_t pos = 0; pos < nc; ++pos) {
         const int32_t cell = perm[pos];
         const int32_t *ci = &idx[(size_t)cell * k];
-        int fresh = 0;
+        int fresh = 0;                              // rows this cell would add to the tile (repeats inside a row count once)
         for (int m = 0; m < k; ++m) {
-            bool dup = false;
-            for (int u = 0; u < m; ++u) dup |= ci[u] == ci[m];
-            if (!dup && stamp[ci[m]] != tile) ++fresh;
+            const int32_t r = ci[m];
+            if (stamp[r] != tile && seen[r] != (int32_t)pos) {
+                seen[r] = (int32_t)pos;
+                ++fresh;
+            }
         }
         if (cells_in_tile == PL_TC || rows_in_tile + fresh > ucap) close_tile(pos);
         for (int m = 0; m < k; ++m) {

@@ -300,3 +300,29 @@ def test_sumsq_leaf(ops):
         ops.sumsq_leaf(dev(m), dev(leaf.astype(np.uint8)), 0, n // 2, a, scratch)
         ops.sumsq_leaf(dev(m), dev(leaf.astype(np.uint8)), n // 2, n, b, scratch)
         assert abs(a.item() + b.item() - ref) <= 1e-12 * max(ref, 1e-300)
+
+
+def test_degenerate_sizes(ops, orc):
+    """zero queries, k = 1, k = n, a single cell plan, one source point repeated"""
+    rng = np.random.default_rng(2)
+    x = rng.random((26, 3))
+    knn = ops.KnnIndex(x)
+    idx, dist = knn.query(np.zeros((0, 3)), 5)
+    assert idx.shape == (0, 5)
+    q = rng.random((7, 3))
+    for k in (1, 26):
+        idx, dist = knn.query(q, k)
+        io, do = orc.knn(x, q, k)
+        assert np.array_equal(idx.cpu().numpy(), io) and np.array_equal(dist.cpu().numpy(), do)
+    idx, dist = knn.query(q[:1], 26)
+    w = ops.idw_weights(dist)
+    data = dev(rng.standard_normal((26, 1, 4)).astype(np.float32))
+    plan = ops.InterpPlan(idx, 26, q[:1])
+    assert plan.n_tiles == 1
+    assert pt.allclose(plan.interp(w, data), ops.interp(w, idx, data), rtol=1e-14, atol=0)
+    knn.close()
+    same = np.tile(rng.random((1, 2)), (50, 1))              # all points identical: zero-extent bounding box
+    knn = ops.KnnIndex(same)
+    idx, dist = knn.query(same[:3], 8)
+    assert np.array_equal(idx.cpu().numpy(), np.tile(np.arange(8), (3, 1))) and float(dist.abs().max()) == 0.0
+    knn.close()

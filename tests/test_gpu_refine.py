@@ -165,3 +165,33 @@ def test_bench_small_workload_matches_reference():
     tree.refine()
     z = load("bench_small_centers")
     assert np.array_equal(tree.all_centers.numpy(), z["all_centers"])
+
+
+@pytest.mark.parametrize("t,ncomp,on_gpu", [(8, 1, False), (12, 3, False), (8, 2, True), (5, 1, True)])
+def test_export_fit_paths_gpu(tmp_path, t, ncomp, on_gpu):
+    """ExportData._fit_data through every transport: padded-row upload + LDS-tiled kernel (rows 16-byte aligned), direct
+    kernel (ragged rows), data already on the GPU, interpolation at the vertices, batches -- against the oracle"""
+    import types
+    from sparsespatialsampling_amd.export import ExportData
+    from oracle import s3_oracle as orc
+    rng = np.random.default_rng(t * 10 + ncomp)
+    n, nc, nv = 20000, 3000, 1500
+    x = rng.random((n, 3))
+    centers, vertices = rng.random((nc, 3)), rng.random((nv, 3))
+    s = types.SimpleNamespace(n_dimensions=3, faces=None, centers=pt.from_numpy(centers), vertices=pt.from_numpy(vertices),
+                              levels=None, metric=pt.from_numpy(rng.random(n)), size_initial_cell=1.0,
+                              save_path=str(tmp_path), save_name="c", grid_name="g")
+    ex = ExportData(s, write_times=[str(i) for i in range(2 * t)], interpolate_at_vertices=True)
+    idx_c, dist_c = orc.knn(x, centers, 26)
+    idx_v, dist_v = orc.knn(x, vertices, 26)
+    w_c, w_v = orc.idw_weights(dist_c), orc.idw_weights(dist_v)
+    for b in range(2):                                       # two batches reuse the cached tables / plans
+        data = rng.standard_normal((n, ncomp, t)).astype(np.float32)
+        d = pt.from_numpy(data).cuda() if on_gpu else pt.from_numpy(data)
+        ex._fit_data(pt.from_numpy(x), d, "f", 2 * t)
+        for got, ref in ((ex._interpolated_fields.centers, orc.interp(w_c, idx_c, data)),
+                         (ex._interpolated_fields.vertices, orc.interp(w_v, idx_v, data))):
+            assert tuple(got.shape) == ref.shape and not got.is_cuda
+            assert np.abs(got.numpy() - ref).max() <= 1e-13 * np.abs(ref).max()
+            assert got[:, :, 0].is_contiguous()              # snapshot-major memory: what the writer stores per time
+    assert ex._snapshot_counter == 2 * t

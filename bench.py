@@ -88,6 +88,22 @@ def recorded_traffic(workload):
     return None
 
 
+def copy_bandwidth_gbs(n_bytes=2 << 30, reps=5):
+    """device-to-device copy rate of this box (read + write bytes per second), the practical HBM ceiling next to the
+    8 TB/s datasheet peak (report both fractions)"""
+    src = pt.empty(n_bytes // 4, dtype=pt.float32, device="cuda").normal_()
+    dst = pt.empty_like(src)
+    dst.copy_(src)
+    pt.cuda.synchronize()
+    a, b = pt.cuda.Event(enable_timing=True), pt.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        dst.copy_(src)
+    b.record()
+    pt.cuda.synchronize()
+    return 2.0 * n_bytes * reps / (a.elapsed_time(b) * 1e-3) / 1e9
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -205,6 +221,7 @@ def main():
         elapsed = float(tmax.item())
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))       # HIP events on the launch stream
 
+    copy_bw = copy_bandwidth_gbs() if rank == 0 else None
     if rank == 0:
         units = nc * 1 * t_b * args.steps * world
         value = units / elapsed / 1e6
@@ -224,6 +241,7 @@ def main():
             "refine_leaves_per_s": nc / refine_s, "knn_cache_s": knn_cache_s,
             "captured_metric": info["metric_per_iter"][-1],
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                         "copy_kernel_GBs": copy_bw, "frac_of_copy_kernel": achieved / copy_bw,
                          "traffic": recorded_traffic(workload) if plan is not None else None, "kernel": "interp_kernel<float,4>" if plan is None else "interp_planned_kernel<float>",
                          "staged_rows_per_launch": None if plan is None else plan.total_rows, "kernel_ms": kernel_ms,
                          "algorithmic_bytes": b_alg, "unique_source_rows": n_unique,

@@ -24,6 +24,7 @@
 #include <algorithm>
 #include <cstring>
 #include <numeric>
+#include <thread>
 #include <vector>
 
 struct s3_interp_plan {
@@ -277,7 +278,8 @@ int s3_interp_plan_create(const int32_t *d_idx, int64_t nc, int k, int64_t n_src
     for (int32_t v : idx)
         S3_REQUIRE(v >= 0 && v < n_src, "s3_interp_plan_create: neighbour index %d outside [0, %lld)", v, (long long)n_src);
 
-    // processing order: Morton order of the cell centres (spatially adjacent cells share neighbours)
+    // processing order: Morton order of the cell centres (spatially adjacent cells share neighbours); LSD radix sort of
+    // (key, cell) pairs, stable, so equal keys keep the caller's order
     std::vector<int32_t> perm(nc);
     std::iota(perm.begin(), perm.end(), 0);
     if (d_centers) {
@@ -290,60 +292,119 @@ int s3_interp_plan_create(const int32_t *d_idx, int64_t nc, int k, int64_t n_src
         double ext = 0;
         for (int j = 0; j < dim; ++j) ext = std::max(ext, hi[j] - lo[j]);
         const double scale = ext > 0 ? ((dim == 3 ? 2097151.0 : 2147483647.0) / ext) : 0.0;
-        std::vector<uint64_t> key(nc);
+        std::vector<uint64_t> key(nc), key2(nc);
+        std::vector<int32_t> perm2(nc);
         for (int64_t c = 0; c < nc; ++c) {
             uint64_t q[3] = {0, 0, 0};
             for (int j = 0; j < dim; ++j) q[j] = (uint64_t)((ctr[c * dim + j] - lo[j]) * scale);
             key[c] = dim == 3 ? (spread3(q[0]) | spread3(q[1]) << 1 | spread3(q[2]) << 2) : (spread2(q[0]) | spread2(q[1]) << 1);
         }
-        std::stable_sort(perm.begin(), perm.end(), [&](int32_t a, int32_t b) { return key[a] < key[b]; });
+        for (int pass = 0; pass < 4; ++pass) {            // 4 x 16 bits cover the 62/63-bit keys
+            const int shift = 16 * pass;
+            std::vector<int64_t> hist(65537, 0);
+            for (int64_t c = 0; c < nc; ++c) ++hist[((key[c] >> shift) & 0xffff) + 1];
+            for (int v = 0; v < 65536; ++v) hist[v + 1] += hist[v];
+            for (int64_t c = 0; c < nc; ++c) {
+                const int64_t dst = hist[(key[c] >> shift) & 0xffff]++;
+                key2[dst] = key[c];
+                perm2[dst] = perm[c];
+            }
+            key.swap(key2);
+            perm.swap(perm2);
+        }
     }
 
-    // greedy packing into tiles
+    // greedy packing into tiles: consecutive cells join a tile while it has room (<= tile_cells cells, <= ucap distinct
+    // rows).  The cell sequence is cut into independent chunks packed by separate host threads; each tile keeps its
+    // distinct rows in a small open-addressing table, so no O(n_src) scratch is needed.
     const int ucap = plan_ucap(k, PL_TC);
-    std::vector<int32_t> stamp(n_src, -1), seen(n_src, -1), local(n_src, 0);
-    std::vector<int32_t> tile_cell_begin{0}, tile_row_begin{0}, rows;
-    std::vector<uint16_t> loc((size_t)nc * k);
-    rows.reserve((size_t)nc * k / 2);
-    int32_t tile = 0, cells_in_tile = 0, rows_in_tile = 0;
-    auto close_tile = [&](int64_t pos_end) {
-        // transpose the tile's positions to [m][cell]
-        const int32_t cb = tile_cell_begin.back(), n_c = (int32_t)pos_end - cb;
-        const int32_t rb = tile_row_begin.back();
-        for (int32_t j = 0; j < n_c; ++j) {
-            const int32_t cell = perm[cb + j];
-            for (int m = 0; m < k; ++m) loc[(size_t)cb * k + (size_t)m * n_c + j] = (uint16_t)local[idx[(size_t)cell * k + m]];
-        }
-        (void)rb;
-        tile_cell_begin.push_back((int32_t)pos_end);
-        tile_row_begin.push_back((int32_t)rows.size());
-        ++tile;
-        cells_in_tile = 0;
-        rows_in_tile = 0;
+    struct Chunk {
+        std::vector<int32_t> cell_end, row_end, rows;      // per tile: end position (in perm) / end of its row list
     };
-    for (int64_t pos = 0; pos < nc; ++pos) {
-        const int32_t cell = perm[pos];
-        const int32_t *ci = &idx[(size_t)cell * k];
-        int fresh = 0;                              // rows this cell would add to the tile (repeats inside a row count once)
-        for (int m = 0; m < k; ++m) {
-            const int32_t r = ci[m];
-            if (stamp[r] != tile && seen[r] != (int32_t)pos) {
-                seen[r] = (int32_t)pos;
-                ++fresh;
+    const int n_threads = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)std::thread::hardware_concurrency(), 32, nc / 4096 + 1}));
+    std::vector<Chunk> chunks(n_threads);
+    std::vector<uint16_t> loc((size_t)nc * k);
+    auto pack = [&](int t) {
+        const int64_t pos0 = nc * t / n_threads, pos1 = nc * (t + 1) / n_threads;
+        Chunk &ch = chunks[t];
+        constexpr int HS = 2048;                            // table slots (power of two, > 2 * max ucap is not needed: ucap <= 1024)
+        std::vector<int32_t> hkey(HS, -1), used;
+        std::vector<uint16_t> hval(HS);
+        used.reserve(1100);
+        auto find = [&](int32_t r) -> int {                 // slot of r, or the empty slot where it would go
+            uint32_t s = ((uint32_t)r * 2654435761u) >> 21;  // 11 bits
+            while (hkey[s] != -1 && hkey[s] != r) s = (s + 1) & (HS - 1);
+            return (int)s;
+        };
+        int64_t tile_pos0 = pos0;
+        int rows_in_tile = 0;
+        auto close_tile = [&](int64_t pos_end) {
+            // positions of the tile's (cell, neighbour) pairs, stored [m][cell]
+            const int32_t n_c = (int32_t)(pos_end - tile_pos0);
+            for (int32_t j = 0; j < n_c; ++j) {
+                const int32_t cell = perm[tile_pos0 + j];
+                for (int m = 0; m < k; ++m)
+                    loc[(size_t)tile_pos0 * k + (size_t)m * n_c + j] = hval[find(idx[(size_t)cell * k + m])];
+            }
+            ch.cell_end.push_back((int32_t)pos_end);
+            ch.row_end.push_back((int32_t)ch.rows.size());
+            for (int32_t s : used) hkey[s] = -1;
+            used.clear();
+            rows_in_tile = 0;
+            tile_pos0 = pos_end;
+        };
+        int32_t fresh_ids[S3_MAX_K];
+        for (int64_t pos = pos0; pos < pos1; ++pos) {
+            const int32_t *ci = &idx[(size_t)perm[pos] * k];
+            int fresh = 0;                                   // rows this cell would add (repeats inside a row count once)
+            for (int m = 0; m < k; ++m) {
+                const int32_t r = ci[m];
+                if (hkey[find(r)] == r) continue;
+                bool dup = false;
+                for (int u = 0; u < fresh; ++u) dup |= fresh_ids[u] == r;
+                if (!dup) fresh_ids[fresh++] = r;
+            }
+            if (pos - tile_pos0 == PL_TC || rows_in_tile + fresh > ucap) {
+                close_tile(pos);
+                fresh = 0;                                   // recount against the empty table
+                for (int m = 0; m < k; ++m) {
+                    bool dup = false;
+                    for (int u = 0; u < fresh; ++u) dup |= fresh_ids[u] == ci[m];
+                    if (!dup) fresh_ids[fresh++] = ci[m];
+                }
+            }
+            for (int u = 0; u < fresh; ++u) {
+                const int s_ = find(fresh_ids[u]);
+                hkey[s_] = fresh_ids[u];
+                hval[s_] = (uint16_t)rows_in_tile++;
+                used.push_back(s_);
+                ch.rows.push_back(fresh_ids[u]);
             }
         }
-        if (cells_in_tile == PL_TC || rows_in_tile + fresh > ucap) close_tile(pos);
-        for (int m = 0; m < k; ++m) {
-            const int32_t r = ci[m];
-            if (stamp[r] != tile) {
-                stamp[r] = tile;
-                local[r] = rows_in_tile++;
-                rows.push_back(r);
-            }
-        }
-        ++cells_in_tile;
+        if (pos1 > tile_pos0) close_tile(pos1);
+    };
+    {
+        std::vector<std::thread> workers;
+        for (int t = 1; t < n_threads; ++t) workers.emplace_back(pack, t);
+        pack(0);
+        for (auto &w : workers) w.join();
     }
-    close_tile(nc);
+    std::vector<int32_t> tile_cell_begin{0}, tile_row_begin{0}, rows;
+    {
+        size_t total = 0;
+        for (const Chunk &ch : chunks) total += ch.rows.size();
+        S3_REQUIRE(total < ((size_t)1 << 31), "s3_interp_plan_create: row lists too large");
+        rows.reserve(total);
+        for (const Chunk &ch : chunks) {
+            const int32_t row_base = (int32_t)rows.size();
+            for (size_t i = 0; i < ch.cell_end.size(); ++i) {
+                tile_cell_begin.push_back(ch.cell_end[i]);
+                tile_row_begin.push_back(row_base + ch.row_end[i]);
+            }
+            rows.insert(rows.end(), ch.rows.begin(), ch.rows.end());
+        }
+    }
+    const int32_t tile = (int32_t)tile_cell_begin.size() - 1;
 
     s3_interp_plan *p = new s3_interp_plan();
     p->nc = nc; p->k = k; p->ucap = ucap; p->tc = PL_TC; p->n_src = n_src; p->n_tiles = tile; p->total_rows = (int64_t)rows.size();

@@ -56,3 +56,12 @@ if "big3d" in which:  # 2e7 points (towards SURVEY 8(d) C4)
     geos = [geometry.CubeGeometry("domain", True, cfg["lo"], [float(v) for v in cfg["hi"]]),
             geometry.CylinderGeometry3D("cylinder", False, [(0.8, 1.0, -1.0), (0.8, 1.0, 1.0)], 0.05, refine=True)]
     run("big3d 2e7", x, m, geos, 26, 256, uniform_level=5, min_metric=0.75)
+if "c4" in which:     # 5e7 points in the unit box, n_cells_max = 1e7, tiles of 16 snapshots
+    rng = np.random.default_rng(3)
+    n = 50_000_000
+    x = rng.random((n, 3))
+    r = np.sqrt(((x - 0.5) ** 2).sum(1))
+    m = 0.05 + np.exp(-6 * r) * (1 + 0.5 * np.sin(25 * x[:, 0]) * np.cos(17 * x[:, 1]))
+    del r
+    geos = [geometry.CubeGeometry("domain", True, [0, 0, 0], [1, 1, 1])]
+    run("C4 stress 5e7", x, m, geos, 26, 16, uniform_level=5, n_cells=10_000_000)

@@ -13,6 +13,11 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the native libraries are git-ignored build products: (re)build whatever is missing or stale before collecting
+    import __graft_entry__ as entry
+    entry.build_hip()
+    entry.build_topo()
+    entry.build_oracle()
 
 
 @pytest.fixture(scope="session")

@@ -14,6 +14,7 @@
 // reference's iteration order); this engine receives ordered id arrays.  Neighbour links are deliberately NOT kept
 // current: like the reference they are written when children are created and refreshed only where the reference
 // refreshes them, because the shared-node numbering depends on that staleness.
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -147,6 +148,20 @@ struct Topo {
         center.insert(center.end(), c, c + dim);
     }
 
+    // room for `extra` more cells (one geometric growth step instead of one reallocation check per vector per cell)
+    void reserve_cells(int64_t extra) {
+        const size_t want = (size_t)(n_cells() + extra);
+        if (want <= level.capacity()) return;
+        const size_t cap = std::max(want, level.capacity() * 2);
+        level.reserve(cap);
+        parent.reserve(cap);
+        first_child.reserve(cap);
+        nb.reserve(cap * nnb);
+        node_idx.reserve(cap * nch);
+        center.reserve(cap * dim);
+        nodes.reserve(std::max(nodes.capacity(), (size_t)(nodes.size() + (size_t)extra * dim)));
+    }
+
     // _assign_neighbors(cell, children=existing children)
     void assign_neighbors(int32_t P) {
         const int32_t fc = first_child[P];
@@ -255,6 +270,7 @@ double *s3t_nodes(void *h) { return static_cast<Topo *>(h)->nodes.data(); }
 int64_t s3t_refine(void *h, const int64_t *parents, int64_t n, int relink) {
     Topo *t = static_cast<Topo *>(h);
     const int64_t first = t->n_cells();
+    t->reserve_cells(n * t->nch);
     for (int64_t i = 0; i < n; ++i) {
         if (parents[i] < 0 || parents[i] >= t->n_cells() || t->first_child[parents[i]] != LEAF) return -1;
         t->refine_one((int32_t)parents[i]);

@@ -42,7 +42,7 @@ inline unsigned grid_for(int64_t n, int block, int64_t cap = (int64_t)1 << 30) {
 }
 
 // child / node direction table of the reference (s_cube.py:188-194); component j of direction c
-__device__ __forceinline__ double dir_comp(int dim, int c, int j) {
+__device__ __forceinline__ double dir_comp(int /*dim*/, int c, int j) {
     // 2-D: (-1,-1) (-1,1) (1,1) (1,-1); 3-D: the same four with z=+1, then with z=-1
     if (j == 0) return (c & 3) >= 2 ? 1.0 : -1.0;
     if (j == 1) return ((c & 3) == 1 || (c & 3) == 2) ? 1.0 : -1.0;

@@ -275,8 +275,8 @@ sub_scan_kernel(const int32_t *__restrict__ cell_start, const uint8_t *__restric
 
 template <int DIM>
 __global__ void sub_scatter_kernel(Grid<DIM> g, const double *__restrict__ pts, const int32_t *__restrict__ orig, int64_t n,
-                                   const int32_t *__restrict__ sid, const uint8_t *__restrict__ sub_res,
-                                   const int32_t *__restrict__ sub_off, const int32_t *__restrict__ sub_start,
+                                   const int32_t *__restrict__ sid, const int32_t *__restrict__ sub_off,
+                                   const int32_t *__restrict__ sub_start,
                                    int32_t *__restrict__ cursor, double *__restrict__ out_pts, int32_t *__restrict__ out_orig) {
     int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (p >= n) return;
@@ -805,12 +805,12 @@ int s3_knn_create(const double *d_pts, int64_t n, int dim, double target_occupan
             if (dim == 2) {
                 sub_count_kernel<2><<<grid_for(n, 256), 256, 0, st>>>(make_grid<2>(k), k->pts, n, k->sub_res, k->sub_off, k->sub_start, sid);
                 sub_scan_kernel<<<(unsigned)ncell, 64, 0, st>>>(k->cell_start, k->sub_res, k->sub_off, k->sub_start, dim);
-                sub_scatter_kernel<2><<<grid_for(n, 256), 256, 0, st>>>(make_grid<2>(k), k->pts, k->orig, n, sid, k->sub_res, k->sub_off,
+                sub_scatter_kernel<2><<<grid_for(n, 256), 256, 0, st>>>(make_grid<2>(k), k->pts, k->orig, n, sid, k->sub_off,
                                                                        k->sub_start, cur2, pts2, orig2);
             } else {
                 sub_count_kernel<3><<<grid_for(n, 256), 256, 0, st>>>(make_grid<3>(k), k->pts, n, k->sub_res, k->sub_off, k->sub_start, sid);
                 sub_scan_kernel<<<(unsigned)ncell, 64, 0, st>>>(k->cell_start, k->sub_res, k->sub_off, k->sub_start, dim);
-                sub_scatter_kernel<3><<<grid_for(n, 256), 256, 0, st>>>(make_grid<3>(k), k->pts, k->orig, n, sid, k->sub_res, k->sub_off,
+                sub_scatter_kernel<3><<<grid_for(n, 256), 256, 0, st>>>(make_grid<3>(k), k->pts, k->orig, n, sid, k->sub_off,
                                                                        k->sub_start, cur2, pts2, orig2);
             }
             S3_TRY2(hipGetLastError());

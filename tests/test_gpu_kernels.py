@@ -326,3 +326,24 @@ def test_degenerate_sizes(ops, orc):
     idx, dist = knn.query(same[:3], 8)
     assert np.array_equal(idx.cpu().numpy(), np.tile(np.arange(8), (3, 1))) and float(dist.abs().max()) == 0.0
     knn.close()
+
+
+def test_integration_md_stub_runs(orc):
+    """the ctypes stub printed in INTEGRATION.md (route B) is executable as written and matches the oracle"""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", text, flags=re.S)
+    stub = [b for b in blocks if "s3_knn_create.argtypes" in b][0]
+    stub = stub.replace('C.CDLL("libs3hip.so")', f'C.CDLL("{os.path.join(root, "sparsespatialsampling_amd", "libs3hip.so")}")')
+    ns = {}
+    exec(compile(stub, "INTEGRATION.md", "exec"), ns)
+    rng = np.random.default_rng(8)
+    x, c = rng.random((5000, 3)), rng.random((700, 3))
+    idx, w = ns["knn_cache"](pt.from_numpy(x), pt.from_numpy(c), 26)
+    idx_o, dist_o = orc.knn(x, c, 26)
+    assert np.array_equal(idx.cpu().numpy(), idx_o) and np.array_equal(w.cpu().numpy(), orc.idw_weights(dist_o))
+    data = rng.standard_normal((5000, 2, 9)).astype(np.float32)
+    out = ns["interpolate_data"](w.cpu(), idx.cpu().long(), pt.from_numpy(data))
+    ref = orc.interp(orc.idw_weights(dist_o), idx_o, data)
+    assert not out.is_cuda and np.abs(out.numpy() - ref).max() <= 1e-13 * np.abs(ref).max()

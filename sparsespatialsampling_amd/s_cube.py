@@ -357,9 +357,13 @@ class SamplingTree(object):
         """create the children of the ordered parents: topology on the host, geometry + metric + gain on the device
         (body shared by s_cube.py:531-555 and 879-900).  Returns (first new id, number of new cells)."""
         nch = 2 ** self._n_dimensions
-        first = self._topo.refine(order, relink=uniform)
+        # the ids of the new cells are known up front (children are numbered consecutively from the current cell count),
+        # so the kernels are launched first and the host topology work overlaps them
+        first = self._topo.n_cells
         n_new = self._backend.refine_batch(order, first)
-        assert n_new == len(order) * nch and self._topo.n_cells == first + n_new
+        first_topo = self._topo.refine(order, relink=uniform)
+        if first_topo != first or n_new != len(order) * nch or self._topo.n_cells != first + n_new:
+            raise RuntimeError("host topology and device cell arrays disagree about the ids of the new cells")
         self._n_cells += n_new
         self._values = None
         return first, n_new

@@ -268,7 +268,9 @@ class SamplingTree(object):
         self._topo = None
         self._cells = _CellList(self)
         self._create_first_cell()
-        self._target_norm = pt.linalg.norm(target.detach().cpu().to(pt.float64)).item()
+        # like the reference (s_cube.py:205) the norm is taken in the dtype the user passed (a float32 metric gives a
+        # float32 norm)
+        self._target_norm = pt.linalg.norm(target.detach().cpu()).item()
 
     # ------------------------------------------------------------------------------------------------------------
     def _create_first_cell(self) -> None:

@@ -29,7 +29,7 @@ import ref_stubs  # noqa: E402,F401  (installs shims + sys.path; must run in spa
 import numpy as np  # noqa: E402
 import torch as pt  # noqa: E402
 
-from inputs import REFINE_CASES, cloud, mask_cells, refine_inputs, sha, wake_metric  # noqa: E402
+from inputs import REFINE_CASES, c1_cylinder2d, cloud, mask_cells, refine_inputs, sha, wake_metric  # noqa: E402
 
 
 def save(name, **kw):
@@ -193,8 +193,21 @@ def gen_refine(only=None):
              max_level=np.array(info["max_level"]), **arr)
 
 
+def gen_c1():
+    """full-size C1 run of the reference (87 adaptive iterations): grid + histories only"""
+    import sparseSpatialSampling.geometry as ref_geometry
+    from sparseSpatialSampling.s_cube import SamplingTree
+    x, m, geos, kw = c1_cylinder2d(ref_geometry)
+    tree = SamplingTree(pt.from_numpy(x), pt.from_numpy(m), geometry_obj=geos, n_jobs=4, **kw)
+    tree.refine()
+    save("c1_cylinder2d", input_sha=np.array(sha(x, m)), all_centers=tree.all_centers.numpy(),
+         all_levels=tree.all_levels.numpy().astype(np.int8), face_ids=tree.face_ids.numpy(),
+         metric_hist=np.array(tree._metric), n_cells_log=np.array(tree._n_cells_log),
+         iterations=np.array(tree.data_final_mesh["iterations"]))
+
+
 if __name__ == "__main__":
-    groups = sys.argv[1:] or ["interp", "knncache", "predict", "masks", "uniform", "refine"]
+    groups = sys.argv[1:] or ["interp", "knncache", "predict", "masks", "uniform", "refine", "c1"]
     pt.manual_seed(0)
     for g in groups:
         if g.startswith("refine_"):

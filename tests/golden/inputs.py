@@ -93,3 +93,16 @@ def mask_cells(d, n, rng):
     c = rng.random((n, d)) * 2.0 - 0.5
     h = rng.random(n) * 0.4 + 0.01
     return c, h
+
+
+def c1_cylinder2d(geometry):
+    """BASELINE config C1 realised synthetically: ~14 000 points in the cylinder2D channel, wake-like metric,
+    Cube domain + Sphere body refined to level 9 (reference examples/s3_for_cylinder2D_Re100.py:43-52)"""
+    rng = np.random.default_rng(0)
+    x = rng.random((14500, 2)) * [2.2, 0.41]
+    x = np.ascontiguousarray(x[((x - [0.2, 0.2]) ** 2).sum(1) > 0.05 ** 2])
+    m = (0.02 + np.exp(-((x[:, 1] - 0.2) / 0.08) ** 2) * np.where(x[:, 0] > 0.2, np.exp(-(x[:, 0] - 0.2)), 0)
+         + np.exp(-20 * np.hypot(x[:, 0] - 0.2, x[:, 1] - 0.2)))
+    geos = [geometry.CubeGeometry("domain", True, [0, 0], [2.2, 0.41]),
+            geometry.SphereGeometry("cylinder", False, [0.2, 0.2], 0.05, refine=True, min_refinement_level=9)]
+    return x, m, geos, dict(uniform_level=5, min_metric=0.75)

@@ -195,3 +195,22 @@ def test_export_fit_paths_gpu(tmp_path, t, ncomp, on_gpu):
             assert np.abs(got.numpy() - ref).max() <= 1e-13 * np.abs(ref).max()
             assert got[:, :, 0].is_contiguous()              # snapshot-major memory: what the writer stores per time
     assert ex._snapshot_counter == 2 * t
+
+
+def test_c1_cylinder2d_full_size_matches_reference():
+    """BASELINE config C1 at full size (14 350 points, 87 adaptive iterations, body refined to level 9): grid, faces and
+    iteration histories against the real reference (18 s there, tests/golden/gen_golden.py c1)"""
+    import sparsespatialsampling_amd.s_cube as s_cube
+    from sparsespatialsampling_amd import geometry
+    from inputs import c1_cylinder2d
+    z = load("c1_cylinder2d")
+    x, m, geos, kw = c1_cylinder2d(geometry)
+    assert sha(x, m) == str(z["input_sha"])
+    tree = s_cube.SamplingTree(pt.from_numpy(x), pt.from_numpy(m), geometry_obj=geos, **kw)
+    tree.refine()
+    assert np.array_equal(tree.all_centers.numpy(), z["all_centers"])
+    assert np.array_equal(tree.all_levels.numpy(), z["all_levels"].astype(np.int64))
+    assert np.array_equal(tree.face_ids.numpy(), z["face_ids"])
+    assert np.array_equal(np.array(tree._n_cells_log), z["n_cells_log"])
+    np.testing.assert_allclose(np.array(tree._metric), z["metric_hist"], rtol=1e-12)
+    assert tree.data_final_mesh["iterations"] == int(z["iterations"])

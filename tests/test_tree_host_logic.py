@@ -97,3 +97,18 @@ def test_refine_matches_reference(oracle_backend, name):
     assert np.array_equal(np.concatenate(trace), z["trace"])
     check_tree_against_golden(tree, z)
     check_outputs_against_golden(tree, z)
+
+
+def test_c1_cylinder2d_full_size(oracle_backend):
+    """BASELINE config C1 at full size, host logic + oracle kernels vs the real reference (87 adaptive iterations)"""
+    from inputs import c1_cylinder2d
+    z = load("c1_cylinder2d")
+    x, m, geos, kw = c1_cylinder2d(geometry)
+    assert sha(x, m) == str(z["input_sha"])
+    tree = s_cube.SamplingTree(pt.from_numpy(x), pt.from_numpy(m), geometry_obj=geos, **kw)
+    tree.refine()
+    assert np.array_equal(tree.all_centers.numpy(), z["all_centers"])
+    assert np.array_equal(tree.all_levels.numpy(), z["all_levels"].astype(np.int64))
+    assert np.array_equal(tree.face_ids.numpy(), z["face_ids"])
+    assert np.array_equal(np.array(tree._n_cells_log), z["n_cells_log"])
+    np.testing.assert_allclose(np.array(tree._metric), z["metric_hist"], rtol=1e-12)

@@ -8,12 +8,14 @@
 // by the Infinity Cache at ~7-8 TB/s and bounds the kernel.  The neighbour table is static for a whole export (it is
 // computed once and reused for every snapshot batch and field), so it pays to de-duplicate it once:
 //
-//   plan (host, once):  cells are put in Morton order of their centres; consecutive cells are packed greedily into
+//   plan (host, once):  cells are put in Morton order of their centres (radix sort); consecutive cells are packed
+//                       greedily (host threads, one hash table per tile) into
 //                       tiles of <= 64 cells whose neighbour sets contain <= ucap (~500) distinct source rows; per tile the
 //                       distinct row ids and, per (cell, neighbour), the 16-bit position in that list are stored.
 //   kernel (per batch): one workgroup (256 threads) per tile.  For every 128-byte column chunk of the row it stages the
-//                       tile's distinct source rows ONCE into LDS (coalesced 128-B segments, <= 19 16-B loads in
-//                       flight per lane), then every thread accumulates its cell's k neighbours from LDS
+//                       tile's distinct source rows ONCE into LDS (coalesced 128-B segments; the loads of the next two
+//                       chunks are in flight in 2 x 16 registers per lane), then every thread accumulates its cell's k
+//                       neighbours from LDS
 //                       (2 x ds_read_b128 + 8 cvt + 8 FMA per neighbour; the tile's weights and LDS positions are
 //                       staged in LDS once per tile), and writes 2 x 32 B of the f64 output row.
 //

@@ -23,7 +23,8 @@ def _stream():
 def _ptr(t):
     if t is None:
         return C.c_void_p(0)
-    assert t.is_cuda and t.is_contiguous(), "device-resident contiguous tensor required"
+    if not (t.is_cuda and t.is_contiguous()):       # a host pointer handed to a kernel would fault the GPU
+        raise TypeError("device-resident contiguous tensor required")
     return C.c_void_p(t.data_ptr())
 
 
@@ -121,7 +122,8 @@ def idw_weights(dist):
 def interp(w, idx, data, out=None):
     """out[c, ...] = sum_m w[c,m] * data[idx[c,m], ...]   (export.py:446-468).  w f64 [nc,k], idx int32 [nc,k],
     data f32/f64 [n_src, ...] -- all on the device; returns f64 [nc, ...] on the device."""
-    assert w.dtype == pt.float64 and idx.dtype == pt.int32 and data.dtype in DTYPE_CODE
+    if not (w.dtype == pt.float64 and idx.dtype == pt.int32 and data.dtype in DTYPE_CODE and w.shape == idx.shape):
+        raise TypeError("interp: w must be float64 [nc,k], idx int32 [nc,k], data float32/float64")
     nc, k = int(w.shape[0]), int(w.shape[1])
     n_src = int(data.shape[0])
     row_len = int(np.prod(data.shape[1:])) if data.dim() > 1 else 1
@@ -146,7 +148,8 @@ class InterpPlan:
     every snapshot batch.  ``centers`` (cell centres, [nc, dim]) gives the Morton processing order."""
 
     def __init__(self, idx, n_src, centers=None, tile_cells=0):
-        assert idx.is_cuda and idx.dtype == pt.int32 and idx.is_contiguous()
+        if not (idx.is_cuda and idx.dtype == pt.int32 and idx.is_contiguous() and idx.dim() == 2):
+            raise TypeError("InterpPlan: idx must be a contiguous int32 [nc, k] device tensor")
         self.nc, self.k = int(idx.shape[0]), int(idx.shape[1])
         self.n_src = int(n_src)
         ctr = to_device(centers, pt.float64) if centers is not None else None
@@ -178,16 +181,21 @@ class InterpPlan:
     def interp(self, w, data, out=None):
         """``data`` [n_src, ...]: contiguous, or a column slice ``buf[:, :L]`` of a wider 2-D buffer (rows padded to a
         multiple of 128 bytes keep every staged segment on one cache line, see ``padded_rows``)."""
-        assert w.dtype == pt.float64 and tuple(w.shape) == (self.nc, self.k) and int(data.shape[0]) == self.n_src
+        if not (w.dtype == pt.float64 and tuple(w.shape) == (self.nc, self.k) and int(data.shape[0]) == self.n_src
+                and data.dtype in DTYPE_CODE):
+            raise TypeError("InterpPlan.interp: weights / data do not match the plan")
         row_len = int(np.prod(data.shape[1:])) if data.dim() > 1 else 1
         if data.is_contiguous():
             in_stride = row_len
-        else:
-            assert data.dim() == 2 and data.stride(1) == 1 and data.stride(0) >= row_len, "unsupported data layout"
+        elif data.dim() == 2 and data.stride(1) == 1 and data.stride(0) >= row_len:
             in_stride = int(data.stride(0))
+        else:
+            raise TypeError("InterpPlan.interp: unsupported data layout")
         if out is None:
             out = pt.empty((self.nc,) + tuple(data.shape[1:]), dtype=pt.float64, device=data.device)
-        assert data.is_cuda and out.is_cuda and out.is_contiguous()
+        if not (data.is_cuda and out.is_cuda and out.is_contiguous() and out.dtype == pt.float64
+                and out.numel() == self.nc * row_len):
+            raise TypeError("InterpPlan.interp: device tensors required, out must be contiguous float64 [nc, ...]")
         check(_lib.hip_lib().s3_interp_planned(self._handle, _ptr(w), C.c_void_p(data.data_ptr()),
                                                DTYPE_CODE[data.dtype], row_len, in_stride, _ptr(out), _stream()),
               "s3_interp_planned")

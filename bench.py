@@ -197,7 +197,7 @@ def main():
     gen = pt.Generator(device="cuda").manual_seed(1234 + (rank if args.shard == "snapshots" else 0))
     if plan is not None:
         # same layout the export path uploads into: [N, n_comp*T] with the row pitch padded to a multiple of 128 bytes
-        data = hipops.padded_rows(n_src, t_b, pt.float32, "cuda")
+        data = hipops.padded_rows(n_src, t_b, pt.float32, "cuda", int(os.environ.get("S3_BENCH_PITCH_EXTRA", "0")))
         data.normal_(generator=gen)
     else:
         data = pt.randn((n_src, 1, t_b), dtype=pt.float32, device="cuda", generator=gen)

@@ -8,7 +8,7 @@
 // by the Infinity Cache at ~7-8 TB/s and bounds the kernel.  The neighbour table is static for a whole export (it is
 // computed once and reused for every snapshot batch and field), so it pays to de-duplicate it once:
 //
-//   plan (host, once):  cells are put in Morton order of their centres (radix sort); consecutive cells are packed
+//   plan (host, once):  cells are put in Hilbert order of their centres (radix sort); consecutive cells are packed
 //                       greedily (host threads, one hash table per tile) into
 //                       tiles of <= 64 cells whose neighbour sets contain <= ucap (~500) distinct source rows; per tile the
 //                       distinct row ids and, per (cell, neighbour), the 16-bit position in that list are stored.
@@ -48,7 +48,6 @@ template <typename T>
 struct Vec16;
 template <> struct Vec16<float> { using type = float4; static constexpr int N = 4; };
 template <> struct Vec16<double> { using type = double2; static constexpr int N = 2; };
-
 template <typename T, int TC>
 __global__ void __launch_bounds__(TC * 4, 2)  // 226 VGPRs: two waves per SIMD
 interp_planned_kernel(const int32_t *__restrict__ perm, const int32_t *__restrict__ tile_cell_begin,
@@ -181,24 +180,33 @@ static int plan_ucap(int k, int tc) {
     return u > cap ? cap : u;
 }
 
-static inline uint64_t spread3(uint64_t v) {   // 21 bits -> every third bit
-    v &= 0x1fffff;
-    v = (v | v << 32) & 0x1f00000000ffffull;
-    v = (v | v << 16) & 0x1f0000ff0000ffull;
-    v = (v | v << 8) & 0x100f00f00f00f00full;
-    v = (v | v << 4) & 0x10c30c30c30c30c3ull;
-    v = (v | v << 2) & 0x1249249249249249ull;
-    return v;
-}
-
-static inline uint64_t spread2(uint64_t v) {   // 31 bits -> every second bit
-    v &= 0x7fffffff;
-    v = (v | v << 16) & 0x0000ffff0000ffffull;
-    v = (v | v << 8) & 0x00ff00ff00ff00ffull;
-    v = (v | v << 4) & 0x0f0f0f0f0f0f0f0full;
-    v = (v | v << 2) & 0x3333333333333333ull;
-    v = (v | v << 1) & 0x5555555555555555ull;
-    return v;
+// Hilbert index of a quantised point (dim axes, b bits each; Skilling's transpose algorithm).  Consecutive cells of the
+// curve are always face neighbours, so runs of the curve make more compact tiles than Z-order runs (3 % fewer staged
+// rows on the cylinder3D workload) and consecutive tiles always touch.
+static inline uint64_t hilbert_key(const uint32_t *q, int dim, int b) {
+    uint32_t X[3] = {q[0], q[1], dim == 3 ? q[2] : 0};
+    const uint32_t M = 1u << (b - 1);
+    for (uint32_t Q = M; Q > 1; Q >>= 1) {
+        const uint32_t P = Q - 1;
+        for (int i = 0; i < dim; ++i) {
+            if (X[i] & Q) {
+                X[0] ^= P;
+            } else {
+                const uint32_t t = (X[0] ^ X[i]) & P;
+                X[0] ^= t;
+                X[i] ^= t;
+            }
+        }
+    }
+    for (int i = 1; i < dim; ++i) X[i] ^= X[i - 1];
+    uint32_t t = 0;
+    for (uint32_t Q = M; Q > 1; Q >>= 1)
+        if (X[dim - 1] & Q) t ^= Q - 1;
+    for (int i = 0; i < dim; ++i) X[i] ^= t;
+    uint64_t h = 0;
+    for (int bit = b - 1; bit >= 0; --bit)
+        for (int i = 0; i < dim; ++i) h = (h << 1) | ((X[i] >> bit) & 1u);
+    return h;
 }
 
 }  // namespace s3
@@ -280,8 +288,8 @@ int s3_interp_plan_create(const int32_t *d_idx, int64_t nc, int k, int64_t n_src
     for (int32_t v : idx)
         S3_REQUIRE(v >= 0 && v < n_src, "s3_interp_plan_create: neighbour index %d outside [0, %lld)", v, (long long)n_src);
 
-    // processing order: Morton order of the cell centres (spatially adjacent cells share neighbours); LSD radix sort of
-    // (key, cell) pairs, stable, so equal keys keep the caller's order
+    // processing order: Hilbert order of the cell centres (spatially adjacent cells share neighbours); LSD radix sort
+    // of (key, cell) pairs, stable, so equal keys keep the caller's order
     std::vector<int32_t> perm(nc);
     std::iota(perm.begin(), perm.end(), 0);
     if (d_centers) {
@@ -293,15 +301,16 @@ int s3_interp_plan_create(const int32_t *d_idx, int64_t nc, int k, int64_t n_src
             }
         double ext = 0;
         for (int j = 0; j < dim; ++j) ext = std::max(ext, hi[j] - lo[j]);
-        const double scale = ext > 0 ? ((dim == 3 ? 2097151.0 : 2147483647.0) / ext) : 0.0;
+        const int bits = dim == 3 ? 16 : 24;                // 48-bit keys: three 16-bit sorting passes
+        const double scale = ext > 0 ? ((double)((1u << bits) - 1) / ext) : 0.0;
         std::vector<uint64_t> key(nc), key2(nc);
         std::vector<int32_t> perm2(nc);
         for (int64_t c = 0; c < nc; ++c) {
-            uint64_t q[3] = {0, 0, 0};
-            for (int j = 0; j < dim; ++j) q[j] = (uint64_t)((ctr[c * dim + j] - lo[j]) * scale);
-            key[c] = dim == 3 ? (spread3(q[0]) | spread3(q[1]) << 1 | spread3(q[2]) << 2) : (spread2(q[0]) | spread2(q[1]) << 1);
+            uint32_t q[3] = {0, 0, 0};
+            for (int j = 0; j < dim; ++j) q[j] = (uint32_t)((ctr[c * dim + j] - lo[j]) * scale);
+            key[c] = hilbert_key(q, dim, bits);
         }
-        for (int pass = 0; pass < 4; ++pass) {            // 4 x 16 bits cover the 62/63-bit keys
+        for (int pass = 0; pass < 3; ++pass) {
             const int shift = 16 * pass;
             std::vector<int64_t> hist(65537, 0);
             for (int64_t c = 0; c < nc; ++c) ++hist[((key[c] >> shift) & 0xffff) + 1];

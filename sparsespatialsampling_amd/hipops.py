@@ -145,7 +145,7 @@ def snapshot_major(values, n_comp, n_snapshots):
 
 class InterpPlan:
     """De-duplicated, LDS-tiled form of a static neighbour table (s3_interp_plan_*): build once per KNN cache, reuse for
-    every snapshot batch.  ``centers`` (cell centres, [nc, dim]) gives the Morton processing order."""
+    every snapshot batch.  ``centers`` (cell centres, [nc, dim]) gives the Hilbert-curve processing order."""
 
     def __init__(self, idx, n_src, centers=None, tile_cells=0):
         if not (idx.is_cuda and idx.dtype == pt.int32 and idx.is_contiguous() and idx.dim() == 2):
@@ -202,11 +202,19 @@ class InterpPlan:
         return out
 
 
-def padded_rows(n_rows, row_len, dtype, dev):
-    """[n_rows, row_len] view of a device buffer whose row pitch is a multiple of 128 bytes (upload target for
-    snapshot batches: every 128-B segment the planned kernel stages then sits on exactly one cache line)"""
+def padded_rows(n_rows, row_len, dtype, dev, extra_lines=0):
+    """[n_rows, row_len] view of a device buffer whose row pitch is a whole number of 128-byte lines (upload target for
+    snapshot batches: every 128-B segment the planned kernel stages then sits on exactly one cache line).  For long rows
+    the line count is moved to the next value = 3 (mod 4): a tile reads the same column of ~400 scattered rows at a
+    time, and with a pitch of 2^n or 2^n + 1 lines those addresses load the memory channels unevenly (MI355X, 4000-B
+    rows, same process: 32 lines 3.69 ms, 33: 3.66, 34: 3.41*, 35: 3.37*/3.54, 37..47: 3.52-3.53, 64: 3.44*; * = a
+    faster box of the pool)"""
     per_line = 128 // pt.empty((), dtype=dtype).element_size()
-    pitch = (row_len + per_line - 1) // per_line * per_line
+    lines = (row_len + per_line - 1) // per_line
+    if lines >= 16:
+        while lines % 4 != 3 or lines % 32 == 31:
+            lines += 1
+    pitch = (lines + int(extra_lines)) * per_line
     return pt.empty((n_rows, pitch), dtype=dtype, device=dev)[:, :row_len]
 
 

@@ -36,17 +36,20 @@ for item in spec.split(";"):
     if extra not in buffers:
         buffers[extra] = hipops.padded_rows(len(x), T, pt.float32, "cuda", extra[0])
         buffers[extra].normal_(generator=pt.Generator(device="cuda").manual_seed(1))
-    variants.append((name, plan, buffers[extra]))
+    variants.append((name, plan, buffers[extra], {kk: v for kk, v in env.items() if kk.startswith("S3_PLAN_EARLY") or kk.startswith("S3_LAUNCH_")}))
     print(f"{name}: tiles {plan.n_tiles} staged rows {plan.total_rows} pitch {buffers[extra].stride(0) * 4} B", flush=True)
-times = {n: [] for n, _, _ in variants}
+times = {v[0]: [] for v in variants}
 for r in range(rounds + 1):
-    for name, plan, data in variants:
+    for name, plan, data, lenv in variants:
+        os.environ.update(lenv)          # switches read at launch time
         e0, e1 = pt.cuda.Event(enable_timing=True), pt.cuda.Event(enable_timing=True)
         plan.interp(w, data, out=out)
         e0.record()
         for _ in range(reps):
             plan.interp(w, data, out=out)
         e1.record(); pt.cuda.synchronize()
+        for kk in lenv:
+            del os.environ[kk]
         if r:
             times[name].append(e0.elapsed_time(e1) / reps)
 for n, t in times.items():

@@ -119,13 +119,21 @@ def main():
                     "planned LDS-tiled kernel (s3_interp_planned)")
     args = ap.parse_args()
 
+    # stdout carries exactly one JSON line: libraries that print there (the RCCL version banner at communicator
+    # creation) are sent to stderr for the whole run, the result goes to the saved descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # S3_BENCH_SHARE_GPU=1 + S3_DIST_BACKEND=gloo: rehearsal of the N>1 code path on a box with a single GPU
     share = os.environ.get("S3_BENCH_SHARE_GPU") == "1"
     pt.cuda.set_device(0 if share else local_rank)
-    if world > 1:
+    # S3_BENCH_FORCE_DIST=1: run the process-group code path (RCCL init, barriers, MAX all-reduce) with a single rank too
+    use_dist = world > 1 or os.environ.get("S3_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         backend = os.environ.get("S3_DIST_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=pt.device("cuda", local_rank))
@@ -212,7 +220,7 @@ def main():
     for _ in range(args.warmup):
         step()
     pt.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     ev = [(pt.cuda.Event(enable_timing=True), pt.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
@@ -221,10 +229,10 @@ def main():
         step()
         b.record()
     pt.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = pt.tensor([elapsed], dtype=pt.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -258,8 +266,8 @@ def main():
         }
         if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(x, centers, k, min(t_b, 64))
-        print(json.dumps(res))
-    if world > 1:
+        os.write(json_fd, (json.dumps(res) + "\n").encode())
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

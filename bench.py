@@ -264,7 +264,7 @@ def main():
                          "algorithmic_bytes": b_alg, "unique_source_rows": n_unique,
                          "gather_upper_bound_bytes": nc * k * t_b * 4 + nc * t_b * 8},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:       # reported at N=1 only
             res["cpu_baseline"] = cpu_baseline(x, centers, k, min(t_b, 64))
         os.write(json_fd, (json.dumps(res) + "\n").encode())
     if use_dist:

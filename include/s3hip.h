@@ -96,7 +96,12 @@ int s3_child_gain(const s3_knn *knn, int k, const double *d_center, const int32_
  *   box:      lo <= x <= hi in every dimension                       cube_geometry.py:50-74
  *   sphere:   ||x - pos|| <= radius                                  sphere_geometry.py:47-72
  *   cylinder: 0 <= proj <= norm && normal distance <= local radius   cylinder_geometry.py:126-157
- *   polygon:  strictly inside (boundary excluded)                    coordinates_2d.py:54-75 */
+ *   polygon:  strictly inside (boundary excluded)                    coordinates_2d.py:54-75
+ *   triangle: edge cross products not of mixed sign (outline inside) triangle_geometry.py:80-103
+ *   prism:    0 <= proj <= norm && in-plane point inside triangle    prism_geometry.py:90-118
+ *   tetrahedra (1 = tetrahedron, 2 = the two halves of a pyramid, union): no inward face normal sees the point
+ *             behind its face                                        tetrahedron_geometry.py:121-140,
+ *                                                                    pyramid_geometry.py:156-170 */
 int s3_mask_box(const double *d_center, const int32_t *d_level, const int32_t *d_cells, int64_t first, int64_t n, int dim,
                 double width, const double *h_lo, const double *h_hi, int refine_mode, int keep_inside,
                 uint8_t *d_invalid, s3_stream stream);
@@ -109,6 +114,18 @@ int s3_mask_cylinder(const double *d_center, const int32_t *d_level, const int32
 int s3_mask_polygon(const double *d_center, const int32_t *d_level, const int32_t *d_cells, int64_t first, int64_t n,
                     double width, const double *d_poly /*[nv,2] device*/, int nv, int refine_mode, int keep_inside,
                     uint8_t *d_invalid, s3_stream stream);
+int s3_mask_triangle(const double *d_center, const int32_t *d_level, const int32_t *d_cells, int64_t first, int64_t n,
+                     double width, const double *h_points /*[3][2]*/, int refine_mode, int keep_inside,
+                     uint8_t *d_invalid, s3_stream stream);
+int s3_mask_prism(const double *d_center, const int32_t *d_level, const int32_t *d_cells, int64_t first, int64_t n,
+                  double width, const double *h_origin /*[3] first point of the first triangle*/,
+                  const double *h_axis /*[3] extrusion*/, double norm, const int32_t *h_dims /*[2] in-plane axes*/,
+                  const double *h_triangle /*[3][2] first triangle in those axes*/, int refine_mode, int keep_inside,
+                  uint8_t *d_invalid, s3_stream stream);
+int s3_mask_tetrahedra(const double *d_center, const int32_t *d_level, const int32_t *d_cells, int64_t first, int64_t n,
+                       double width, const double *h_positions /*[n_tets][4][3]*/,
+                       const double *h_normals /*[n_tets][3][4] inward, column p belongs to point p*/, int n_tets,
+                       int refine_mode, int keep_inside, uint8_t *d_invalid, s3_stream stream);
 
 /* bookkeeping of one refine batch on the device-resident cell arrays: parents stop being leaves, valid children
  * become leaves, invalid children get gain 0 (s_cube.py:721-723, 250-251) */

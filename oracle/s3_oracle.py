@@ -175,6 +175,34 @@ def mask_cylinder(centers, level, width, position, radius, refine_mode, keep_ins
     return inv.astype(bool)
 
 
+def mask_triangle(centers, level, width, points, refine_mode, keep_inside):
+    centers, level, inv = _cells(centers, level)
+    pts = _f64(points).reshape(3, 2)
+    lib().s3o_mask_triangle(_p(centers), _p(level), C.c_int64(len(centers)), C.c_double(float(width)), _p(pts),
+                            int(refine_mode), int(keep_inside), _p(inv))
+    return inv.astype(bool)
+
+
+def mask_prism(centers, level, width, origin, axis, norm, dims, triangle, refine_mode, keep_inside):
+    centers, level, inv = _cells(centers, level)
+    origin, axis, tri = _f64(origin), _f64(axis), _f64(triangle).reshape(3, 2)
+    dims = np.ascontiguousarray(dims, dtype=np.int32)
+    lib().s3o_mask_prism(_p(centers), _p(level), C.c_int64(len(centers)), C.c_double(float(width)), _p(origin),
+                         _p(axis), C.c_double(float(norm)), _p(dims), _p(tri), int(refine_mode), int(keep_inside),
+                         _p(inv))
+    return inv.astype(bool)
+
+
+def mask_tetrahedra(centers, level, width, positions, normals, refine_mode, keep_inside):
+    centers, level, inv = _cells(centers, level)
+    pos, nrm = _f64(positions), _f64(normals)
+    n_tets = pos.shape[0]
+    assert pos.shape == (n_tets, 4, 3) and nrm.shape == (n_tets, 3, 4)
+    lib().s3o_mask_tetrahedra(_p(centers), _p(level), C.c_int64(len(centers)), C.c_double(float(width)), _p(pos),
+                              _p(nrm), n_tets, int(refine_mode), int(keep_inside), _p(inv))
+    return inv.astype(bool)
+
+
 def mask_polygon(centers, level, width, poly, refine_mode, keep_inside):
     centers, level, inv = _cells(centers, level)
     poly = _f64(poly)

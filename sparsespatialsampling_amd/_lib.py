@@ -53,6 +53,10 @@ HIP_SIGNATURES = {
     "s3_mask_cylinder": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_dbl, c_vp, c_vp, c_dbl, c_dbl, c_dbl, c_int, c_int,
                                  c_int, c_vp, c_vp]),
     "s3_mask_polygon": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_dbl, c_vp, c_int, c_int, c_int, c_vp, c_vp]),
+    "s3_mask_triangle": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_dbl, c_vp, c_int, c_int, c_vp, c_vp]),
+    "s3_mask_prism": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_dbl, c_vp, c_vp, c_dbl, c_vp, c_vp, c_int, c_int, c_vp,
+                              c_vp]),
+    "s3_mask_tetrahedra": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_dbl, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp]),
     "s3_commit_batch": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp]),
     "s3_sumsq_leaf": (c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp]),
     "s3_topn_scratch_bytes": (C.c_size_t, [c_i64, c_i64]),

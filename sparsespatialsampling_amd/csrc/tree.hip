@@ -48,6 +48,9 @@ struct BoxParams { double lo[3], hi[3]; };
 struct SphereParams { double pos[3], radius; };
 struct CylParams { double p0[3], axis[3], norm, r0, r1; int is_cone; };
 struct PolyParams { const double *poly; int nv; };
+struct TriParams { double p[3][2]; };
+struct PrismParams { double origin[3], axis[3], norm; int dims[2]; TriParams tri; };
+struct TetParams { double pos[2][4][3], nrm[2][3][4]; int n_tets; };
 
 template <int DIM>
 __device__ __forceinline__ bool inside(const BoxParams &g, const double (&x)[DIM]) {
@@ -100,6 +103,56 @@ __device__ __forceinline__ bool inside(const PolyParams &g, const double (&x)[DI
         }
     }
     return in;
+}
+
+// triangle: sign test of the three edge cross products (triangle_geometry.py:80-103); edges 0->1, 1->2, 2->0, the third
+// one measured from point 0 as the reference does; the outline counts as inside
+__device__ __forceinline__ bool inside_triangle(const TriParams &g, double x, double y) {
+    const double d1 = (g.p[1][0] - g.p[0][0]) * (y - g.p[0][1]) - (g.p[1][1] - g.p[0][1]) * (x - g.p[0][0]);
+    const double d2 = (g.p[2][0] - g.p[1][0]) * (y - g.p[1][1]) - (g.p[2][1] - g.p[1][1]) * (x - g.p[1][0]);
+    const double d3 = (g.p[0][0] - g.p[2][0]) * (y - g.p[0][1]) - (g.p[0][1] - g.p[2][1]) * (x - g.p[0][0]);
+    const bool neg = (d1 < 0.0) | (d2 < 0.0) | (d3 < 0.0), pos = (d1 > 0.0) | (d2 > 0.0) | (d3 > 0.0);
+    return !(neg & pos);
+}
+
+template <int DIM>
+__device__ __forceinline__ bool inside(const TriParams &g, const double (&x)[DIM]) {
+    static_assert(DIM == 2, "triangle is 2-D only");
+    return inside_triangle(g, x[0], x[1]);
+}
+
+// prism: projection on the extrusion axis within [0, |axis|] and the in-plane coordinates inside the first triangle
+// (prism_geometry.py:90-118)
+template <int DIM>
+__device__ __forceinline__ bool inside(const PrismParams &g, const double (&x)[DIM]) {
+    static_assert(DIM == 3, "prism is 3-D only");
+    double v[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) v[j] = x[j] - g.origin[j];
+    const double proj = ((v[0] * g.axis[0] + v[1] * g.axis[1]) + v[2] * g.axis[2]) / g.norm;
+    const double u0 = g.dims[0] == 0 ? x[0] : (g.dims[0] == 1 ? x[1] : x[2]);
+    const double u1 = g.dims[1] == 0 ? x[0] : (g.dims[1] == 1 ? x[1] : x[2]);
+    return (0.0 <= proj) & (proj <= g.norm) & inside_triangle(g.tri, u0, u1);
+}
+
+// tetrahedron / pyramid (= union of two tetrahedra): no face sees the point on its outer side
+// (tetrahedron_geometry.py:121-140, pyramid_geometry.py:156-170).  The reference takes the products with torch.dot on a
+// contiguous and a strided operand; its BLAS evaluates fma(a2, b2, a0*b0 + a1*b1) for three elements.
+template <int DIM>
+__device__ __forceinline__ bool inside(const TetParams &g, const double (&x)[DIM]) {
+    static_assert(DIM == 3, "tetrahedron is 3-D only");
+    bool in_any = false;
+    for (int t = 0; t < g.n_tets; ++t) {
+        bool outside = false;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const double a0 = x[0] - g.pos[t][p][0], a1 = x[1] - g.pos[t][p][1], a2 = x[2] - g.pos[t][p][2];
+            const double d = __fma_rn(a2, g.nrm[t][2][p], a0 * g.nrm[t][0][p] + a1 * g.nrm[t][1][p]);
+            outside |= d < 0.0;
+        }
+        in_any |= !outside;
+    }
+    return in_any;
 }
 
 template <int DIM, typename G>
@@ -340,6 +393,63 @@ int s3_mask_polygon(const double *d_center, const int32_t *d_level, const int32_
     mask_kernel<2, PolyParams><<<grid_for(n, 256), 256, 0, as_stream(stream)>>>(d_center, d_level, d_cells, first, n,
                                                                                0.5 * width, g, refine_mode, keep_inside,
                                                                                d_invalid);
+    S3_LAUNCH_CHECK();
+    return S3_OK;
+}
+
+int s3_mask_triangle(const double *d_center, const int32_t *d_level, const int32_t *d_cells, int64_t first, int64_t n,
+                     double width, const double *h_points, int refine_mode, int keep_inside, uint8_t *d_invalid,
+                     s3_stream stream) {
+    if (int rc = check_mask_args(d_center, d_level, first, n, 2, d_invalid, "s3_mask_triangle")) return rc;
+    S3_REQUIRE(h_points != nullptr, "s3_mask_triangle: null points");
+    if (n == 0) return S3_OK;
+    TriParams g{};
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 2; ++j) g.p[i][j] = h_points[2 * i + j];
+    mask_kernel<2, TriParams><<<grid_for(n, 256), 256, 0, as_stream(stream)>>>(d_center, d_level, d_cells, first, n,
+                                                                              0.5 * width, g, refine_mode, keep_inside,
+                                                                              d_invalid);
+    S3_LAUNCH_CHECK();
+    return S3_OK;
+}
+
+int s3_mask_prism(const double *d_center, const int32_t *d_level, const int32_t *d_cells, int64_t first, int64_t n,
+                  double width, const double *h_origin, const double *h_axis, double norm, const int32_t *h_dims,
+                  const double *h_triangle, int refine_mode, int keep_inside, uint8_t *d_invalid, s3_stream stream) {
+    if (int rc = check_mask_args(d_center, d_level, first, n, 3, d_invalid, "s3_mask_prism")) return rc;
+    S3_REQUIRE(h_origin && h_axis && h_dims && h_triangle && norm > 0, "s3_mask_prism: bad axis");
+    S3_REQUIRE(h_dims[0] >= 0 && h_dims[0] < 3 && h_dims[1] >= 0 && h_dims[1] < 3 && h_dims[0] != h_dims[1],
+               "s3_mask_prism: the triangle plane must be two different coordinate directions");
+    if (n == 0) return S3_OK;
+    PrismParams g{};
+    for (int j = 0; j < 3; ++j) { g.origin[j] = h_origin[j]; g.axis[j] = h_axis[j]; }
+    g.norm = norm; g.dims[0] = h_dims[0]; g.dims[1] = h_dims[1];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 2; ++j) g.tri.p[i][j] = h_triangle[2 * i + j];
+    mask_kernel<3, PrismParams><<<grid_for(n, 256), 256, 0, as_stream(stream)>>>(d_center, d_level, d_cells, first, n,
+                                                                                0.5 * width, g, refine_mode,
+                                                                                keep_inside, d_invalid);
+    S3_LAUNCH_CHECK();
+    return S3_OK;
+}
+
+int s3_mask_tetrahedra(const double *d_center, const int32_t *d_level, const int32_t *d_cells, int64_t first, int64_t n,
+                       double width, const double *h_positions, const double *h_normals, int n_tets, int refine_mode,
+                       int keep_inside, uint8_t *d_invalid, s3_stream stream) {
+    if (int rc = check_mask_args(d_center, d_level, first, n, 3, d_invalid, "s3_mask_tetrahedra")) return rc;
+    S3_REQUIRE(h_positions && h_normals && (n_tets == 1 || n_tets == 2), "s3_mask_tetrahedra: one or two tetrahedra");
+    if (n == 0) return S3_OK;
+    TetParams g{};
+    g.n_tets = n_tets;
+    for (int t = 0; t < n_tets; ++t) {
+        for (int p = 0; p < 4; ++p)
+            for (int j = 0; j < 3; ++j) g.pos[t][p][j] = h_positions[(t * 4 + p) * 3 + j];
+        for (int j = 0; j < 3; ++j)
+            for (int p = 0; p < 4; ++p) g.nrm[t][j][p] = h_normals[(t * 3 + j) * 4 + p];
+    }
+    mask_kernel<3, TetParams><<<grid_for(n, 256), 256, 0, as_stream(stream)>>>(d_center, d_level, d_cells, first, n,
+                                                                              0.5 * width, g, refine_mode, keep_inside,
+                                                                              d_invalid);
     S3_LAUNCH_CHECK();
     return S3_OK;
 }

@@ -64,7 +64,8 @@ class GeometryObject(ABC):
     @abstractmethod
     def kernel_spec(self) -> tuple:
         """``(kind, params...)`` consumed by the device mask kernels: ``("box", lo, hi)``, ``("sphere", pos, r)``,
-        ``("cylinder", p0, axis, norm, r0, r1, is_cone)`` or ``("polygon", xy[nv,2])``"""
+        ``("cylinder", p0, axis, norm, r0, r1, is_cone)``, ``("polygon", xy[nv,2])``, ``("triangle", xy[3,2])``,
+        ``("prism", origin, axis, norm, dims, xy[3,2])`` or ``("tetrahedra", pos[n,4,3], normals[n,3,4])``"""
 
     @abstractmethod
     def _check_geometry(self) -> None:

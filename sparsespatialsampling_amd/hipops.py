@@ -263,6 +263,36 @@ def mask_polygon(center, level, cells, first, n, width, poly_dev, refine_mode, k
                                          _ptr(invalid), _stream()), "s3_mask_polygon")
 
 
+def mask_triangle(center, level, cells, first, n, width, points, refine_mode, keep_inside, invalid):
+    pts = _host_f64(points, 6)
+    check(_lib.hip_lib().s3_mask_triangle(_ptr(center), _ptr(level), _ptr(cells), int(first), int(n), float(width),
+                                          pts.ctypes.data_as(C.c_void_p), int(refine_mode), int(keep_inside),
+                                          _ptr(invalid), _stream()), "s3_mask_triangle")
+
+
+def mask_prism(center, level, cells, first, n, width, origin, axis, norm, dims, triangle, refine_mode, keep_inside,
+               invalid):
+    origin, axis, tri = _host_f64(origin), _host_f64(axis), _host_f64(triangle, 6)
+    dims = np.ascontiguousarray(dims, dtype=np.int32)
+    check(_lib.hip_lib().s3_mask_prism(_ptr(center), _ptr(level), _ptr(cells), int(first), int(n), float(width),
+                                       origin.ctypes.data_as(C.c_void_p), axis.ctypes.data_as(C.c_void_p), float(norm),
+                                       dims.ctypes.data_as(C.c_void_p), tri.ctypes.data_as(C.c_void_p),
+                                       int(refine_mode), int(keep_inside), _ptr(invalid), _stream()), "s3_mask_prism")
+
+
+def mask_tetrahedra(center, level, cells, first, n, width, positions, normals, refine_mode, keep_inside, invalid):
+    """positions [n_tets, 4, 3], normals [n_tets, 3, 4] (inward; column p belongs to point p)"""
+    pos = np.ascontiguousarray(positions, dtype=np.float64)
+    nrm = np.ascontiguousarray(normals, dtype=np.float64)
+    n_tets = int(pos.shape[0])
+    if pos.shape != (n_tets, 4, 3) or nrm.shape != (n_tets, 3, 4):
+        raise ValueError("mask_tetrahedra: positions [n_tets,4,3] and normals [n_tets,3,4] expected")
+    check(_lib.hip_lib().s3_mask_tetrahedra(_ptr(center), _ptr(level), _ptr(cells), int(first), int(n), float(width),
+                                            pos.ctypes.data_as(C.c_void_p), nrm.ctypes.data_as(C.c_void_p), n_tets,
+                                            int(refine_mode), int(keep_inside), _ptr(invalid), _stream()),
+          "s3_mask_tetrahedra")
+
+
 def commit_batch(leaf, gain, parents, first, n_new, invalid):
     n_par = int(parents.numel()) if parents is not None else 0
     check(_lib.hip_lib().s3_commit_batch(_ptr(leaf), _ptr(gain), _ptr(parents), n_par, int(first), int(n_new),

@@ -110,6 +110,13 @@ class HipTreeBackend:
                     self._poly_cache[key] = hipops.to_device(np.ascontiguousarray(spec[1], dtype=np.float64))
                 hipops.mask_polygon(self.center, self.level, d_cells, first, n, w, self._poly_cache[key], refine_mode,
                                     ki, invalid)
+            elif spec[0] == "triangle":
+                hipops.mask_triangle(self.center, self.level, d_cells, first, n, w, spec[1], refine_mode, ki, invalid)
+            elif spec[0] == "prism":
+                hipops.mask_prism(self.center, self.level, d_cells, first, n, w, *spec[1:], refine_mode, ki, invalid)
+            elif spec[0] == "tetrahedra":
+                hipops.mask_tetrahedra(self.center, self.level, d_cells, first, n, w, spec[1], spec[2], refine_mode, ki,
+                                       invalid)
             else:
                 raise NotImplementedError(f"geometry kind {spec[0]!r} has no device kernel")
         self._last_invalid = invalid

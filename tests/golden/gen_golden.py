@@ -12,6 +12,7 @@ Fixture groups:
     knncache_*    ExportData._build_knn_cache idx / weights      (reference export.py:403-444)
     predict_*     KNeighborsRegressor(weights="distance").predict as used at s_cube.py:161-163,224,328,372
     masks         geometry check_cell truth tables                (geometry/*.py)
+    masks_polytopes   the same for triangle / prism / tetrahedron / pyramid
     uniform_*     _refine_uniform() neighbour + node tables       (s_cube.py:508-561, 904-1536)
     refine_*      full SamplingTree.refine() outputs + traces     (s_cube.py:563-667)
 
@@ -29,7 +30,8 @@ import ref_stubs  # noqa: E402,F401  (installs shims + sys.path; must run in spa
 import numpy as np  # noqa: E402
 import torch as pt  # noqa: E402
 
-from inputs import REFINE_CASES, c1_cylinder2d, cloud, mask_cells, refine_inputs, sha, wake_metric  # noqa: E402
+from inputs import (POLYTOPES, REFINE_CASES, c1_cylinder2d, cloud, mask_cells, polytope, polytope_cells,  # noqa: E402
+                    refine_inputs, sha, wake_metric)
 
 
 def save(name, **kw):
@@ -131,6 +133,28 @@ def gen_masks():
     save("masks", **out)
 
 
+def gen_masks_polytopes():
+    """check_cell truth tables of TriangleGeometry / PrismGeometry3D / TetrahedronGeometry3D / PyramidGeometry3D"""
+    from sparseSpatialSampling import geometry
+    rng = np.random.default_rng(11)
+    out = {}
+    dirs = {2: np.array([[-1, -1], [-1, 1], [1, 1], [1, -1]], dtype=np.float64),
+            3: np.array([[-1, -1, 1], [-1, 1, 1], [1, 1, 1], [1, -1, 1],
+                         [-1, -1, -1], [-1, 1, -1], [1, 1, -1], [1, -1, -1]], dtype=np.float64)}
+    for d in (2, 3):
+        c, h = polytope_cells(d, rng)
+        out[f"c{d}"], out[f"h{d}"] = c, h
+    for key in POLYTOPES:
+        d = 2 if key.startswith("tri") else 3
+        nodes = out[f"c{d}"][:, None, :] + dirs[d][None] * out[f"h{d}"][:, None, None]
+        for ki in (True, False):
+            g = polytope(geometry, key, ki)
+            for rm in (False, True):
+                out[f"{key}_{int(ki)}_r{int(rm)}"] = np.array([g.check_cell(pt.from_numpy(nodes[i]), rm)
+                                                               for i in range(len(nodes))])
+    save("masks_polytopes", **out)
+
+
 def _tree_arrays(tree):
     """Dump the per-cell state of a reference SamplingTree into arrays (None -> -1)."""
     cells = tree._cells
@@ -207,7 +231,7 @@ def gen_c1():
 
 
 if __name__ == "__main__":
-    groups = sys.argv[1:] or ["interp", "knncache", "predict", "masks", "uniform", "refine", "c1"]
+    groups = sys.argv[1:] or ["interp", "knncache", "predict", "masks", "masks_polytopes", "uniform", "refine", "c1"]
     pt.manual_seed(0)
     for g in groups:
         if g.startswith("refine_"):

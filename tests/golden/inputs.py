@@ -50,6 +50,12 @@ REFINE_CASES = {
     # 3-D, n_cells_max stopping, cone body (two radii) refined to a fixed level
     "refine_3d_ncells_cone": dict(d=3, seed=76, n=12000, lo=[0.0, 0.0, 0.0], hi=[2.0, 1.0, 1.0], body="cone",
                                   kw=dict(uniform_level=3, n_cells=3000, n_cells_iter_start=20, n_cells_iter_end=5)),
+    # 2-D: triangular body refined to a fixed level
+    "refine_2d_triangle": dict(d=2, seed=77, n=5000, lo=[0.0, 0.0], hi=[2.2, 0.41], body="triangle",
+                               kw=dict(uniform_level=3, min_metric=0.5)),
+    # 3-D: prism + tetrahedron + (refined) pyramid bodies in one domain
+    "refine_3d_polytopes": dict(d=3, seed=78, n=9000, lo=[0.0, 0.0, 0.0], hi=[1.0, 1.0, 1.0], body="polytopes",
+                                kw=dict(uniform_level=2, min_metric=0.4)),
 }
 
 
@@ -58,7 +64,21 @@ def refine_inputs(name, geometry):
     case = REFINE_CASES[name]
     d = case["d"]
     x = cloud(case["seed"], case["n"], case["lo"], case["hi"])
-    if d == 2:
+    if case["body"] == "triangle":
+        centre = [0.4, 0.2]
+        body = geometry.TriangleGeometry("wedge", False, [(0.3, 0.1), (0.6, 0.2), (0.3, 0.3)], refine=True,
+                                         min_refinement_level=6)
+        y = wake_metric(x, centre)
+    elif case["body"] == "polytopes":
+        centre = [0.4, 0.5, 0.5]
+        body = [geometry.PrismGeometry3D("prism", False, [[(0.1, 0.1, 0.1), (0.3, 0.1, 0.1), (0.1, 0.35, 0.1)],
+                                                          [(0.1, 0.1, 0.4), (0.3, 0.1, 0.4), (0.1, 0.35, 0.4)]]),
+                geometry.TetrahedronGeometry3D("tet", False, [[0.6, 0.1, 0.1], [0.95, 0.15, 0.1], [0.7, 0.45, 0.15],
+                                                              [0.75, 0.2, 0.5]]),
+                geometry.PyramidGeometry3D("pyramid", False, [[0.3, 0.55, 0.2], [0.7, 0.55, 0.2], [0.7, 0.9, 0.2],
+                                                              [0.3, 0.9, 0.2], [0.5, 0.7, 0.7]], refine=True)]
+        y = wake_metric(x, centre, decay=4.0)
+    elif d == 2:
         centre, rad = [0.2, 0.2], 0.05
         keep = ((x - np.asarray(centre)) ** 2).sum(1) > rad ** 2
         x = np.ascontiguousarray(x[keep])
@@ -84,7 +104,7 @@ def refine_inputs(name, geometry):
         x = np.ascontiguousarray(x[keep])
         body = geometry.CylinderGeometry3D("cylinder", False, [(0.8, 1.0, -1.0), (0.8, 1.0, 1.0)], rad, refine=True)
         y = wake_metric(x, centre, decay=2.5)
-    geos = [geometry.CubeGeometry("domain", True, case["lo"], case["hi"]), body]
+    geos = [geometry.CubeGeometry("domain", True, case["lo"], case["hi"])] + (body if isinstance(body, list) else [body])
     return x, y, geos, case["kw"]
 
 
@@ -93,6 +113,42 @@ def mask_cells(d, n, rng):
     c = rng.random((n, d)) * 2.0 - 0.5
     h = rng.random(n) * 0.4 + 0.01
     return c, h
+
+
+# flat-faced bodies of the ``masks_polytopes`` fixture: constructor arguments per class; "*_dyadic" bodies have corners on
+# the 1/8 lattice, so that lattice cells put nodes exactly on faces, edges and corners (ties of the sign tests)
+POLYTOPES = {
+    "tri_generic": ("TriangleGeometry", dict(points=[(0.1, 0.1), (0.9, 0.2), (0.4, 1.1)])),
+    "tri_dyadic": ("TriangleGeometry", dict(points=[(-0.25, -0.125), (0.25, 1.0), (1.5, -0.125)])),
+    "prism_generic": ("PrismGeometry3D", dict(positions=[[(0.1, 0.1, 0.2), (0.1, 0.9, 0.3), (0.1, 0.4, 1.0)],
+                                                         [(0.8, 0.1, 0.2), (0.8, 0.9, 0.3), (0.8, 0.4, 1.0)]])),
+    "prism_dyadic": ("PrismGeometry3D", dict(positions=[[(-0.25, -0.125, 0.0), (0.25, 1.0, 0.0), (1.5, -0.125, 0.0)],
+                                                        [(-0.25, -0.125, 0.75), (0.25, 1.0, 0.75), (1.5, -0.125, 0.75)]])),
+    "tet_generic": ("TetrahedronGeometry3D", dict(positions=[[-0.3, 0.1, -0.1], [1.1, -0.2, 0.0], [0.9, 1.2, 0.1],
+                                                             [0.4, 0.5, 1.3]])),
+    "tet_dyadic": ("TetrahedronGeometry3D", dict(positions=[[-0.5, -0.5, -0.5], [1.5, -0.5, -0.5], [-0.5, 1.5, -0.5],
+                                                            [-0.5, -0.5, 1.5]])),
+    "pyr_generic": ("PyramidGeometry3D", dict(nodes=[[0.0, 0.1, 0.05], [1.0, 0.0, 0.05], [1.1, 0.9, 0.05],
+                                                     [0.1, 1.0, 0.05], [0.5, 0.5, 1.2]])),
+    "pyr_dyadic": ("PyramidGeometry3D", dict(nodes=[[0.375, 0.375, 1.25], [-0.25, -0.25, -0.25], [1.0, -0.25, -0.25],
+                                                    [1.0, 1.0, -0.25], [-0.25, 1.0, -0.25]])),
+}
+
+
+def polytope(geometry, key, keep_inside):
+    """instance of POLYTOPES[key] from the given geometry module (reference or this package); arguments are copied
+    because the constructors convert list entries in place"""
+    import copy
+    cls, kw = POLYTOPES[key]
+    return getattr(geometry, cls)("g", keep_inside, **copy.deepcopy(kw))
+
+
+def polytope_cells(d, rng):
+    """300 random cells + 300 cells on the 1/8 lattice (half width 1/8 or 1/4): centre + half width per cell"""
+    c, h = mask_cells(d, 300, rng)
+    cl = rng.integers(-4, 13, size=(300, d)) / 8.0
+    hl = np.where(rng.random(300) < 0.5, 0.125, 0.25)
+    return np.concatenate([c, cl]), np.concatenate([h, hl])
 
 
 def c1_cylinder2d(geometry):

@@ -71,6 +71,12 @@ class OracleTreeBackend:
                 inv |= _mask_cylinder_spec(c, lv, self.width, spec, refine_mode, ki)
             elif spec[0] == "polygon":
                 inv |= orc.mask_polygon(c, lv, self.width, spec[1], refine_mode, ki)
+            elif spec[0] == "triangle":
+                inv |= orc.mask_triangle(c, lv, self.width, spec[1], refine_mode, ki)
+            elif spec[0] == "prism":
+                inv |= orc.mask_prism(c, lv, self.width, *spec[1:], refine_mode, ki)
+            elif spec[0] == "tetrahedra":
+                inv |= orc.mask_tetrahedra(c, lv, self.width, spec[1], spec[2], refine_mode, ki)
             else:
                 raise NotImplementedError(spec[0])
         self._last_invalid = inv

@@ -262,6 +262,30 @@ def test_masks_golden(ops):
             assert np.array_equal(run(ops.mask_polygon, c2, h2, poly, rm, ki), z["poly2" + sfx])
 
 
+@pytest.mark.parametrize("key", ["tri_generic", "tri_dyadic", "prism_generic", "prism_dyadic", "tet_generic", "tet_dyadic",
+                                 "pyr_generic", "pyr_dyadic"])
+def test_masks_polytopes_golden(ops, key):
+    """triangle / prism / tetrahedron / pyramid kernels against the real reference's check_cell, incl. lattice cells with
+    nodes exactly on faces, edges and corners of the dyadic bodies"""
+    from inputs import polytope, polytope_cells
+    from sparsespatialsampling_amd import geometry
+    z = load("masks_polytopes")
+    d = 2 if key.startswith("tri") else 3
+    c, h = z[f"c{d}"], z[f"h{d}"]
+    center = dev(c)
+    level = pt.zeros(len(c), dtype=pt.int32, device="cuda")
+    fn = {"triangle": ops.mask_triangle, "prism": ops.mask_prism, "tetrahedra": ops.mask_tetrahedra}
+    for ki in (1, 0):
+        spec = polytope(geometry, key, bool(ki)).kernel_spec()
+        for rm in (0, 1):
+            got = np.zeros(len(c), dtype=bool)
+            for i in range(len(c)):                      # per-cell width: one tiny launch per cell
+                inv = pt.zeros(1, dtype=pt.uint8, device="cuda")
+                fn[spec[0]](center, level, None, i, 1, 2.0 * h[i], *spec[1:], rm, ki, inv)
+                got[i] = bool(inv.item())
+            assert np.array_equal(got, z[f"{key}_{ki}_r{rm}"]), (key, ki, rm)
+
+
 # ---- selection + reduction (a6, a8) -----------------------------------------------------------------------------
 @pytest.mark.parametrize("n,n_top,ties", [(50_000, 37, False), (50_000, 5000, True), (300, 1000, False), (200_000, 1, True),
                                           (70_000, 69_000, True)])

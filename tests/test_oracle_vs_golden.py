@@ -8,9 +8,10 @@ import types
 
 import numpy as np
 import pytest
+import torch as pt
 
 from oracle import s3_oracle as orc
-from inputs import mask_cells, refine_inputs, sha
+from inputs import POLYTOPES, mask_cells, polytope, polytope_cells, refine_inputs, sha
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -88,6 +89,38 @@ def test_masks():
                                   z["cone3" + sfx])
             assert np.array_equal(run(orc.mask_polygon, c2, h2, z["poly"], rm, ki), z["poly2" + sfx])
     assert 0 < z["cyl3_0_r0"].sum() < 400 and 0 < z["poly2_1_r1"].sum() < 400     # non-trivial truth tables
+
+
+@pytest.mark.parametrize("key", sorted(POLYTOPES))
+def test_masks_polytopes(key):
+    """triangle / prism / tetrahedron / pyramid: (i) the package's geometry classes give the reference's verdict per cell
+    (host check_cell), (ii) the oracle predicate fed with their kernel_spec() does too -- incl. lattice cells whose nodes
+    lie exactly on faces, edges and corners of the dyadic bodies"""
+    from sparsespatialsampling_amd import geometry
+    z = load("masks_polytopes")
+    d = 2 if key.startswith("tri") else 3
+    c, h = polytope_cells(2, np.random.default_rng(11)) if d == 2 else _second(polytope_cells, 11)
+    assert np.array_equal(c, z[f"c{d}"]) and np.array_equal(h, z[f"h{d}"])
+    nodes = c[:, None, :] + orc.DIRS[d][None] * h[:, None, None]
+    lv = np.zeros(1, dtype=np.int32)
+    for ki in (True, False):
+        g = polytope(geometry, key, ki)
+        spec = g.kernel_spec()
+        fn = {"triangle": orc.mask_triangle, "prism": orc.mask_prism, "tetrahedra": orc.mask_tetrahedra}[spec[0]]
+        for rm in (False, True):
+            want = z[f"{key}_{int(ki)}_r{int(rm)}"]
+            host = np.array([g.check_cell(pt.from_numpy(nodes[i]), rm) for i in range(len(nodes))])
+            assert np.array_equal(host, want), (key, ki, rm, "host class")
+            got = np.array([fn(c[i:i + 1], lv, 2.0 * h[i], *spec[1:], rm, ki)[0] for i in range(len(c))])
+            assert np.array_equal(got, want), (key, ki, rm, "oracle")
+    assert 0 < z[f"{key}_0_r0"].sum() < len(c) and 0 < z[f"{key}_1_r1"].sum() < len(c)       # non-trivial tables
+
+
+def _second(fn, seed):
+    """the 3-D cell stream of the fixture is drawn after the 2-D one from the same generator"""
+    rng = np.random.default_rng(seed)
+    fn(2, rng)
+    return fn(3, rng)
 
 
 @pytest.mark.parametrize("name,k", [("refine_2d_metric", 8), ("refine_2d_delta", 8), ("refine_3d_metric", 26),

@@ -131,6 +131,61 @@ def test_geometry_truth_tables(keep_inside, where):
         assert g.check_cell(cell(CELLS_3D, where), refine_geometry=True) is refine, g.type
 
 
+# the flat-faced bodies of the reference's tests/test_{triangle,prism,tetrahedron,pyramid}_geometry.py: the partially
+# overlapping cell is neither removed in body mode nor in domain mode
+POLY_TRUTH = {(False, "inside"): True, (False, "outside"): False, (False, "partially"): False,
+              (True, "inside"): False, (True, "outside"): True, (True, "partially"): False}
+
+
+@pytest.mark.parametrize("keep_inside", [False, True])
+@pytest.mark.parametrize("where", ["inside", "outside", "partially"])
+def test_polytope_truth_tables(keep_inside, where):
+    tri = geometry.TriangleGeometry("triangle", keep_inside, [(-1, -0.5), (0.25, 4), (1.5, -0.5)])
+    prism = geometry.PrismGeometry3D("prism", keep_inside, [[(-1, -0.5, -0.5), (0.25, 4, -0.5), (1.5, -0.5, -0.5)],
+                                                            [(-1, -0.5, 1.25), (0.25, 4, 1.25), (1.5, -0.5, 1.25)]])
+    tet = geometry.TetrahedronGeometry3D("tetra", keep_inside, [[-1.5, 0.5, -0.1], [1.5, -1.5, -0.1], [1.5, 2.5, -0.1],
+                                                                [0.5, 0.5, 3]])
+    pyr = geometry.PyramidGeometry3D("pyramid", keep_inside, [[-1, -1, -0.25], [2, -1, -0.25], [2, 2, -0.25],
+                                                              [-1, 2, -0.25], [0.5, 0.5, 3]])
+    assert tri.check_cell(cell(CELLS_2D, where)) is POLY_TRUTH[(keep_inside, where)]
+    for g in (prism, tet, pyr):
+        assert g.check_cell(cell(CELLS_3D, where)) is POLY_TRUTH[(keep_inside, where)], g.type
+    assert (tri.type, prism.type, tet.type, pyr.type) == ("triangle", "prism", "tetrahedron", "pyramid")
+
+
+def test_polytope_argument_checks():
+    T, P, H, Y = (geometry.TriangleGeometry, geometry.PrismGeometry3D, geometry.TetrahedronGeometry3D,
+                  geometry.PyramidGeometry3D)
+    T("triangle", False, [(0, 0), (1, 0), (0, 1)])
+    assert T("triangle", False, [pt.tensor([0.0, 0.0]), pt.tensor([1.0, 0.0]), pt.tensor([0.0, 1.0])]).type == "triangle"
+    with pytest.raises(AssertionError, match="Expected 3 points"):
+        T("triangle", False, [(0, 0), (1, 0)])
+    with pytest.raises(AssertionError, match="Expected 3 points"):
+        T("triangle", False, [(0, 0), (1, 0), (0, 1), (1, 1)])
+    with pytest.raises(AssertionError, match="have to contain exactly 2 entries"):
+        T("triangle", False, [(0, 0), (1, 1, 5), (0, 1)])
+    with pytest.raises(AssertionError, match="area of the triangle has to be larger than zero"):
+        T("triangle", False, [(0, 0), (1, 1), (2, 2)])
+    with pytest.raises(AssertionError):
+        P("bad_prism", True, positions=[[[0, 0, 0], [1, 0, 0], [0, 1, 0]]])
+    with pytest.raises(AssertionError):
+        P("bad_prism2", True, positions=[[[0, 0, 0], [1, 0, 0]], [[0, 0, 1], [1, 0, 1], [0, 1, 1]]])
+    for bad in ([], [[0, 0, 0], [1, 0, 0], [0, 1, 0]], [[0, 0, 0], [1, 0, 0], [0, 1, 0], [0.5, 0.5]]):
+        with pytest.raises(AssertionError):
+            H("bad_tetra", True, positions=bad)
+    for bad in ([], [[0, 0, 0], [1, 0, 0], [0, 1, 0], [0.5, 0.5, 1]],
+                [[0, 0, 0], [1, 0, 0], [0, 1, 0], [0.5, 0.5, 1], [0.5, 0.5]]):
+        with pytest.raises(AssertionError):
+            Y("bad_pyramid", True, nodes=bad)
+    # derived attributes follow the reference's definitions
+    t = T("t", True, [(0, 0), (2, 0), (0, 1)])
+    assert t.main_width == 2.0 and pt.allclose(t.center, pt.tensor([2 / 3, 1 / 3], dtype=pt.float64))
+    p = P("p", True, [[(0, 0, 0), (2, 0, 0), (0, 1, 0)], [(0, 0, 3), (2, 0, 3), (0, 1, 3)]])
+    assert p.main_width == 3.0 and pt.allclose(p.center, pt.tensor([2 / 3, 1 / 3, 1.5], dtype=pt.float64))
+    y = Y("y", True, [[-1, -1, -0.25], [2, -1, -0.25], [2, 2, -0.25], [-1, 2, -0.25], [0.5, 0.5, 3]])
+    assert y._apex_idx == 4 and y.main_width == 3.25
+
+
 def test_geometry_properties_and_argument_checks():
     c = geometry.CubeGeometry("domain", True, [0, 0], [2.2, 0.41])
     assert c.main_width == 2.2 and pt.allclose(c.center, pt.tensor([1.1, 0.205])) and c.type == "cube"

@@ -214,3 +214,54 @@ def test_c1_cylinder2d_full_size_matches_reference():
     assert np.array_equal(np.array(tree._n_cells_log), z["n_cells_log"])
     np.testing.assert_allclose(np.array(tree._metric), z["metric_hist"], rtol=1e-12)
     assert tree.data_final_mesh["iterations"] == int(z["iterations"])
+
+
+def test_full_size_c3_properties():
+    """BASELINE's bench configuration at full size (4 991 774 points -> 461 130 cells, k = 26), checked through
+    size-independent properties: grid geometry (centres = mean of the cell's vertices, edge length = width / 2^level,
+    unique leaves, body cells removed, surface resolved), stopping rule, and -- for the planned interpolation on the real
+    neighbour table -- reproduction of a constant field, linearity in the data and agreement with the direct kernel"""
+    import bench
+    import sparsespatialsampling_amd.s_cube as s_cube
+    from sparsespatialsampling_amd import geometry, hipops
+    cfg = dict(bench.WORKLOADS["cylinder3D_Re3900"])
+    x, metric = bench.synthetic_cylinder3d(cfg)
+    geos = [geometry.CubeGeometry("domain", True, cfg["lo"], [float(v) for v in cfg["hi"]]),
+            geometry.CylinderGeometry3D("cylinder", False, [(0.8, 1.0, -1.0), (0.8, 1.0, 1.0)], 0.05, refine=True)]
+    tree = s_cube.SamplingTree(pt.from_numpy(x), pt.from_numpy(metric), geos, uniform_level=cfg["uniform_levels"],
+                               min_metric=cfg["min_metric"])
+    tree.refine()
+    centers, nodes = tree.all_centers.numpy(), tree.all_nodes.numpy()
+    faces, levels = tree.face_ids.numpy().astype(np.int64), tree.all_levels.numpy().reshape(-1)
+    nc = len(centers)
+    assert nc == 461_130 and faces.shape == (nc, 8) and tree.face_ids.dtype == pt.int32
+    corner = nodes[faces]                                                   # [nc, 8, 3]
+    assert np.abs(corner.mean(1) - centers).max() <= 1e-15 * 4
+    edge = corner.max(1) - corner.min(1)
+    assert np.allclose(edge, (float(tree._width) / 2.0 ** levels)[:, None], rtol=1e-12, atol=0)
+    assert len(np.unique(centers, axis=0)) == nc
+    # no leaf lies completely inside the cylinder, and the cells cut by its surface sit on the finest level found there
+    r = np.hypot(corner[..., 0] - 0.8, corner[..., 1] - 1.0)
+    inside = r <= 0.05
+    assert not inside.all(1).any()
+    cut = inside.any(1) & ~inside.all(1)
+    assert cut.any() and len(np.unique(levels[cut])) == 1 and levels[cut][0] == levels.max()
+    assert tree._metric[-1] >= cfg["min_metric"] > tree._metric[-2]        # stopped by the metric, not earlier
+
+    k, t = 26, 64
+    knn = hipops.KnnIndex(x)
+    idx, dist = knn.query(centers, k)
+    knn.close()
+    w = hipops.idw_weights(dist)
+    assert pt.allclose(w.sum(1), pt.ones(nc, dtype=pt.float64, device="cuda"), rtol=1e-14, atol=0)
+    plan = hipops.InterpPlan(idx, len(x), centers)
+    a, b = hipops.padded_rows(len(x), t, pt.float32, "cuda"), hipops.padded_rows(len(x), t, pt.float32, "cuda")
+    a.normal_(), b.normal_()
+    const = hipops.padded_rows(len(x), t, pt.float32, "cuda")
+    const.fill_(-2.5)
+    assert pt.allclose(plan.interp(w, const), pt.full((nc, t), -2.5, dtype=pt.float64, device="cuda"), rtol=1e-13, atol=0)
+    fa, fb = plan.interp(w, a), plan.interp(w, b)
+    both = hipops.padded_rows(len(x), t, pt.float64, "cuda")
+    both.copy_(a.double() + 2 * b.double())
+    assert pt.allclose(plan.interp(w, both), fa + 2 * fb, rtol=1e-12, atol=1e-12)
+    assert pt.equal(fa, hipops.interp(w, idx, a.contiguous()).reshape(nc, t))        # same arithmetic as the direct kernel

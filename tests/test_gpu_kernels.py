@@ -96,7 +96,7 @@ def test_interp_empty_and_errors(ops):
 @pytest.mark.parametrize("d,k,ncomp,t,dtype", [(3, 26, 1, 1000, np.float32), (3, 26, 1, 36, np.float32), (2, 8, 3, 28, np.float32),
                                                (3, 26, 1, 50, np.float64), (2, 5, 1, 64, np.float32), (3, 40, 1, 8, np.float32)])
 def test_interp_planned_vs_oracle(ops, orc, d, k, ncomp, t, dtype):
-    """real neighbour tables (spatially coherent -> shared rows), Morton-ordered tiles, ragged last chunk"""
+    """real neighbour tables (spatially coherent -> shared rows), tiles cut from the Hilbert curve, ragged last chunk"""
     rng = np.random.default_rng(100 * d + k + t)
     x = rng.random((30000, d))
     centers = rng.random((4111, d))

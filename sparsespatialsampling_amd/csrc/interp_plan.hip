@@ -304,10 +304,19 @@ int s3_interp_plan_create(const int32_t *d_idx, int64_t nc, int k, int64_t n_src
         const double scale = ext > 0 ? ((double)((1u << bits) - 1) / ext) : 0.0;
         std::vector<uint64_t> key(nc), key2(nc);
         std::vector<int32_t> perm2(nc);
-        for (int64_t c = 0; c < nc; ++c) {
-            uint32_t q[3] = {0, 0, 0};
-            for (int j = 0; j < dim; ++j) q[j] = (uint32_t)((ctr[c * dim + j] - lo[j]) * scale);
-            key[c] = hilbert_key(q, dim, bits);
+        {
+            const int kt = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)std::thread::hardware_concurrency(), 32, nc / 16384 + 1}));
+            auto keys = [&](int t) {
+                for (int64_t c = nc * t / kt; c < nc * (t + 1) / kt; ++c) {
+                    uint32_t q[3] = {0, 0, 0};
+                    for (int j = 0; j < dim; ++j) q[j] = (uint32_t)((ctr[c * dim + j] - lo[j]) * scale);
+                    key[c] = hilbert_key(q, dim, bits);
+                }
+            };
+            std::vector<std::thread> workers;
+            for (int t = 1; t < kt; ++t) workers.emplace_back(keys, t);
+            keys(0);
+            for (auto &w : workers) w.join();
         }
         for (int pass = 0; pass < 3; ++pass) {
             const int shift = 16 * pass;

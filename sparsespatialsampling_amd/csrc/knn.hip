@@ -665,11 +665,12 @@ int s3_knn_create(const double *d_pts, int64_t n, int dim, double target_occupan
     double *d_partial = nullptr;
     S3_HIP_CHECK(hipMalloc(&d_partial, sizeof(double) * nb * 6));
     bbox_kernel<<<nb, 256, 0, st>>>(d_pts, n, dim, d_partial);
-    S3_LAUNCH_CHECK();
     std::vector<double> part(nb * 6);
-    S3_HIP_CHECK(hipMemcpyAsync(part.data(), d_partial, sizeof(double) * nb * 6, hipMemcpyDeviceToHost, st));
-    S3_HIP_CHECK(hipStreamSynchronize(st));
-    S3_HIP_CHECK(hipFree(d_partial));
+    hipError_t e_bbox = hipGetLastError();
+    if (e_bbox == hipSuccess) e_bbox = hipMemcpyAsync(part.data(), d_partial, sizeof(double) * nb * 6, hipMemcpyDeviceToHost, st);
+    if (e_bbox == hipSuccess) e_bbox = hipStreamSynchronize(st);
+    (void)hipFree(d_partial);
+    S3_HIP_CHECK(e_bbox);
     double lo[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, hi[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
     for (int b = 0; b < nb; ++b)
         for (int j = 0; j < dim; ++j) {

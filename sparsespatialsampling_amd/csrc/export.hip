@@ -150,10 +150,13 @@ template <typename T, int VEC>
 static int launch_interp(const double *w, const int32_t *idx, int64_t nc, int k, const void *data, int64_t row_len,
                          double *out, hipStream_t st) {
     const int64_t lv_count = row_len / VEC;
-    // tile height: enough outputs per workgroup to amortise the LDS staging, bounded by LDS (12 B per (cell, k))
+    // tile height: enough outputs per workgroup to amortise the LDS staging, bounded by 48 KiB of LDS (12 B per
+    // (cell, neighbour): a few workgroups stay resident per CU and the launch needs no opt-in to a larger LDS window)
     int64_t tc = (2048 + lv_count - 1) / lv_count;
-    if (tc < 1) tc = 1;
+    const int64_t tc_lds = (48 * 1024) / ((int64_t)k * (sizeof(double) + sizeof(int32_t)));
     if (tc > 256) tc = 256;
+    if (tc > tc_lds) tc = tc_lds;
+    if (tc < 1) tc = 1;
     if (tc > nc) tc = nc;
     const int64_t n_tiles = (nc + tc - 1) / tc;
     const int64_t tiles_per_xcd = (n_tiles + 7) / 8;

@@ -81,6 +81,20 @@ def test_interp_linearity_and_constant_full_size(ops):
     assert pt.allclose(lhs, rhs, rtol=1e-12, atol=1e-12)
 
 
+def test_interp_short_rows_many_neighbours(ops, orc):
+    """k = 64 with one-element rows: the tile height of the direct kernel is bounded by its LDS budget (a launch with
+    256 cells x 64 neighbours staged would not fit)"""
+    rng = np.random.default_rng(5)
+    n, nc, k = 5000, 3000, 64
+    w = rng.random((nc, k))
+    idx = rng.integers(0, n, (nc, k)).astype(np.int32)
+    for dtype in (np.float32, np.float64):
+        data = rng.standard_normal((n, 1, 1)).astype(dtype)
+        got = ops.interp(dev(w), dev(idx), dev(data)).cpu().numpy()
+        ref = orc.interp(w, idx, data)
+        assert np.abs(got - ref).max() <= 1e-13 * np.abs(ref).max()
+
+
 def test_interp_empty_and_errors(ops):
     from sparsespatialsampling_amd._lib import S3HipError
     w = pt.zeros((0, 8), dtype=pt.float64, device="cuda")

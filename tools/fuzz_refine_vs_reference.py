@@ -1,0 +1,151 @@
+"""dev helper (development container only, CPU): randomised differential test of SamplingTree.refine() -- this
+package's host logic with the oracle kernels -- against the REAL reference (imported read-only through
+tests/golden/ref_stubs.py) on small random configurations: dimension, cloud, stopping rule, cell ramp, 2:1 balance,
+bodies of every supported kind with / without geometry refinement.
+    python tools/fuzz_refine_vs_reference.py [seed] [cases]
+Must stay a file with a __main__ guard (the reference spawns a worker pool that re-imports it)."""
+import copy
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
+import ref_stubs  # noqa: E402,F401
+
+import numpy as np  # noqa: E402
+import torch as pt  # noqa: E402
+
+
+def bodies(rng, d):
+    """[(class name, kwargs)] for 0-2 bodies inside the unit domain"""
+    out = []
+    for _ in range(int(rng.integers(0, 3))):
+        refine = bool(rng.random() < 0.5)
+        extra = dict(refine=refine)
+        if refine and rng.random() < 0.5:
+            extra["min_refinement_level"] = int(rng.integers(3, 6))
+        c = rng.random(d) * 0.6 + 0.2
+        r = float(rng.random() * 0.15 + 0.05)
+        if d == 2:
+            kind = rng.choice(["sphere", "triangle", "cube"])
+            if kind == "sphere":
+                out.append(("SphereGeometry", dict(position=c.tolist(), radius=r, **extra)))
+            elif kind == "cube":
+                out.append(("CubeGeometry", dict(lower_bound=(c - r).tolist(), upper_bound=(c + r).tolist(), **extra)))
+            else:
+                p = [(c + r * np.array([np.cos(a), np.sin(a)])).tolist() for a in rng.random() * 6.28 + np.array([0, 2.1, 4.2])]
+                out.append(("TriangleGeometry", dict(points=[tuple(v) for v in p], **extra)))
+        else:
+            kind = rng.choice(["sphere", "cylinder", "cone", "cube", "prism", "tet", "pyramid"])
+            if kind == "sphere":
+                out.append(("SphereGeometry", dict(position=c.tolist(), radius=r, **extra)))
+            elif kind == "cube":
+                out.append(("CubeGeometry", dict(lower_bound=(c - r).tolist(), upper_bound=(c + r).tolist(), **extra)))
+            elif kind in ("cylinder", "cone"):
+                ax = rng.standard_normal(3); ax *= 0.3 / np.linalg.norm(ax)
+                rad = r if kind == "cylinder" else [r, r * 0.4]
+                out.append(("CylinderGeometry3D", dict(position=[tuple((c - ax).tolist()), tuple((c + ax).tolist())], radius=rad, **extra)))
+            elif kind == "prism":
+                a = int(rng.integers(0, 3))
+                dims = [j for j in range(3) if j != a]
+                tri = c[dims][None] + r * np.array([[-1.0, -0.8], [1.2, -0.5], [0.1, 1.1]])
+                lo, hi = [], []
+                for v in tri:
+                    p0 = np.zeros(3); p0[dims] = v; p0[a] = c[a] - r
+                    p1 = p0.copy(); p1[a] = c[a] + r
+                    lo.append(tuple(p0.tolist())); hi.append(tuple(p1.tolist()))
+                out.append(("PrismGeometry3D", dict(positions=[lo, hi], **extra)))
+            elif kind == "tet":
+                p = c[None] + r * 1.5 * np.array([[-1, -1, -1], [1.2, -0.7, -0.9], [0.1, 1.1, -0.8], [0.0, 0.1, 1.2]])
+                out.append(("TetrahedronGeometry3D", dict(positions=p.tolist(), **extra)))
+            else:
+                z0 = float(c[2] - r)
+                base = [[c[0] - r, c[1] - r, z0], [c[0] + r, c[1] - r, z0], [c[0] + r, c[1] + r, z0], [c[0] - r, c[1] + r, z0]]
+                out.append(("PyramidGeometry3D", dict(nodes=[[float(v) for v in b] for b in base] + [[float(c[0]), float(c[1]), float(c[2] + 1.5 * r)]], **extra)))
+    return out
+
+
+def build(geometry, d, spec):
+    geos = [geometry.CubeGeometry("domain", True, [0.0] * d, [1.0] * d)]
+    for i, (cls, kw) in enumerate(spec):
+        kw = copy.deepcopy(kw)
+        first = kw.pop(next(iter(kw)))                   # the positional geometry argument
+        geos.append(getattr(geometry, cls)(f"body{i}", False, first, **kw))
+    return geos
+
+
+def main():
+    import sparseSpatialSampling.geometry as ref_geometry
+    from sparseSpatialSampling.s_cube import SamplingTree as RefTree
+    from sparsespatialsampling_amd import geometry, s_cube
+    from oracle_backend import OracleTreeBackend
+    s_cube._make_backend = lambda v, t, k: OracleTreeBackend(v, t, k)
+    import logging
+    logging.disable(logging.CRITICAL)
+    rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+    n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+    bad = 0
+    for case in range(n_cases):
+        d = int(rng.integers(2, 4))
+        n = int(rng.integers(2100, 5000))                  # >= 2 cells per iteration: the reference cannot refine a single one
+        x = rng.random((n, d))
+        c0 = rng.random(d)
+        y = 0.05 + np.exp(-rng.uniform(2, 12) * np.linalg.norm(x - c0, axis=1)) * (1 + 0.3 * np.sin(9 * x[:, 0]))
+        kw = dict(uniform_level=int(rng.integers(1, 4 if d == 2 else 3)))
+        if rng.random() < 0.6:
+            kw["min_metric"] = float(rng.uniform(0.3, 0.9))
+        else:
+            kw["n_cells"] = int(rng.integers(100, 1500))
+        if rng.random() < 0.3:
+            kw["max_delta_level"] = True
+        if rng.random() < 0.3:
+            kw["n_cells_iter_start"], kw["n_cells_iter_end"] = int(rng.integers(2, 30)), int(rng.integers(2, 10))
+        if rng.random() < 0.3:
+            kw["relTol"] = float(10.0 ** rng.uniform(-4, -1.5))
+        if rng.random() < 0.3:
+            kw["reach_at_least"] = float(rng.uniform(0.3, 0.95))
+        if rng.random() < 0.2:
+            kw["pre_select"] = True
+        spec = bodies(rng, d)
+        tag = dict(case=case, d=d, n=n, kw=kw, bodies=[s[0] for s in spec])
+        try:
+            ref = RefTree(pt.from_numpy(x), pt.from_numpy(y), geometry_obj=build(ref_geometry, d, spec), n_jobs=2, **kw)
+            ref.refine()
+            ref_err = None
+        except Exception as e:                             # noqa: BLE001  (the reference raises on some corner cases)
+            ref_err = type(e)
+            if os.environ.get("FUZZ_TRACE"):
+                import traceback
+                traceback.print_exc()
+        try:
+            mine = s_cube.SamplingTree(pt.from_numpy(x), pt.from_numpy(y), geometry_obj=build(geometry, d, spec), **kw)
+            mine.refine()
+            my_err = None
+        except Exception as e:                             # noqa: BLE001
+            my_err = type(e)
+        if ref_err is IndexError and my_err is None:
+            # reference bug: _compute_cell_centers squeezes the cell axis away when exactly one cell is refined in an
+            # iteration and _refine_cells (s_cube.py:883) then fails; this build refines that cell
+            print("skip reference IndexError (single-cell iteration)", tag, flush=True)
+            continue
+        if ref_err or my_err:
+            same = ref_err is my_err
+            print(("ok  " if same else "BAD ") + f"both raise {ref_err} / {my_err}", tag, flush=True)
+            bad += not same
+            continue
+        ok = (np.array_equal(mine.all_centers.numpy(), ref.all_centers.numpy())
+              and np.array_equal(mine.all_levels.numpy(), ref.all_levels.numpy())
+              and np.array_equal(mine.face_ids.numpy(), ref.face_ids.numpy())
+              and np.array_equal(mine.all_nodes.numpy(), ref.all_nodes.numpy())
+              and list(mine._n_cells_log) == list(ref._n_cells_log)
+              and np.allclose(np.array(mine._metric), np.array(ref._metric), rtol=1e-12, atol=0))
+        print(("ok  " if ok else "BAD ") + f"{len(ref.all_centers)} cells, {ref.data_final_mesh['iterations']} it", tag, flush=True)
+        bad += not ok
+    print(f"{n_cases} cases, {bad} mismatches")
+    return bad
+
+
+if __name__ == "__main__":
+    sys.exit(1 if main() else 0)

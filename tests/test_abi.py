@@ -58,3 +58,25 @@ def test_product_never_imports_oracle():
 def test_topology_tables_selfcheck():
     from sparsespatialsampling_amd import _lib
     assert _lib.topo_lib().s3t_selfcheck(2) == 0 and _lib.topo_lib().s3t_selfcheck(3) == 0
+
+
+def test_header_is_plain_c():
+    """include/s3hip.h and the torch-free host in tests/native compile as C11"""
+    import subprocess
+    src = os.path.join(ROOT, "tests", "native", "c_host.c")
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), src],
+                   check=True)
+
+
+@pytest.mark.gpu
+def test_c_host_without_torch(tmp_path):
+    """a plain-C program drives KNN -> weights -> direct and planned interpolation through the C ABI (own HIP runtime, no
+    torch in the process) and checks the results against a scalar loop"""
+    import subprocess
+    pkg = os.path.join(ROOT, "sparsespatialsampling_amd")
+    exe = str(tmp_path / "c_host")
+    subprocess.run(["gcc", "-std=c11", "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "native", "c_host.c"),
+                    "-o", exe, "-L", pkg, "-ls3hip", "-lm", f"-Wl,-rpath,{pkg}"], check=True)
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "mismatches 0" in run.stdout

@@ -27,4 +27,6 @@ shutil.copy(f"{src}/bench.json", f"{dst}/bench_{tag}.json")
 shutil.copy(f"{src}/kernel_stats.csv", f"{dst}/bench_kernel_stats.csv")
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     shutil.copy(f"{src}/pmc_{c}.csv", f"{dst}/pmc_{c}.csv")
+if os.path.exists(f"{src}/pmc_extra.csv"):          # tools/collect_counters.sh
+    shutil.copy(f"{src}/pmc_extra.csv", f"{dst}/pmc_extra.csv")
 print(json.dumps(summary, indent=1))

@@ -100,6 +100,34 @@ static Result pack_window(const std::vector<int32_t> &perm, const std::vector<in
     return {tiles, rows};
 }
 
+// block-aligned packing: cells in octree-aligned Hilbert order; a "block" = the cells sharing the ancestor two levels up
+// (64 cells when fully refined).  Tiles are closed at block boundaries whenever the next whole block does not fit.
+static Result pack_blocks(const std::vector<int32_t> &perm, const std::vector<uint64_t> &block, const std::vector<int32_t> &idx,
+                          int k, int tc, int ucap) {
+    std::unordered_map<int32_t, int> seen;
+    int64_t tiles = 0, rows = 0;
+    int cells = 0;
+    const size_t n = perm.size();
+    size_t pos = 0;
+    while (pos < n) {
+        size_t end = pos;                                   // extent of the block starting at pos
+        while (end < n && block[perm[end]] == block[perm[pos]]) ++end;
+        const int bsize = (int)(end - pos);
+        if (cells > 0 && cells + bsize > tc) { ++tiles; rows += seen.size(); seen.clear(); cells = 0; }
+        for (size_t p = pos; p < end; ++p) {
+            const int32_t *ci = &idx[(size_t)perm[p] * k];
+            int fresh = 0;
+            for (int m = 0; m < k; ++m) fresh += !seen.count(ci[m]);
+            if (cells == tc || (int)seen.size() + fresh > ucap) { ++tiles; rows += seen.size(); seen.clear(); cells = 0; }
+            for (int m = 0; m < k; ++m) seen.emplace(ci[m], 0);
+            ++cells;
+        }
+        pos = end;
+    }
+    if (cells) { ++tiles; rows += seen.size(); }
+    return {tiles, rows};
+}
+
 int main(int argc, char **argv) {
     if (argc < 4) return 1;
     const int k = atoi(argv[3]);
@@ -111,6 +139,31 @@ int main(int argc, char **argv) {
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
     for (int64_t c = 0; c < nc; ++c) for (int j = 0; j < 3; ++j) { lo[j] = std::min(lo[j], ctr[c*3+j]); hi[j] = std::max(hi[j], ctr[c*3+j]); }
     double ext = 0; for (int j = 0; j < 3; ++j) ext = std::max(ext, hi[j] - lo[j]);
+    if (argc > 4) {                                          // octree-aligned experiment: levels file + root origin/width
+        std::vector<int8_t> lev(nc);
+        f = fopen(argv[4], "rb"); if (fread(lev.data(), 1, nc, f) != (size_t)nc) return 2; fclose(f);
+        const double org[3] = {atof(argv[5]), atof(argv[6]), atof(argv[7])}, width = atof(argv[8]);
+        const int LMAX = 12;
+        std::vector<uint64_t> key(nc), block(nc);
+        std::vector<int32_t> perm(nc);
+        std::iota(perm.begin(), perm.end(), 0);
+        for (int64_t c = 0; c < nc; ++c) {
+            uint32_t q[3];
+            for (int j = 0; j < 3; ++j) q[j] = (uint32_t)((ctr[c*3+j] - org[j]) / width * (1 << LMAX));
+            key[c] = hilbert3(q[0], q[1], q[2], LMAX);
+            block[c] = key[c] >> (3 * (LMAX - lev[c] + 2));
+            block[c] = block[c] * 16 + (uint64_t)lev[c];   // blocks of different levels are different blocks
+        }
+        std::stable_sort(perm.begin(), perm.end(), [&](int32_t a, int32_t b_) { return key[a] < key[b_]; });
+        g_mult.assign(*std::max_element(idx.begin(), idx.end()) + 1, 0);
+        Result r0 = pack(perm, idx, k, 64, 496);
+        printf("octree-aligned hilbert, greedy : tiles %7lld staged rows %9lld\n", (long long)r0.tiles, (long long)r0.rows);
+        Result r1 = pack_blocks(perm, block, idx, k, 64, 496);
+        printf("octree-aligned hilbert, blocks : tiles %7lld staged rows %9lld\n", (long long)r1.tiles, (long long)r1.rows);
+        Result r2 = pack_blocks(perm, block, idx, k, 64, 560);
+        printf("  (ucap 560)                   : tiles %7lld staged rows %9lld\n", (long long)r2.tiles, (long long)r2.rows);
+        return 0;
+    }
     std::vector<int32_t> perm(nc);
     g_mult.assign(*std::max_element(idx.begin(), idx.end()) + 1, 0);
     for (const char *order : {"creation", "morton", "hilbert"}) {

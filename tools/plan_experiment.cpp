@@ -182,6 +182,11 @@ int main(int argc, char **argv) {
                 Result r = pack_window(perm, idx, k, 64, 496, W);
                 printf("%-9s window %4d tc=64: tiles %7lld staged rows %9lld (%.3f per cell)\n", order, W, (long long)r.tiles, (long long)r.rows, (double)r.rows / nc);
             }
+        if (order[0] == 'h')
+            for (int ucap : {400, 448, 560, 600, 700}) {
+                Result r = pack(perm, idx, k, 64, ucap);
+                printf("%-9s tc= 64 ucap=%4d: tiles %7lld staged rows %9lld\n", order, ucap, (long long)r.tiles, (long long)r.rows);
+            }
         for (int tc : {64, 128}) {
             const int ucap = tc == 64 ? 496 : 1024;
             Result r = pack(perm, idx, k, tc, ucap);

@@ -262,7 +262,7 @@ void s3_interp_plan_destroy(s3_interp_plan *p) {
 }
 
 int s3_interp_plan_create(const int32_t *d_idx, int64_t nc, int k, int64_t n_src, const double *d_centers, int dim,
-                          int tile_cells, s3_stream stream, s3_interp_plan **out) {
+                          int tile_cells, s3_stream stream, s3_interp_plan **out) try {
     S3_REQUIRE(out != nullptr, "s3_interp_plan_create: null output");
     *out = nullptr;
     S3_REQUIRE(nc >= 1 && nc < ((int64_t)1 << 31) && n_src >= 1 && n_src < ((int64_t)1 << 31),
@@ -445,6 +445,9 @@ int s3_interp_plan_create(const int32_t *d_idx, int64_t nc, int k, int64_t n_src
     }
     *out = p;
     return S3_OK;
+} catch (const std::exception &e) {      // host tables of the builder (std::bad_alloc, std::system_error of a thread)
+    s3::set_error("s3_interp_plan_create: %s", e.what());
+    return S3_ENOMEM;
 }
 
 int s3_interp_plan_info(const s3_interp_plan *p, int64_t *n_tiles, int64_t *total_rows) {

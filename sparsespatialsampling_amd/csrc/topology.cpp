@@ -233,7 +233,9 @@ struct Topo {
 
 extern "C" {
 
-void *s3t_create(int dim, double width, const double *root_center) {
+// C++ exceptions (std::bad_alloc of the growing tables) must not cross the C boundary: the entry points that allocate
+// report them as an error value instead (nullptr / -2 / -1)
+void *s3t_create(int dim, double width, const double *root_center) try {
     if (dim != 2 && dim != 3) return nullptr;
     Topo *t = new Topo();
     t->dim = dim;
@@ -248,6 +250,8 @@ void *s3t_create(int dim, double width, const double *root_center) {
         t->node_idx[c] = c;
     }
     return t;
+} catch (...) {
+    return nullptr;
 }
 
 void s3t_destroy(void *h) { delete static_cast<Topo *>(h); }
@@ -266,8 +270,8 @@ double *s3t_nodes(void *h) { return static_cast<Topo *>(h)->nodes.data(); }
 
 // refine the listed parents in order (s_cube.py:879-895 / 531-544).  relink != 0 additionally re-runs the neighbour
 // assignment of every parent of the batch afterwards (the "update all nb" pass of the uniform loop, s_cube.py:547-549).
-// Returns the id of the first new cell, or -1 if a parent is not a leaf.
-int64_t s3t_refine(void *h, const int64_t *parents, int64_t n, int relink) {
+// Returns the id of the first new cell, -1 if a parent is not a leaf, -2 if the tables could not grow.
+int64_t s3t_refine(void *h, const int64_t *parents, int64_t n, int relink) try {
     Topo *t = static_cast<Topo *>(h);
     const int64_t first = t->n_cells();
     t->reserve_cells(n * t->nch);
@@ -278,6 +282,8 @@ int64_t s3t_refine(void *h, const int64_t *parents, int64_t n, int relink) {
     if (relink)
         for (int64_t i = 0; i < n; ++i) t->assign_neighbors((int32_t)parents[i]);
     return first;
+} catch (...) {
+    return -2;
 }
 
 // cell.parent.children = _assign_neighbors(cell.parent, children=cell.parent.children)   (s_cube.py:609, 834, 494)
@@ -318,7 +324,7 @@ int s3t_check_nb(void *h, int64_t cell, int64_t *out) {
 
 // _resort_nodes_and_indices_of_grid, s_cube.py:734-772 (+ 1695-1736).  Returns the number of leaf cells; results
 // are read through s3t_face_ids / s3t_unique_nodes.
-int64_t s3t_finalize(void *h, int64_t *n_unique_nodes) {
+int64_t s3t_finalize(void *h, int64_t *n_unique_nodes) try {
     Topo *t = static_cast<Topo *>(h);
     const int nch = t->nch;
     t->face_ids.clear();
@@ -349,6 +355,8 @@ int64_t s3t_finalize(void *h, int64_t *n_unique_nodes) {
     for (int64_t &v : t->face_ids) v = mapping[v];
     *n_unique_nodes = counter;
     return t->n_leaf;
+} catch (...) {
+    return -1;
 }
 
 int64_t *s3t_face_ids(void *h) { return static_cast<Topo *>(h)->face_ids.data(); }

@@ -56,7 +56,8 @@ class _Topology:
         self.dim, self.nch, self.nnb = dim, 2 ** dim, 8 if dim == 2 else 26
         rc = np.ascontiguousarray(root_center, dtype=np.float64)
         self._h = C.c_void_p(self._lib.s3t_create(dim, float(width), rc.ctypes.data_as(C.c_void_p)))
-        assert self._h.value, "topology engine: bad dimension"
+        if not self._h.value:
+            raise RuntimeError("topology engine: could not be created (dimension must be 2 or 3)")
 
     def close(self):
         if self._h is not None and self._h.value:
@@ -117,6 +118,8 @@ class _Topology:
     def refine(self, parents, relink):
         p = self._ids(parents)
         first = self._lib.s3t_refine(self._h, p.ctypes.data_as(C.c_void_p), len(p), int(relink))
+        if first == -2:
+            raise MemoryError("topology engine: out of host memory")
         if first < 0:
             raise RuntimeError("topology engine: tried to refine a cell that is not a leaf")
         return first
@@ -137,6 +140,8 @@ class _Topology:
     def finalize(self):
         n_nodes = C.c_int64(0)
         n_leaf = self._lib.s3t_finalize(self._h, C.byref(n_nodes))
+        if n_leaf < 0:
+            raise MemoryError("topology engine: out of host memory")
         faces = self._view(self._lib.s3t_face_ids, np.int64, (n_leaf, self.nch)).copy()
         nodes = self._view(self._lib.s3t_unique_nodes, np.float64, (n_nodes.value, self.dim)).copy()
         return faces, nodes

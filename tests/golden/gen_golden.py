@@ -15,6 +15,7 @@ Fixture groups:
     masks_polytopes   the same for triangle / prism / tetrahedron / pyramid
     uniform_*     _refine_uniform() neighbour + node tables       (s_cube.py:508-561, 904-1536)
     refine_*      full SamplingTree.refine() outputs + traces     (s_cube.py:563-667)
+    refine_random_<seed>   final grids of randomly drawn configurations (inputs.random_refine_case)
 
 The script must stay a real file with a ``__main__`` guard: the reference creates a *spawn* multiprocessing pool
 (s_cube.py:159) whose workers re-import this module and need the shims installed before unpickling.
@@ -30,8 +31,8 @@ import ref_stubs  # noqa: E402,F401  (installs shims + sys.path; must run in spa
 import numpy as np  # noqa: E402
 import torch as pt  # noqa: E402
 
-from inputs import (POLYTOPES, REFINE_CASES, c1_cylinder2d, cloud, mask_cells, polytope, polytope_cells,  # noqa: E402
-                    refine_inputs, sha, wake_metric)
+from inputs import (POLYTOPES, REFINE_CASES, build_geometries, c1_cylinder2d, cloud, mask_cells, polytope,  # noqa: E402
+                    polytope_cells, random_refine_case, refine_inputs, sha, wake_metric)
 
 
 def save(name, **kw):
@@ -217,6 +218,29 @@ def gen_refine(only=None):
              max_level=np.array(info["max_level"]), **arr)
 
 
+def gen_refine_random():
+    """randomly drawn configurations (inputs.random_refine_case): final grid + histories; seeds the reference cannot
+    finish (its single-cell-iteration IndexError) are skipped and listed"""
+    import sparseSpatialSampling.geometry as ref_geometry
+    from sparseSpatialSampling.s_cube import SamplingTree
+    done = []
+    for seed in range(12):
+        x, y, spec, kw, d = random_refine_case(seed)
+        try:
+            tree = SamplingTree(pt.from_numpy(x), pt.from_numpy(y), geometry_obj=build_geometries(ref_geometry, d, spec),
+                                n_jobs=2, **kw)
+            tree.refine()
+        except IndexError:
+            print(f"seed {seed}: reference raised IndexError, skipped")
+            continue
+        done.append(seed)
+        save(f"refine_random_{seed}", input_sha=np.array(sha(x, y)), all_centers=tree.all_centers.numpy(),
+             all_levels=tree.all_levels.numpy().astype(np.int8), face_ids=tree.face_ids.numpy(),
+             all_nodes=tree.all_nodes.numpy(), metric_hist=np.array(tree._metric), n_cells_log=np.array(tree._n_cells_log),
+             iterations=np.array(tree.data_final_mesh["iterations"]))
+    print("seeds with a fixture:", done)
+
+
 def gen_c1():
     """full-size C1 run of the reference (87 adaptive iterations): grid + histories only"""
     import sparseSpatialSampling.geometry as ref_geometry
@@ -231,10 +255,10 @@ def gen_c1():
 
 
 if __name__ == "__main__":
-    groups = sys.argv[1:] or ["interp", "knncache", "predict", "masks", "masks_polytopes", "uniform", "refine", "c1"]
+    groups = sys.argv[1:] or ["interp", "knncache", "predict", "masks", "masks_polytopes", "uniform", "refine", "refine_random", "c1"]
     pt.manual_seed(0)
     for g in groups:
-        if g.startswith("refine_"):
+        if g.startswith("refine_") and g != "refine_random":
             gen_refine(only=[g])
         else:
             globals()["gen_" + g]()

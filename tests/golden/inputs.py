@@ -2,6 +2,7 @@
 Seeded synthetic inputs shared by the golden generator (which feeds them to the REAL reference) and by the tests
 (which feed them to the oracle / the HIP path).  Pure numpy; no reference code, no product code.
 """
+import copy
 import hashlib
 
 import numpy as np
@@ -162,3 +163,92 @@ def c1_cylinder2d(geometry):
     geos = [geometry.CubeGeometry("domain", True, [0, 0], [2.2, 0.41]),
             geometry.SphereGeometry("cylinder", False, [0.2, 0.2], 0.05, refine=True, min_refinement_level=9)]
     return x, m, geos, dict(uniform_level=5, min_metric=0.75)
+
+
+# ---- randomly drawn refine configurations (tools/fuzz_refine_vs_reference.py and the ``refine_random_*`` fixtures) ----
+def random_bodies(rng, d):
+    """[(class name, kwargs)] for 0-2 bodies inside the unit domain"""
+    out = []
+    for _ in range(int(rng.integers(0, 3))):
+        refine = bool(rng.random() < 0.5)
+        extra = dict(refine=refine)
+        if refine and rng.random() < 0.5:
+            extra["min_refinement_level"] = int(rng.integers(3, 6))
+        c = rng.random(d) * 0.6 + 0.2
+        r = float(rng.random() * 0.15 + 0.05)
+        if d == 2:
+            kind = rng.choice(["sphere", "triangle", "cube"])
+            if kind == "sphere":
+                out.append(("SphereGeometry", dict(position=c.tolist(), radius=r, **extra)))
+            elif kind == "cube":
+                out.append(("CubeGeometry", dict(lower_bound=(c - r).tolist(), upper_bound=(c + r).tolist(), **extra)))
+            else:
+                p = [(c + r * np.array([np.cos(a), np.sin(a)])).tolist() for a in rng.random() * 6.28 + np.array([0, 2.1, 4.2])]
+                out.append(("TriangleGeometry", dict(points=[tuple(v) for v in p], **extra)))
+        else:
+            kind = rng.choice(["sphere", "cylinder", "cone", "cube", "prism", "tet", "pyramid"])
+            if kind == "sphere":
+                out.append(("SphereGeometry", dict(position=c.tolist(), radius=r, **extra)))
+            elif kind == "cube":
+                out.append(("CubeGeometry", dict(lower_bound=(c - r).tolist(), upper_bound=(c + r).tolist(), **extra)))
+            elif kind in ("cylinder", "cone"):
+                ax = rng.standard_normal(3); ax *= 0.3 / np.linalg.norm(ax)
+                rad = r if kind == "cylinder" else [r, r * 0.4]
+                out.append(("CylinderGeometry3D", dict(position=[tuple((c - ax).tolist()), tuple((c + ax).tolist())], radius=rad, **extra)))
+            elif kind == "prism":
+                a = int(rng.integers(0, 3))
+                dims = [j for j in range(3) if j != a]
+                tri = c[dims][None] + r * np.array([[-1.0, -0.8], [1.2, -0.5], [0.1, 1.1]])
+                lo, hi = [], []
+                for v in tri:
+                    p0 = np.zeros(3); p0[dims] = v; p0[a] = c[a] - r
+                    p1 = p0.copy(); p1[a] = c[a] + r
+                    lo.append(tuple(p0.tolist())); hi.append(tuple(p1.tolist()))
+                out.append(("PrismGeometry3D", dict(positions=[lo, hi], **extra)))
+            elif kind == "tet":
+                p = c[None] + r * 1.5 * np.array([[-1, -1, -1], [1.2, -0.7, -0.9], [0.1, 1.1, -0.8], [0.0, 0.1, 1.2]])
+                out.append(("TetrahedronGeometry3D", dict(positions=p.tolist(), **extra)))
+            else:
+                z0 = float(c[2] - r)
+                base = [[c[0] - r, c[1] - r, z0], [c[0] + r, c[1] - r, z0], [c[0] + r, c[1] + r, z0], [c[0] - r, c[1] + r, z0]]
+                out.append(("PyramidGeometry3D", dict(nodes=[[float(v) for v in b] for b in base] + [[float(c[0]), float(c[1]), float(c[2] + 1.5 * r)]], **extra)))
+    return out
+
+
+def build_geometries(geometry, d, spec):
+    geos = [geometry.CubeGeometry("domain", True, [0.0] * d, [1.0] * d)]
+    for i, (cls, kw) in enumerate(spec):
+        kw = copy.deepcopy(kw)
+        first = kw.pop(next(iter(kw)))                   # the positional geometry argument
+        geos.append(getattr(geometry, cls)(f"body{i}", False, first, **kw))
+    return geos
+
+
+
+
+def random_refine_case(seed):
+    """(x, y, body spec, SamplingTree keyword arguments, d) of the randomly drawn configuration ``seed``: dimension, cloud,
+    metric, stopping rule, cell ramp, 2:1 balance, pre_select, 0-2 bodies.  N >= 2100 and ramps >= 2 keep the reference
+    away from its single-cell-iteration IndexError."""
+    rng = np.random.default_rng(1000 + seed)
+    d = int(rng.integers(2, 4))
+    n = int(rng.integers(2100, 5000))
+    x = rng.random((n, d))
+    c0 = rng.random(d)
+    y = 0.05 + np.exp(-rng.uniform(2, 12) * np.linalg.norm(x - c0, axis=1)) * (1 + 0.3 * np.sin(9 * x[:, 0]))
+    kw = dict(uniform_level=int(rng.integers(1, 4 if d == 2 else 3)))
+    if rng.random() < 0.6:
+        kw["min_metric"] = float(rng.uniform(0.3, 0.9))
+    else:
+        kw["n_cells"] = int(rng.integers(100, 1500))
+    if rng.random() < 0.3:
+        kw["max_delta_level"] = True
+    if rng.random() < 0.3:
+        kw["n_cells_iter_start"], kw["n_cells_iter_end"] = int(rng.integers(2, 30)), int(rng.integers(2, 10))
+    if rng.random() < 0.3:
+        kw["relTol"] = float(10.0 ** rng.uniform(-4, -1.5))
+    if rng.random() < 0.3:
+        kw["reach_at_least"] = float(rng.uniform(0.3, 0.95))
+    if rng.random() < 0.2:
+        kw["pre_select"] = True
+    return x, y, random_bodies(rng, d), kw, d

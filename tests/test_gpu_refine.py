@@ -265,3 +265,11 @@ def test_full_size_c3_properties():
     both.copy_(a.double() + 2 * b.double())
     assert pt.allclose(plan.interp(w, both), fa + 2 * fb, rtol=1e-12, atol=1e-12)
     assert pt.equal(fa, hipops.interp(w, idx, a.contiguous()).reshape(nc, t))        # same arithmetic as the direct kernel
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 4, 5, 6, 7, 8, 9, 10, 11])
+def test_refine_random_configurations_gpu(seed):
+    """randomly drawn configurations (dimension, stopping rule, ramp, 2:1 balance, pre_select, bodies of every kind): the
+    HIP path against the real reference's grid"""
+    from tests.test_tree_host_logic import check_random_case
+    check_random_case(seed)

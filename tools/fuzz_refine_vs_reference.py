@@ -4,7 +4,6 @@ tests/golden/ref_stubs.py) on small random configurations: dimension, cloud, sto
 bodies of every supported kind with / without geometry refinement.
     python tools/fuzz_refine_vs_reference.py [seed] [cases]
 Must stay a file with a __main__ guard (the reference spawns a worker pool that re-imports it)."""
-import copy
 import os
 import sys
 
@@ -18,62 +17,7 @@ import numpy as np  # noqa: E402
 import torch as pt  # noqa: E402
 
 
-def bodies(rng, d):
-    """[(class name, kwargs)] for 0-2 bodies inside the unit domain"""
-    out = []
-    for _ in range(int(rng.integers(0, 3))):
-        refine = bool(rng.random() < 0.5)
-        extra = dict(refine=refine)
-        if refine and rng.random() < 0.5:
-            extra["min_refinement_level"] = int(rng.integers(3, 6))
-        c = rng.random(d) * 0.6 + 0.2
-        r = float(rng.random() * 0.15 + 0.05)
-        if d == 2:
-            kind = rng.choice(["sphere", "triangle", "cube"])
-            if kind == "sphere":
-                out.append(("SphereGeometry", dict(position=c.tolist(), radius=r, **extra)))
-            elif kind == "cube":
-                out.append(("CubeGeometry", dict(lower_bound=(c - r).tolist(), upper_bound=(c + r).tolist(), **extra)))
-            else:
-                p = [(c + r * np.array([np.cos(a), np.sin(a)])).tolist() for a in rng.random() * 6.28 + np.array([0, 2.1, 4.2])]
-                out.append(("TriangleGeometry", dict(points=[tuple(v) for v in p], **extra)))
-        else:
-            kind = rng.choice(["sphere", "cylinder", "cone", "cube", "prism", "tet", "pyramid"])
-            if kind == "sphere":
-                out.append(("SphereGeometry", dict(position=c.tolist(), radius=r, **extra)))
-            elif kind == "cube":
-                out.append(("CubeGeometry", dict(lower_bound=(c - r).tolist(), upper_bound=(c + r).tolist(), **extra)))
-            elif kind in ("cylinder", "cone"):
-                ax = rng.standard_normal(3); ax *= 0.3 / np.linalg.norm(ax)
-                rad = r if kind == "cylinder" else [r, r * 0.4]
-                out.append(("CylinderGeometry3D", dict(position=[tuple((c - ax).tolist()), tuple((c + ax).tolist())], radius=rad, **extra)))
-            elif kind == "prism":
-                a = int(rng.integers(0, 3))
-                dims = [j for j in range(3) if j != a]
-                tri = c[dims][None] + r * np.array([[-1.0, -0.8], [1.2, -0.5], [0.1, 1.1]])
-                lo, hi = [], []
-                for v in tri:
-                    p0 = np.zeros(3); p0[dims] = v; p0[a] = c[a] - r
-                    p1 = p0.copy(); p1[a] = c[a] + r
-                    lo.append(tuple(p0.tolist())); hi.append(tuple(p1.tolist()))
-                out.append(("PrismGeometry3D", dict(positions=[lo, hi], **extra)))
-            elif kind == "tet":
-                p = c[None] + r * 1.5 * np.array([[-1, -1, -1], [1.2, -0.7, -0.9], [0.1, 1.1, -0.8], [0.0, 0.1, 1.2]])
-                out.append(("TetrahedronGeometry3D", dict(positions=p.tolist(), **extra)))
-            else:
-                z0 = float(c[2] - r)
-                base = [[c[0] - r, c[1] - r, z0], [c[0] + r, c[1] - r, z0], [c[0] + r, c[1] + r, z0], [c[0] - r, c[1] + r, z0]]
-                out.append(("PyramidGeometry3D", dict(nodes=[[float(v) for v in b] for b in base] + [[float(c[0]), float(c[1]), float(c[2] + 1.5 * r)]], **extra)))
-    return out
-
-
-def build(geometry, d, spec):
-    geos = [geometry.CubeGeometry("domain", True, [0.0] * d, [1.0] * d)]
-    for i, (cls, kw) in enumerate(spec):
-        kw = copy.deepcopy(kw)
-        first = kw.pop(next(iter(kw)))                   # the positional geometry argument
-        geos.append(getattr(geometry, cls)(f"body{i}", False, first, **kw))
-    return geos
+from inputs import build_geometries as build, random_bodies as bodies  # noqa: E402  (tests/golden/inputs.py)
 
 
 def main():

@@ -275,7 +275,43 @@ int64_t s3t_refine(void *h, const int64_t *parents, int64_t n, int relink) try {
     Topo *t = static_cast<Topo *>(h);
     const int64_t first = t->n_cells();
     t->reserve_cells(n * t->nch);
+    // the work per parent is a few dozen dependent look-ups in tables far larger than the caches; two software
+    // prefetch stages run ahead of it: the neighbour row of the parent four positions ahead, and -- once that row is
+    // there -- the entries of those neighbours two positions ahead
+    const int64_t n_before = t->n_cells();
+    auto valid = [&](int64_t i) { return i < n && parents[i] >= 0 && parents[i] < n_before; };
     for (int64_t i = 0; i < n; ++i) {
+        if (valid(i + 4)) {
+            const int32_t *row = &t->nb[(size_t)parents[i + 4] * t->nnb];
+            __builtin_prefetch(row);
+            __builtin_prefetch(row + 16);
+            __builtin_prefetch(&t->node_idx[(size_t)parents[i + 4] * t->nch]);
+            __builtin_prefetch(&t->center[(size_t)parents[i + 4] * t->dim]);
+        }
+        if (valid(i + 2)) {
+            const int32_t *row = &t->nb[(size_t)parents[i + 2] * t->nnb];
+            for (int s_ = 0; s_ < t->nnb; ++s_) {
+                const int32_t q = row[s_];
+                if (q < 0) continue;
+                __builtin_prefetch(&t->first_child[q]);
+                __builtin_prefetch(&t->level[q]);
+                __builtin_prefetch(&t->node_idx[(size_t)q * t->nch]);
+            }
+        }
+        if (valid(i + 1)) {
+            // third stage: where a neighbour is refined already, its children are what the new cells link to and share
+            // nodes with
+            const int32_t *row = &t->nb[(size_t)parents[i + 1] * t->nnb];
+            for (int s_ = 0; s_ < t->nnb; ++s_) {
+                const int32_t q = row[s_];
+                if (q < 0) continue;
+                const int32_t fc = t->first_child[q];
+                if (fc < 0) continue;
+                __builtin_prefetch(&t->first_child[fc]);
+                __builtin_prefetch(&t->level[fc]);
+                for (int c = 0; c < t->nch; ++c) __builtin_prefetch(&t->node_idx[(size_t)(fc + c) * t->nch]);
+            }
+        }
         if (parents[i] < 0 || parents[i] >= t->n_cells() || t->first_child[parents[i]] != LEAF) return -1;
         t->refine_one((int32_t)parents[i]);
     }

@@ -159,8 +159,8 @@ int s3_interp(const double *d_w /*[nc,k]*/, const int32_t *d_idx /*[nc,k]*/, int
 int s3_snapshot_major(const double *d_in, int64_t nc, int n_comp, int64_t n_snapshots, double *d_out, s3_stream stream);
 
 /* Planned form of a17 for a static neighbour table (the table ExportData caches at export.py:431-432 and reuses for
- * every snapshot batch and field): the plan de-duplicates the source rows of spatially adjacent cells once (host side,
- * Hilbert order of d_centers[nc,dim] when given), the kernel then stages each distinct row once per tile in LDS.
+ * every snapshot batch and field): the plan de-duplicates the source rows of spatially adjacent cells once (built on the
+ * device; Hilbert order of d_centers[nc,dim] when given), the kernel then stages each distinct row once per tile in LDS.
  * Same results as s3_interp.  Rows must be 16-byte aligned (row_len % 4 == 0 for f32, % 2 == 0 for f64). */
 typedef struct s3_interp_plan s3_interp_plan;
 int s3_interp_plan_create(const int32_t *d_idx /*[nc,k]*/, int64_t nc, int k, int64_t n_src,

@@ -8,8 +8,8 @@
 // by the Infinity Cache at ~7-8 TB/s and bounds the kernel.  The neighbour table is static for a whole export (it is
 // computed once and reused for every snapshot batch and field), so it pays to de-duplicate it once:
 //
-//   plan (host, once):  cells are put in Hilbert order of their centres (radix sort); consecutive cells are packed
-//                       greedily (host threads, one hash table per tile) into
+//   plan (device, once): cells are put in Hilbert order of their centres (radix sort); consecutive cells are packed
+//                       greedily (plan_build.hip: one wavefront per 64 cells, LDS hash table of the tile's rows) into
 //                       tiles of <= 64 cells whose neighbour sets contain <= ucap (~500) distinct source rows; per tile the
 //                       distinct row ids and, per (cell, neighbour), the 16-bit position in that list are stored.
 //   kernel (per batch): one workgroup (256 threads) per tile.  For every 128-byte column chunk of the row it stages the
@@ -22,21 +22,13 @@
 // HBM/L2 traffic per tile-chunk drops from n_cells*k segments to n_distinct segments (2.5-3x fewer on the cylinder3D
 // workload), which moves the kernel from the Infinity-Cache gather bound towards the HBM bound.
 #include "common.h"
+#include "plan_build.h"
 
-#include <algorithm>
-#include <cstring>
-#include <numeric>
-#include <thread>
-#include <vector>
+#include <exception>
 
-struct s3_interp_plan {
-    int64_t nc = 0, n_src = 0, n_tiles = 0, total_rows = 0;
+struct s3_interp_plan : s3::PlanTables {
+    int64_t nc = 0, n_src = 0;
     int k = 0, ucap = 0, tc = 64;
-    int32_t *perm = nullptr;             // [nc] processing position -> cell id
-    int32_t *tile_cell_begin = nullptr;  // [n_tiles+1]
-    int32_t *tile_row_begin = nullptr;   // [n_tiles+1]
-    int32_t *rows = nullptr;             // [total_rows] distinct source rows, tile after tile
-    uint16_t *loc = nullptr;             // [nc*k] per tile: [m][cell in tile] -> position in the tile's row list
 };
 
 namespace s3 {
@@ -180,35 +172,6 @@ static int plan_ucap(int k, int tc) {
     return u > cap ? cap : u;
 }
 
-// Hilbert index of a quantised point (dim axes, b bits each; Skilling's transpose algorithm).  Consecutive cells of the
-// curve are always face neighbours, so runs of the curve make more compact tiles than Z-order runs (3 % fewer staged
-// rows on the cylinder3D workload) and consecutive tiles always touch.
-static inline uint64_t hilbert_key(const uint32_t *q, int dim, int b) {
-    uint32_t X[3] = {q[0], q[1], dim == 3 ? q[2] : 0};
-    const uint32_t M = 1u << (b - 1);
-    for (uint32_t Q = M; Q > 1; Q >>= 1) {
-        const uint32_t P = Q - 1;
-        for (int i = 0; i < dim; ++i) {
-            if (X[i] & Q) {
-                X[0] ^= P;
-            } else {
-                const uint32_t t = (X[0] ^ X[i]) & P;
-                X[0] ^= t;
-                X[i] ^= t;
-            }
-        }
-    }
-    for (int i = 1; i < dim; ++i) X[i] ^= X[i - 1];
-    uint32_t t = 0;
-    for (uint32_t Q = M; Q > 1; Q >>= 1)
-        if (X[dim - 1] & Q) t ^= Q - 1;
-    for (int i = 0; i < dim; ++i) X[i] ^= t;
-    uint64_t h = 0;
-    for (int bit = b - 1; bit >= 0; --bit)
-        for (int i = 0; i < dim; ++i) h = (h << 1) | ((X[i] >> bit) & 1u);
-    return h;
-}
-
 }  // namespace s3
 
 using namespace s3;
@@ -276,176 +239,16 @@ int s3_interp_plan_create(const int32_t *d_idx, int64_t nc, int k, int64_t n_src
     S3_REQUIRE(nc * (int64_t)k < ((int64_t)1 << 31), "s3_interp_plan_create: table too large");
     hipStream_t st = as_stream(stream);
 
-    std::vector<int32_t> idx((size_t)nc * k);
-    S3_HIP_CHECK(hipMemcpyAsync(idx.data(), d_idx, sizeof(int32_t) * idx.size(), hipMemcpyDeviceToHost, st));
-    std::vector<double> ctr;
-    if (d_centers) {
-        ctr.resize((size_t)nc * dim);
-        S3_HIP_CHECK(hipMemcpyAsync(ctr.data(), d_centers, sizeof(double) * ctr.size(), hipMemcpyDeviceToHost, st));
-    }
-    S3_HIP_CHECK(hipStreamSynchronize(st));
-    for (int32_t v : idx)
-        S3_REQUIRE(v >= 0 && v < n_src, "s3_interp_plan_create: neighbour index %d outside [0, %lld)", v, (long long)n_src);
-
-    // processing order: Hilbert order of the cell centres (spatially adjacent cells share neighbours); LSD radix sort
-    // of (key, cell) pairs, stable, so equal keys keep the caller's order
-    std::vector<int32_t> perm(nc);
-    std::iota(perm.begin(), perm.end(), 0);
-    if (d_centers) {
-        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-        for (int64_t c = 0; c < nc; ++c)
-            for (int j = 0; j < dim; ++j) {
-                lo[j] = std::min(lo[j], ctr[c * dim + j]);
-                hi[j] = std::max(hi[j], ctr[c * dim + j]);
-            }
-        double ext = 0;
-        for (int j = 0; j < dim; ++j) ext = std::max(ext, hi[j] - lo[j]);
-        const int bits = dim == 3 ? 16 : 24;                // 48-bit keys: three 16-bit sorting passes
-        const double scale = ext > 0 ? ((double)((1u << bits) - 1) / ext) : 0.0;
-        std::vector<uint64_t> key(nc), key2(nc);
-        std::vector<int32_t> perm2(nc);
-        {
-            const int kt = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)std::thread::hardware_concurrency(), 32, nc / 16384 + 1}));
-            auto keys = [&](int t) {
-                for (int64_t c = nc * t / kt; c < nc * (t + 1) / kt; ++c) {
-                    uint32_t q[3] = {0, 0, 0};
-                    for (int j = 0; j < dim; ++j) q[j] = (uint32_t)((ctr[c * dim + j] - lo[j]) * scale);
-                    key[c] = hilbert_key(q, dim, bits);
-                }
-            };
-            std::vector<std::thread> workers;
-            for (int t = 1; t < kt; ++t) workers.emplace_back(keys, t);
-            keys(0);
-            for (auto &w : workers) w.join();
-        }
-        for (int pass = 0; pass < 3; ++pass) {
-            const int shift = 16 * pass;
-            std::vector<int64_t> hist(65537, 0);
-            for (int64_t c = 0; c < nc; ++c) ++hist[((key[c] >> shift) & 0xffff) + 1];
-            for (int v = 0; v < 65536; ++v) hist[v + 1] += hist[v];
-            for (int64_t c = 0; c < nc; ++c) {
-                const int64_t dst = hist[(key[c] >> shift) & 0xffff]++;
-                key2[dst] = key[c];
-                perm2[dst] = perm[c];
-            }
-            key.swap(key2);
-            perm.swap(perm2);
-        }
-    }
-
-    // greedy packing into tiles: consecutive cells join a tile while it has room (<= tile_cells cells, <= ucap distinct
-    // rows).  The cell sequence is cut into independent chunks packed by separate host threads; each tile keeps its
-    // distinct rows in a small open-addressing table, so no O(n_src) scratch is needed.
-    const int ucap = plan_ucap(k, PL_TC);
-    struct Chunk {
-        std::vector<int32_t> cell_end, row_end, rows;      // per tile: end position (in perm) / end of its row list
-    };
-    const int n_threads = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)std::thread::hardware_concurrency(), 32, nc / 4096 + 1}));
-    std::vector<Chunk> chunks(n_threads);
-    std::vector<uint16_t> loc((size_t)nc * k);
-    auto pack = [&](int t) {
-        const int64_t pos0 = nc * t / n_threads, pos1 = nc * (t + 1) / n_threads;
-        Chunk &ch = chunks[t];
-        constexpr int HS = 2048;                            // table slots (power of two, > 2 * max ucap is not needed: ucap <= 1024)
-        std::vector<int32_t> hkey(HS, -1), used;
-        std::vector<uint16_t> hval(HS);
-        used.reserve(1100);
-        auto find = [&](int32_t r) -> int {                 // slot of r, or the empty slot where it would go
-            uint32_t s = ((uint32_t)r * 2654435761u) >> 21;  // 11 bits
-            while (hkey[s] != -1 && hkey[s] != r) s = (s + 1) & (HS - 1);
-            return (int)s;
-        };
-        int64_t tile_pos0 = pos0;
-        int rows_in_tile = 0;
-        auto close_tile = [&](int64_t pos_end) {
-            // positions of the tile's (cell, neighbour) pairs, stored [m][cell]
-            const int32_t n_c = (int32_t)(pos_end - tile_pos0);
-            for (int32_t j = 0; j < n_c; ++j) {
-                const int32_t cell = perm[tile_pos0 + j];
-                for (int m = 0; m < k; ++m)
-                    loc[(size_t)tile_pos0 * k + (size_t)m * n_c + j] = hval[find(idx[(size_t)cell * k + m])];
-            }
-            ch.cell_end.push_back((int32_t)pos_end);
-            ch.row_end.push_back((int32_t)ch.rows.size());
-            for (int32_t s : used) hkey[s] = -1;
-            used.clear();
-            rows_in_tile = 0;
-            tile_pos0 = pos_end;
-        };
-        int32_t fresh_ids[S3_MAX_K];
-        for (int64_t pos = pos0; pos < pos1; ++pos) {
-            const int32_t *ci = &idx[(size_t)perm[pos] * k];
-            int fresh = 0;                                   // rows this cell would add (repeats inside a row count once)
-            for (int m = 0; m < k; ++m) {
-                const int32_t r = ci[m];
-                if (hkey[find(r)] == r) continue;
-                bool dup = false;
-                for (int u = 0; u < fresh; ++u) dup |= fresh_ids[u] == r;
-                if (!dup) fresh_ids[fresh++] = r;
-            }
-            if (pos - tile_pos0 == PL_TC || rows_in_tile + fresh > ucap) {
-                close_tile(pos);
-                fresh = 0;                                   // recount against the empty table
-                for (int m = 0; m < k; ++m) {
-                    bool dup = false;
-                    for (int u = 0; u < fresh; ++u) dup |= fresh_ids[u] == ci[m];
-                    if (!dup) fresh_ids[fresh++] = ci[m];
-                }
-            }
-            for (int u = 0; u < fresh; ++u) {
-                const int s_ = find(fresh_ids[u]);
-                hkey[s_] = fresh_ids[u];
-                hval[s_] = (uint16_t)rows_in_tile++;
-                used.push_back(s_);
-                ch.rows.push_back(fresh_ids[u]);
-            }
-        }
-        if (pos1 > tile_pos0) close_tile(pos1);
-    };
-    {
-        std::vector<std::thread> workers;
-        for (int t = 1; t < n_threads; ++t) workers.emplace_back(pack, t);
-        pack(0);
-        for (auto &w : workers) w.join();
-    }
-    std::vector<int32_t> tile_cell_begin{0}, tile_row_begin{0}, rows;
-    {
-        size_t total = 0;
-        for (const Chunk &ch : chunks) total += ch.rows.size();
-        S3_REQUIRE(total < ((size_t)1 << 31), "s3_interp_plan_create: row lists too large");
-        rows.reserve(total);
-        for (const Chunk &ch : chunks) {
-            const int32_t row_base = (int32_t)rows.size();
-            for (size_t i = 0; i < ch.cell_end.size(); ++i) {
-                tile_cell_begin.push_back(ch.cell_end[i]);
-                tile_row_begin.push_back(row_base + ch.row_end[i]);
-            }
-            rows.insert(rows.end(), ch.rows.begin(), ch.rows.end());
-        }
-    }
-    const int32_t tile = (int32_t)tile_cell_begin.size() - 1;
-
     s3_interp_plan *p = new s3_interp_plan();
-    p->nc = nc; p->k = k; p->ucap = ucap; p->tc = PL_TC; p->n_src = n_src; p->n_tiles = tile; p->total_rows = (int64_t)rows.size();
-    auto upload = [&](void **dst, const void *src, size_t bytes) -> hipError_t {
-        hipError_t e = hipMalloc(dst, bytes ? bytes : 4);
-        if (e != hipSuccess) return e;
-        return hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, st);
-    };
-    hipError_t e = upload((void **)&p->perm, perm.data(), sizeof(int32_t) * perm.size());
-    if (e == hipSuccess) e = upload((void **)&p->tile_cell_begin, tile_cell_begin.data(), sizeof(int32_t) * tile_cell_begin.size());
-    if (e == hipSuccess) e = upload((void **)&p->tile_row_begin, tile_row_begin.data(), sizeof(int32_t) * tile_row_begin.size());
-    if (e == hipSuccess) e = upload((void **)&p->rows, rows.data(), sizeof(int32_t) * rows.size());
-    if (e == hipSuccess) e = upload((void **)&p->loc, loc.data(), sizeof(uint16_t) * loc.size());
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e != hipSuccess) {
-        s3::set_error("s3_interp_plan_create: %s", hipGetErrorString(e));
+    p->nc = nc; p->k = k; p->ucap = plan_ucap(k, PL_TC); p->tc = PL_TC; p->n_src = n_src;
+    const int rc = build_plan_tables(d_idx, nc, k, n_src, d_centers, dim, PL_TC, p->ucap, st, p);
+    if (rc != S3_OK) {
         s3_interp_plan_destroy(p);
-        return e == hipErrorOutOfMemory ? S3_ENOMEM : S3_EHIP;
+        return rc;
     }
     *out = p;
     return S3_OK;
-} catch (const std::exception &e) {      // host tables of the builder (std::bad_alloc, std::system_error of a thread)
+} catch (const std::exception &e) {      // host-side allocations of the builder
     s3::set_error("s3_interp_plan_create: %s", e.what());
     return S3_ENOMEM;
 }

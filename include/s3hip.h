@@ -51,6 +51,12 @@ int s3_free(void *d_ptr);
 int s3_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes, s3_stream stream);
 int s3_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes, s3_stream stream);
 int s3_stream_synchronize(s3_stream stream);
+/* upload target of a snapshot batch (the .to(device) of a host tensor handed to ExportData.export, export.py:128-167):
+ * pageable host rows [n_rows][row_bytes] -> device rows with pitch dst_pitch_bytes, staged through persistent pinned
+ * buffers filled by several host threads; asynchronous on `stream` (the host data may be reused on return).  The
+ * bytes between row_bytes and dst_pitch_bytes of every row but the last are padding and may be overwritten. */
+int s3_upload_rows(const void *h_src, int64_t n_rows, int64_t row_bytes, void *d_dst, int64_t dst_pitch_bytes,
+                   s3_stream stream);
 
 /* ---- KNN index over the original CFD points -------------------------------------------------------------------
  * Replaces KNeighborsRegressor(...).fit(vertices, target)           s_cube.py:161-163

@@ -1,7 +1,13 @@
 // Runtime plumbing of libs3hip.so: error string, device selection, raw memory helpers for hosts without torch.
 #include "common.h"
 
+#include <algorithm>
+#include <atomic>
 #include <cstring>
+#include <exception>
+#include <mutex>
+#include <thread>
+#include <vector>
 
 namespace s3 {
 static thread_local char g_err[512] = "";
@@ -12,9 +18,105 @@ void set_error(const char *fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+
+// ---- staged upload of pageable host rows -------------------------------------------------------------------------
+// A snapshot batch arrives as a pageable host tensor; handed to hipMemcpy as it is, it goes up at 14-26 GB/s on an
+// MI355X host (the runtime stages it through one thread).  Here a few host threads copy row chunks into their own
+// persistent pinned buffers and each chunk goes up asynchronously, so the host-side copies of all threads and the DMA
+// transfers overlap.
+namespace {
+constexpr int UP_THREADS_MAX = 16;
+constexpr int UP_BUFS = 2;                           // pinned buffers per thread
+constexpr size_t UP_CHUNK_BYTES = (size_t)8 << 20;   // per buffer
+
+struct UploadLane {
+    void *pinned[UP_BUFS] = {nullptr, nullptr};
+    hipEvent_t ev[UP_BUFS] = {nullptr, nullptr};
+};
+std::mutex g_upload_mutex;
+UploadLane g_lanes[UP_THREADS_MAX];
+
+hipError_t upload_lane_init(UploadLane &l) {
+    for (int b = 0; b < UP_BUFS; ++b) {
+        if (!l.pinned[b]) {
+            hipError_t e = hipHostMalloc(&l.pinned[b], UP_CHUNK_BYTES, hipHostMallocPortable);
+            if (e != hipSuccess) return e;
+        }
+        if (!l.ev[b]) {
+            hipError_t e = hipEventCreateWithFlags(&l.ev[b], hipEventDisableTiming);
+            if (e != hipSuccess) return e;
+        }
+    }
+    return hipSuccess;
+}
+}  // namespace
+
 }  // namespace s3
 
 extern "C" {
+
+int s3_upload_rows(const void *h_src, int64_t n_rows, int64_t row_bytes, void *d_dst, int64_t dst_pitch_bytes,
+                   s3_stream stream) try {
+    using namespace s3;
+    S3_REQUIRE(n_rows >= 0 && row_bytes >= 0 && dst_pitch_bytes >= row_bytes, "s3_upload_rows: bad shape");
+    if (n_rows == 0 || row_bytes == 0) return S3_OK;
+    S3_REQUIRE(h_src && d_dst, "s3_upload_rows: null array");
+    S3_REQUIRE((size_t)dst_pitch_bytes <= UP_CHUNK_BYTES, "s3_upload_rows: rows longer than %zu bytes are not staged", UP_CHUNK_BYTES);
+    hipStream_t st = as_stream(stream);
+    std::lock_guard<std::mutex> guard(g_upload_mutex);
+    int dev = 0;
+    S3_HIP_CHECK(hipGetDevice(&dev));
+    const int64_t rows_per_chunk = std::max<int64_t>(1, (int64_t)(UP_CHUNK_BYTES / (size_t)dst_pitch_bytes));
+    const int64_t n_chunks = (n_rows + rows_per_chunk - 1) / rows_per_chunk;
+    const int hw = (int)std::thread::hardware_concurrency();
+    const int n_thr = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)UP_THREADS_MAX, (int64_t)std::max(1, hw / 2), n_chunks}));
+    for (int t = 0; t < n_thr; ++t) S3_HIP_CHECK(upload_lane_init(g_lanes[t]));
+
+    std::atomic<int64_t> next{0};
+    std::atomic<int> first_error{(int)hipSuccess};
+    auto work = [&](int t) {
+        if (hipSetDevice(dev) != hipSuccess) { first_error = (int)hipErrorInvalidDevice; return; }
+        UploadLane &l = g_lanes[t];
+        int b = 0;
+        while (first_error.load() == (int)hipSuccess) {
+            const int64_t c = next.fetch_add(1);
+            if (c >= n_chunks) break;
+            const int64_t r0 = c * rows_per_chunk, rows = std::min(rows_per_chunk, n_rows - r0);
+            hipError_t e = hipEventSynchronize(l.ev[b]);             // the buffer's previous transfer has left it
+            if (e == hipSuccess) {
+                const char *src = static_cast<const char *>(h_src) + r0 * row_bytes;
+                char *stage = static_cast<char *>(l.pinned[b]);
+                char *dst = static_cast<char *>(d_dst) + r0 * dst_pitch_bytes;
+                if (row_bytes == dst_pitch_bytes) {
+                    std::memcpy(stage, src, (size_t)(rows * row_bytes));
+                    e = hipMemcpyAsync(dst, stage, (size_t)(rows * row_bytes), hipMemcpyHostToDevice, st);
+                } else if (row_bytes >= 512) {
+                    // long rows: packed in the pinned buffer, the 2-D copy converts the pitch (4000-byte rows: 49 GB/s)
+                    std::memcpy(stage, src, (size_t)(rows * row_bytes));
+                    e = hipMemcpy2DAsync(dst, (size_t)dst_pitch_bytes, stage, (size_t)row_bytes, (size_t)row_bytes, (size_t)rows,
+                                         hipMemcpyHostToDevice, st);
+                } else {
+                    // short rows: laid out with the device pitch on the host, one contiguous copy (100-byte rows: 32 GB/s,
+                    // 21 GB/s as a 2-D copy); the padding of the chunk's last row is left alone
+                    for (int64_t r = 0; r < rows; ++r) std::memcpy(stage + r * dst_pitch_bytes, src + r * row_bytes, (size_t)row_bytes);
+                    e = hipMemcpyAsync(dst, stage, (size_t)((rows - 1) * dst_pitch_bytes + row_bytes), hipMemcpyHostToDevice, st);
+                }
+            }
+            if (e == hipSuccess) e = hipEventRecord(l.ev[b], st);
+            if (e != hipSuccess) { first_error = (int)e; break; }
+            b = (b + 1) % UP_BUFS;
+        }
+    };
+    std::vector<std::thread> workers;
+    for (int t = 1; t < n_thr; ++t) workers.emplace_back(work, t);
+    work(0);
+    for (auto &w : workers) w.join();
+    S3_HIP_CHECK((hipError_t)first_error.load());
+    return S3_OK;
+} catch (const std::exception &e) {          // thread creation
+    s3::set_error("s3_upload_rows: %s", e.what());
+    return S3_ENOMEM;
+}
 
 const char *s3_last_error(void) { return s3::g_err; }
 

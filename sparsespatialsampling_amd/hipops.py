@@ -202,6 +202,21 @@ class InterpPlan:
         return out
 
 
+def upload_rows(host, rows):
+    """contiguous host tensor [n_rows, row_len] -> device rows ``rows`` (a ``padded_rows`` view: the bytes between two
+    rows are padding and may be overwritten) through the native staged upload (s3_upload_rows); asynchronous on the
+    current stream"""
+    if host.is_cuda or not host.is_contiguous() or host.dim() != 2 or host.dtype != rows.dtype:
+        raise TypeError("upload_rows: contiguous 2-D host tensor of the rows' dtype required")
+    if not rows.is_cuda or rows.dim() != 2 or rows.stride(1) != 1 or tuple(rows.shape) != tuple(host.shape):
+        raise TypeError("upload_rows: 2-D device rows of the same shape with unit inner stride required")
+    item = host.element_size()
+    check(_lib.hip_lib().s3_upload_rows(C.c_void_p(host.data_ptr()), int(host.shape[0]), int(host.shape[1]) * item,
+                                        C.c_void_p(rows.data_ptr()), int(rows.stride(0)) * item, _stream()),
+          "s3_upload_rows")
+    return rows
+
+
 def padded_rows(n_rows, row_len, dtype, dev, extra_lines=0):
     """[n_rows, row_len] view of a device buffer whose row pitch is a whole number of 128-byte lines (upload target for
     snapshot batches: every 128-B segment the planned kernel stages then sits on exactly one cache line).  For long rows

@@ -146,6 +146,29 @@ def test_interp_planned_random_table_no_centers(ops, orc):
         ops.InterpPlan(dev(np.full((4, 8), n), pt.int32), n)                              # index out of range
 
 
+@pytest.mark.parametrize("n,row_len,dtype", [(70_000, 25, pt.float32), (3_000, 1000, pt.float32), (50_000, 7, pt.float64),
+                                             (1, 4, pt.float32), (200_000, 32, pt.float32), (999, 3000, pt.float64)])
+def test_upload_rows(ops, n, row_len, dtype):
+    """native staged upload (pinned buffers filled by host threads): every row lands in its pitched device row, for rows
+    shorter / longer than the 2-D-copy threshold, rows without padding and several chunks per thread"""
+    host = pt.randn((n, row_len), dtype=dtype)
+    rows = ops.padded_rows(n, row_len, dtype, "cuda")
+    base = rows.storage_offset()
+    ops.upload_rows(host, rows)
+    ops.synchronize()
+    assert pt.equal(rows.cpu(), host) and rows.storage_offset() == base
+    again = pt.randn((n, row_len), dtype=dtype)                       # the pinned buffers are reused by the next call
+    ops.upload_rows(again, rows)
+    ops.synchronize()
+    assert pt.equal(rows.cpu(), again)
+    dense = pt.empty((n, row_len), dtype=dtype, device="cuda")        # pitch == row length
+    ops.upload_rows(host, dense)
+    ops.synchronize()
+    assert pt.equal(dense.cpu(), host)
+    with pytest.raises(TypeError):
+        ops.upload_rows(host.t(), rows)
+
+
 @pytest.mark.parametrize("nc,ncomp,t", [(1000, 1, 25), (777, 3, 40), (33, 2, 1), (5, 1, 70)])
 def test_snapshot_major(ops, nc, ncomp, t):
     a = pt.randn((nc, ncomp, t), dtype=pt.float64, device="cuda")

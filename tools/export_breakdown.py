@@ -1,0 +1,29 @@
+"""dev helper: where one ExportData._fit_data call of a 25-snapshot batch spends its time (C3-sized problem)"""
+import sys, time, types, logging
+import numpy as np, torch as pt
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+from tests import fake_h5py
+fake_h5py.install()
+from sparsespatialsampling_amd import hipops
+from sparsespatialsampling_amd.export import ExportData, _as_float
+logging.getLogger().setLevel(logging.WARNING)
+n, nc, t = 5_000_000, 461_130, int(sys.argv[1]) if len(sys.argv) > 1 else 25
+rng = np.random.default_rng(0)
+x = rng.random((n, 3)) * [2.4, 2.0, 0.314]
+centers = rng.random((nc, 3)) * [2.4, 2.0, 0.314]
+s = types.SimpleNamespace(n_dimensions=3, faces=pt.zeros((nc, 8), dtype=pt.int32), centers=pt.from_numpy(centers),
+                          vertices=pt.zeros((8, 3)), levels=pt.ones((nc, 1), dtype=pt.int64), metric=pt.rand(n),
+                          size_initial_cell=2.4, save_path="/tmp", save_name="probe", grid_name="g")
+ex = ExportData(s, write_times=[str(i) for i in range(4 * t)])
+coords = pt.from_numpy(x)
+ex._fit_data(coords, pt.randn((n, 1, t), dtype=pt.float32), "p", 4 * t)          # builds the caches
+def tick():
+    pt.cuda.synchronize(); return time.perf_counter()
+for rep in range(3):
+    data = pt.randn((n, 1, t), dtype=pt.float32)
+    t0 = tick()
+    batch = ex._upload(_as_float(data)); t1 = tick()
+    dev = ex._table_centers.apply(batch); t2 = tick()
+    out = ex._download(dev, 1, t, "centers"); t3 = tick()
+    print(f"T={t}: upload {1e3*(t1-t0):6.1f}  interp {1e3*(t2-t1):5.2f}  transpose + download {1e3*(t3-t2):6.1f} ms   "
+          f"(total {1e3*(t3-t0):.1f})", flush=True)

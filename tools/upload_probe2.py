@@ -17,7 +17,14 @@ for T in (25, 200):
         rows.copy_(d); pt.cuda.synchronize()
         dt = time.perf_counter() - t0
         print(f"T={T} direct copy_ of a fresh tensor: {dt*1e3:7.1f} ms {gb/dt:5.1f} GB/s", flush=True)
-    for n_thr, slab_mb in ((8, 64), (16, 64), (16, 128), (32, 128)):
+    for rep in range(4):
+        d = fresh()
+        pt.cuda.synchronize(); t0 = time.perf_counter()
+        hipops.upload_rows(d, rows); pt.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print(f"T={T} native staged upload (s3_upload_rows): {dt*1e3:7.1f} ms {gb/dt:5.1f} GB/s", flush=True)
+    chk = fresh(); hipops.upload_rows(chk, rows); pt.cuda.synchronize(); assert pt.equal(rows.cpu(), chk)
+    for n_thr, slab_mb in ((16, 128),):
         slab = max(1, slab_mb * (1 << 20) // (T * 4))
         pins = [pt.empty((slab, T), dtype=pt.float32).pin_memory() for _ in range(3)]
         evs = [pt.cuda.Event() for _ in range(3)]

@@ -48,12 +48,24 @@ def synchronize():
 
 
 def to_device(x, dtype=None):
-    """numpy / CPU tensor / CUDA tensor -> contiguous CUDA tensor (optionally cast)."""
+    """numpy / CPU tensor / CUDA tensor -> contiguous CUDA tensor (optionally cast).  Large host tensors go through the
+    native staged upload (s3_upload_rows), small ones through a plain copy."""
     if isinstance(x, np.ndarray):
         x = pt.from_numpy(np.ascontiguousarray(x))
     if dtype is not None and x.dtype != dtype:
         x = x.to(dtype)
-    return x.to(device(), non_blocking=False).contiguous()
+    dev = device()
+    if x.is_cuda or not x.is_contiguous() or x.numel() * x.element_size() < (32 << 20):
+        return x.to(dev, non_blocking=False).contiguous()
+    out = pt.empty(x.shape, dtype=x.dtype, device=dev)
+    flat_h, flat_d = x.reshape(-1), out.reshape(-1)
+    row = (1 << 20) // x.element_size()                     # 1-MiB rows, pitch = row length
+    n_full = flat_h.numel() // row
+    upload_rows(flat_h[:n_full * row].view(n_full, row), flat_d[:n_full * row].view(n_full, row))
+    if n_full * row < flat_h.numel():
+        flat_d[n_full * row:].copy_(flat_h[n_full * row:])
+    synchronize()                                           # the caller may release or overwrite x
+    return out
 
 
 class KnnIndex:

@@ -164,6 +164,13 @@ int s3_interp(const double *d_w /*[nc,k]*/, const int32_t *d_idx /*[nc,k]*/, int
  * sink (one dataset per snapshot, export.py:283-299) gets contiguous snapshots instead of slicing out[:, :, i] on the host. */
 int s3_snapshot_major(const double *d_in, int64_t nc, int n_comp, int64_t n_snapshots, double *d_out, s3_stream stream);
 
+/* Metric upstream of S^3 (what the reference's example scripts compute with torch before the grid is generated:
+ * metric = pt.std(field, dim=1), examples/s3_for_OAT15_airfoil.py:91): temporal mean and standard deviation of every row
+ * of a snapshot matrix [n_rows][row_len] (row pitch in_stride elements, 0 = row_len), f64 accumulation, one pass over
+ * the data.  ddof = 1: torch's default (unbiased), 0: population.  Either output may be NULL. */
+int s3_row_moments(const void *d_data, int dtype, int64_t n_rows, int64_t row_len, int64_t in_stride, int ddof,
+                   double *d_mean /*[n_rows] or NULL*/, double *d_std /*[n_rows] or NULL*/, s3_stream stream);
+
 /* Planned form of a17 for a static neighbour table (the table ExportData caches at export.py:431-432 and reuses for
  * every snapshot batch and field): the plan de-duplicates the source rows of spatially adjacent cells once (built on the
  * device; Hilbert order of d_centers[nc,dim] when given), the kernel then stages each distinct row once per tile in LDS.

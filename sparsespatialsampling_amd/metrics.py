@@ -1,0 +1,46 @@
+"""
+Metric fields upstream of S^3: the temporal statistics the reference's example scripts compute with torch on the CPU
+before they hand a metric to ``SparseSpatialSampling`` (``metric = pt.std(field, dim=1)``,
+examples/s3_for_OAT15_airfoil.py:91).  One streaming pass over the snapshot matrix on the GPU
+(``s3_row_moments``, csrc/metric.hip): f64 accumulation, results equal to ``torch.std`` / ``torch.mean`` of the float64
+data to rounding (1e-12 relative).
+"""
+import ctypes as C
+
+import numpy as np
+import torch as pt
+
+from . import _lib, hipops
+
+
+def temporal_moments(field: pt.Tensor, unbiased: bool = True):
+    """mean and standard deviation over the last axis of ``field`` ([N, T] or [N, n_comp, T], float32 / float64, host or
+    device) -> (mean, std) float64 tensors of shape ``field.shape[:-1]`` on the device the field came from"""
+    if field.dim() < 2:
+        raise ValueError(f"expected a field of shape [N, T] or [N, n_comp, T], got {tuple(field.shape)}")
+    if field.dtype not in hipops.DTYPE_CODE:
+        field = field.to(pt.float64)
+    on_host = not field.is_cuda
+    dev = hipops.to_device(field)
+    t = int(dev.shape[-1])
+    n_rows = int(np.prod(dev.shape[:-1]))
+    mean = pt.empty(n_rows, dtype=pt.float64, device=dev.device)
+    std = pt.empty(n_rows, dtype=pt.float64, device=dev.device)
+    hipops.check(_lib.hip_lib().s3_row_moments(C.c_void_p(dev.data_ptr()), hipops.DTYPE_CODE[dev.dtype], n_rows, t, t,
+                                               1 if unbiased else 0, C.c_void_p(mean.data_ptr()),
+                                               C.c_void_p(std.data_ptr()), hipops._stream()), "s3_row_moments")
+    mean, std = mean.reshape(dev.shape[:-1]), std.reshape(dev.shape[:-1])
+    if on_host:
+        hipops.synchronize()
+        return mean.cpu(), std.cpu()
+    return mean, std
+
+
+def temporal_std(field: pt.Tensor, unbiased: bool = True) -> pt.Tensor:
+    """``torch.std(field, dim=-1)`` (unbiased by default, as torch) computed in float64 in one pass on the GPU"""
+    return temporal_moments(field, unbiased)[1]
+
+
+def temporal_mean(field: pt.Tensor) -> pt.Tensor:
+    """``torch.mean(field, dim=-1)`` computed in float64 on the GPU"""
+    return temporal_moments(field)[0]

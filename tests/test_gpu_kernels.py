@@ -427,3 +427,45 @@ def test_cell_range_shards_reassemble(ops):
         parts.append(plan.interp(w[b:e].contiguous(), data))
     assert pt.equal(pt.cat(parts), full)        # same neighbour order per cell -> bit-identical rows
     knn.close()
+
+
+# ---- metric upstream of S^3 ----------------------------------------------------------------------
+@pytest.mark.parametrize("shape,dtype", [((3000, 1000), pt.float32), ((500, 3, 400), pt.float32), ((4000, 25), pt.float32),
+                                         ((1000, 7), pt.float64), ((300, 5000), pt.float32), ((64, 2, 33), pt.float64),
+                                         ((10, 1), pt.float32), ((1, 4096), pt.float32), ((2000, 130), pt.float32)])
+def test_temporal_moments(shape, dtype):
+    """temporal mean / standard deviation kernel against torch in float64 (tolerance 1e-12 relative: both accumulate in
+    f64, the summation orders differ); vector widths 4 / 2 / 1, every lanes-per-row variant, ragged tails, several chunks
+    per lane, host and device input, biased and unbiased"""
+    from sparsespatialsampling_amd import metrics
+    gen = pt.Generator().manual_seed(sum(shape))
+    field = (pt.randn(shape, generator=gen, dtype=pt.float64) * 3.0 + 10.0 * pt.rand(shape[:-1] + (1,), generator=gen,
+                                                                                     dtype=pt.float64)).to(dtype)
+    ref_mean, ref_std = field.double().mean(-1), field.double().std(-1)
+    mean, std = metrics.temporal_moments(field)                          # host in -> host out
+    assert not mean.is_cuda and mean.shape == field.shape[:-1] and std.dtype == pt.float64
+    assert pt.allclose(mean, ref_mean, rtol=1e-12, atol=1e-13)
+    if shape[-1] > 1:
+        assert pt.allclose(std, ref_std, rtol=1e-12, atol=0)
+        biased = metrics.temporal_std(field.cuda(), unbiased=False)      # device in -> device out
+        assert biased.is_cuda and pt.allclose(biased.cpu(), field.double().std(-1, unbiased=False), rtol=1e-12, atol=0)
+    else:
+        assert bool(pt.isnan(std).all())                                 # torch: std of one sample is NaN
+    assert pt.equal(metrics.temporal_mean(field), mean)
+
+
+def test_temporal_std_is_a_valid_metric():
+    """the example workflow: metric = std over time -> SamplingTree (same grid as with torch's std of the f64 data when
+    the two metrics agree to rounding)"""
+    from sparsespatialsampling_amd import geometry, metrics
+    from sparsespatialsampling_amd.s_cube import SamplingTree
+    rng = np.random.default_rng(3)
+    x = rng.random((4000, 2))
+    t = np.arange(64.0)
+    field = pt.from_numpy((np.exp(-8 * np.abs(x[:, 1:2] - 0.5)) * np.sin(6.0 * x[:, 0:1] - 0.3 * t[None, :])).astype(np.float32))
+    metric = metrics.temporal_std(field)
+    assert pt.allclose(metric, field.double().std(-1), rtol=1e-12, atol=0)
+    tree = SamplingTree(pt.from_numpy(x), metric, [geometry.CubeGeometry("domain", True, [0, 0], [1, 1])], uniform_level=3,
+                        min_metric=0.6)
+    tree.refine()
+    assert len(tree.all_centers) > 64

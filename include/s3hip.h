@@ -57,6 +57,11 @@ int s3_stream_synchronize(s3_stream stream);
  * bytes between row_bytes and dst_pitch_bytes of every row but the last are padding and may be overwritten. */
 int s3_upload_rows(const void *h_src, int64_t n_rows, int64_t row_bytes, void *d_dst, int64_t dst_pitch_bytes,
                    s3_stream stream);
+/* the same for a selection of the host rows: row h_rows[i] of h_src becomes device row i.  A generated grid references
+ * only the source points near its cell centres (k neighbours each): uploading just those rows cuts the PCIe volume by
+ * the sparsity of the grid. */
+int s3_upload_rows_indexed(const void *h_src, const int32_t *h_rows /*[n_sel]*/, int64_t n_sel, int64_t row_bytes,
+                           void *d_dst, int64_t dst_pitch_bytes, s3_stream stream);
 
 /* ---- KNN index over the original CFD points -------------------------------------------------------------------
  * Replaces KNeighborsRegressor(...).fit(vertices, target)           s_cube.py:161-163

@@ -55,8 +55,9 @@ hipError_t upload_lane_init(UploadLane &l) {
 
 extern "C" {
 
-int s3_upload_rows(const void *h_src, int64_t n_rows, int64_t row_bytes, void *d_dst, int64_t dst_pitch_bytes,
-                   s3_stream stream) try {
+// h_rows == NULL: rows 0..n_rows-1 of h_src; otherwise the rows listed in h_rows[n_rows] (any order), packed on the device
+static int upload_rows_impl(const void *h_src, const int32_t *h_rows, int64_t n_rows, int64_t row_bytes, void *d_dst,
+                            int64_t dst_pitch_bytes, s3_stream stream) try {
     using namespace s3;
     S3_REQUIRE(n_rows >= 0 && row_bytes >= 0 && dst_pitch_bytes >= row_bytes, "s3_upload_rows: bad shape");
     if (n_rows == 0 || row_bytes == 0) return S3_OK;
@@ -84,23 +85,29 @@ int s3_upload_rows(const void *h_src, int64_t n_rows, int64_t row_bytes, void *d
             const int64_t r0 = c * rows_per_chunk, rows = std::min(rows_per_chunk, n_rows - r0);
             hipError_t e = hipEventSynchronize(l.ev[b]);             // the buffer's previous transfer has left it
             if (e == hipSuccess) {
-                const char *src = static_cast<const char *>(h_src) + r0 * row_bytes;
+                const char *base = static_cast<const char *>(h_src);
                 char *stage = static_cast<char *>(l.pinned[b]);
                 char *dst = static_cast<char *>(d_dst) + r0 * dst_pitch_bytes;
-                if (row_bytes == dst_pitch_bytes) {
-                    std::memcpy(stage, src, (size_t)(rows * row_bytes));
+                // long rows are packed in the pinned buffer and the 2-D copy converts the pitch (4000-byte rows: 49 GB/s);
+                // short rows are laid out with the device pitch on the host and go up as one contiguous copy (100-byte
+                // rows: 32 GB/s, 21 GB/s as a 2-D copy); the padding of the chunk's last row is left alone
+                const bool pitched = row_bytes != dst_pitch_bytes && row_bytes < 512;
+                const int64_t step = pitched ? dst_pitch_bytes : row_bytes;
+                if (h_rows) {
+                    for (int64_t r = 0; r < rows; ++r)
+                        std::memcpy(stage + r * step, base + (int64_t)h_rows[r0 + r] * row_bytes, (size_t)row_bytes);
+                } else if (pitched) {
+                    for (int64_t r = 0; r < rows; ++r) std::memcpy(stage + r * step, base + (r0 + r) * row_bytes, (size_t)row_bytes);
+                } else {
+                    std::memcpy(stage, base + r0 * row_bytes, (size_t)(rows * row_bytes));
+                }
+                if (row_bytes == dst_pitch_bytes)
                     e = hipMemcpyAsync(dst, stage, (size_t)(rows * row_bytes), hipMemcpyHostToDevice, st);
-                } else if (row_bytes >= 512) {
-                    // long rows: packed in the pinned buffer, the 2-D copy converts the pitch (4000-byte rows: 49 GB/s)
-                    std::memcpy(stage, src, (size_t)(rows * row_bytes));
+                else if (pitched)
+                    e = hipMemcpyAsync(dst, stage, (size_t)((rows - 1) * dst_pitch_bytes + row_bytes), hipMemcpyHostToDevice, st);
+                else
                     e = hipMemcpy2DAsync(dst, (size_t)dst_pitch_bytes, stage, (size_t)row_bytes, (size_t)row_bytes, (size_t)rows,
                                          hipMemcpyHostToDevice, st);
-                } else {
-                    // short rows: laid out with the device pitch on the host, one contiguous copy (100-byte rows: 32 GB/s,
-                    // 21 GB/s as a 2-D copy); the padding of the chunk's last row is left alone
-                    for (int64_t r = 0; r < rows; ++r) std::memcpy(stage + r * dst_pitch_bytes, src + r * row_bytes, (size_t)row_bytes);
-                    e = hipMemcpyAsync(dst, stage, (size_t)((rows - 1) * dst_pitch_bytes + row_bytes), hipMemcpyHostToDevice, st);
-                }
             }
             if (e == hipSuccess) e = hipEventRecord(l.ev[b], st);
             if (e != hipSuccess) { first_error = (int)e; break; }
@@ -116,6 +123,17 @@ int s3_upload_rows(const void *h_src, int64_t n_rows, int64_t row_bytes, void *d
 } catch (const std::exception &e) {          // thread creation
     s3::set_error("s3_upload_rows: %s", e.what());
     return S3_ENOMEM;
+}
+
+int s3_upload_rows(const void *h_src, int64_t n_rows, int64_t row_bytes, void *d_dst, int64_t dst_pitch_bytes,
+                   s3_stream stream) {
+    return upload_rows_impl(h_src, nullptr, n_rows, row_bytes, d_dst, dst_pitch_bytes, stream);
+}
+
+int s3_upload_rows_indexed(const void *h_src, const int32_t *h_rows, int64_t n_sel, int64_t row_bytes, void *d_dst,
+                           int64_t dst_pitch_bytes, s3_stream stream) {
+    S3_REQUIRE(n_sel == 0 || h_rows != nullptr, "s3_upload_rows_indexed: null row list");
+    return upload_rows_impl(h_src, h_rows, n_sel, row_bytes, d_dst, dst_pitch_bytes, stream);
 }
 
 const char *s3_last_error(void) { return s3::g_err; }

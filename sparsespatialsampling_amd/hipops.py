@@ -229,6 +229,23 @@ def upload_rows(host, rows):
     return rows
 
 
+def upload_rows_indexed(host, row_ids, rows):
+    """rows ``row_ids`` (ascending int32 numpy array) of the contiguous host tensor [n, row_len] -> device rows ``rows``
+    [len(row_ids), row_len] (see ``upload_rows``)"""
+    if host.is_cuda or not host.is_contiguous() or host.dim() != 2 or host.dtype != rows.dtype:
+        raise TypeError("upload_rows_indexed: contiguous 2-D host tensor of the rows' dtype required")
+    ids = np.ascontiguousarray(row_ids, dtype=np.int32)
+    if not rows.is_cuda or rows.dim() != 2 or rows.stride(1) != 1 or tuple(rows.shape) != (len(ids), int(host.shape[1])):
+        raise TypeError("upload_rows_indexed: device rows [len(row_ids), row_len] with unit inner stride required")
+    if len(ids) and (int(ids.min()) < 0 or int(ids.max()) >= int(host.shape[0])):
+        raise IndexError("upload_rows_indexed: row id outside the host tensor")
+    item = host.element_size()
+    check(_lib.hip_lib().s3_upload_rows_indexed(C.c_void_p(host.data_ptr()), ids.ctypes.data_as(C.c_void_p), len(ids),
+                                                int(host.shape[1]) * item, C.c_void_p(rows.data_ptr()),
+                                                int(rows.stride(0)) * item, _stream()), "s3_upload_rows_indexed")
+    return rows
+
+
 def padded_rows(n_rows, row_len, dtype, dev, extra_lines=0):
     """[n_rows, row_len] view of a device buffer whose row pitch is a whole number of 128-byte lines (upload target for
     snapshot batches: every 128-B segment the planned kernel stages then sits on exactly one cache line).  For long rows

@@ -167,6 +167,14 @@ def test_upload_rows(ops, n, row_len, dtype):
     assert pt.equal(dense.cpu(), host)
     with pytest.raises(TypeError):
         ops.upload_rows(host.t(), rows)
+    # a selection of the rows (what a sparse grid references)
+    ids = np.unique(np.random.default_rng(n).integers(0, n, max(1, n // 3))).astype(np.int32)
+    part = ops.padded_rows(len(ids), row_len, dtype, "cuda")
+    ops.upload_rows_indexed(host, ids, part)
+    ops.synchronize()
+    assert pt.equal(part.cpu(), host[pt.from_numpy(ids).long()])
+    with pytest.raises(IndexError):
+        ops.upload_rows_indexed(host, np.array([n], dtype=np.int32), ops.padded_rows(1, row_len, dtype, "cuda"))
 
 
 @pytest.mark.parametrize("nc,ncomp,t", [(1000, 1, 25), (777, 3, 40), (33, 2, 1), (5, 1, 70)])

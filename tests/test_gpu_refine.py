@@ -94,7 +94,10 @@ def test_export_pipeline_gpu(tmp_path):
     ref = orc.interp(orc.idw_weights(dist_o), idx_o, data)
     got = ex._interpolated_fields.centers.numpy()
     assert got.shape == ref.shape and np.abs(got - ref).max() <= 1e-13 * np.abs(ref).max()
-    assert np.array_equal(ex._table_centers.idx.cpu().numpy(), idx_o)
+    table = ex._table_centers.idx.cpu().numpy()
+    if ex._used_rows is not None:                               # the table addresses the referenced rows by position
+        table = ex._used_rows.cpu().numpy()[table]
+    assert np.array_equal(table, idx_o)
     ref_metric = orc.interp(orc.idw_weights(dist_o), idx_o, y)
     assert np.abs(ex._metric.numpy() - ref_metric).max() <= 1e-13 * np.abs(ref_metric).max()
 
@@ -167,15 +170,18 @@ def test_bench_small_workload_matches_reference():
     assert np.array_equal(tree.all_centers.numpy(), z["all_centers"])
 
 
-@pytest.mark.parametrize("t,ncomp,on_gpu", [(8, 1, False), (12, 3, False), (8, 2, True), (5, 1, True)])
-def test_export_fit_paths_gpu(tmp_path, t, ncomp, on_gpu):
-    """ExportData._fit_data through every transport: padded-row upload + LDS-tiled kernel (rows 16-byte aligned), direct
-    kernel (ragged rows), data already on the GPU, interpolation at the vertices, batches -- against the oracle"""
+@pytest.mark.parametrize("t,ncomp,on_gpu,n,nc", [(8, 1, False, 20000, 3000), (12, 3, False, 20000, 3000), (8, 2, True, 20000, 3000),
+                                                 (5, 1, True, 20000, 3000), (8, 1, False, 150000, 400), (5, 3, False, 150000, 400),
+                                                 (8, 2, True, 150000, 400)])
+def test_export_fit_paths_gpu(tmp_path, t, ncomp, on_gpu, n, nc):
+    """ExportData._fit_data through every transport: staged upload into padded rows + LDS-tiled kernel (rows 16-byte
+    aligned), direct kernel (ragged rows), data already on the GPU, interpolation at the vertices, batches, and the
+    upload of the referenced source rows only when the grid is sparse -- against the oracle"""
     import types
     from sparsespatialsampling_amd.export import ExportData
     from oracle import s3_oracle as orc
     rng = np.random.default_rng(t * 10 + ncomp)
-    n, nc, nv = 20000, 3000, 1500
+    nv = nc // 2                                                 # n = 150000: the grid references a fraction of the points
     x = rng.random((n, 3))
     centers, vertices = rng.random((nc, 3)), rng.random((nv, 3))
     s = types.SimpleNamespace(n_dimensions=3, faces=None, centers=pt.from_numpy(centers), vertices=pt.from_numpy(vertices),
@@ -195,6 +201,9 @@ def test_export_fit_paths_gpu(tmp_path, t, ncomp, on_gpu):
             assert np.abs(got.numpy() - ref).max() <= 1e-13 * np.abs(ref).max()
             assert got[:, :, 0].is_contiguous()              # snapshot-major memory: what the writer stores per time
     assert ex._snapshot_counter == 2 * t
+    assert (ex._used_rows is not None) == (n > 100000)          # sparse grid: only the referenced source rows go up
+    if ex._used_rows is not None:
+        assert ex._used_rows.numel() == len(np.unique(np.concatenate([idx_c.ravel(), idx_v.ravel()])))
 
 
 def test_c1_cylinder2d_full_size_matches_reference():

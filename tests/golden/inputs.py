@@ -54,10 +54,24 @@ REFINE_CASES = {
     # 2-D: triangular body refined to a fixed level
     "refine_2d_triangle": dict(d=2, seed=77, n=5000, lo=[0.0, 0.0], hi=[2.2, 0.41], body="triangle",
                                kw=dict(uniform_level=3, min_metric=0.5)),
+    # 2-D, OAT15-like (BASELINE config C2 reduced): clustered cloud, NACA outline as GeometryCoordinates2D (refined),
+    # n_cells_max stopping.  The reference evaluates the outline through shapely; the generator's stand-in
+    # (ref_stubs.py) is the strict-interior rule the reference's own tests pin
+    "refine_2d_polygon": dict(d=2, seed=79, n=40000, lo=[-0.2, -0.5], hi=[1.2, 0.5], body="polygon",
+                              kw=dict(uniform_level=4, n_cells=6000)),
     # 3-D: prism + tetrahedron + (refined) pyramid bodies in one domain
     "refine_3d_polytopes": dict(d=3, seed=78, n=9000, lo=[0.0, 0.0, 0.0], hi=[1.0, 1.0, 1.0], body="polytopes",
                                 kw=dict(uniform_level=2, min_metric=0.4)),
 }
+
+
+def naca_outline(n=120, chord=1.0, t=0.12):
+    """closed NACA-00xx outline (the OAT15-like body of BASELINE config C2)"""
+    xs = 0.5 * (1 - np.cos(np.linspace(0, np.pi, n // 2)))
+    yt = 5 * t * (0.2969 * np.sqrt(xs) - 0.126 * xs - 0.3516 * xs ** 2 + 0.2843 * xs ** 3 - 0.1036 * xs ** 4)
+    upper = np.stack([xs, yt], 1)
+    lower = np.stack([xs[::-1], -yt[::-1]], 1)[1:-1]
+    return np.concatenate([upper, lower]) * chord
 
 
 def refine_inputs(name, geometry):
@@ -65,6 +79,15 @@ def refine_inputs(name, geometry):
     case = REFINE_CASES[name]
     d = case["d"]
     x = cloud(case["seed"], case["n"], case["lo"], case["hi"])
+    if case["body"] == "polygon":
+        rng = np.random.default_rng(case["seed"])
+        poly = naca_outline()
+        x = np.concatenate([rng.random((case["n"] * 3 // 4, 2)) * [1.4, 1.0] + [-0.2, -0.5],
+                            poly[rng.integers(0, len(poly), case["n"] // 4)] + 0.03 * rng.standard_normal((case["n"] // 4, 2))])
+        y = 0.05 + np.exp(-8 * np.abs(x[:, 1])) * (1 + np.sin(6 * x[:, 0]) ** 2)
+        geos = [geometry.CubeGeometry("domain", True, case["lo"], case["hi"]),
+                geometry.GeometryCoordinates2D("airfoil", False, poly, refine=True, min_refinement_level=8)]
+        return x, y, geos, case["kw"]
     if case["body"] == "triangle":
         centre = [0.4, 0.2]
         body = geometry.TriangleGeometry("wedge", False, [(0.3, 0.1), (0.6, 0.2), (0.3, 0.3)], refine=True,

@@ -27,7 +27,8 @@ def test_uniform_tables_gpu(d):
 
 
 @pytest.mark.parametrize("name", ["refine_2d_metric", "refine_2d_ncells", "refine_2d_delta", "refine_3d_metric",
-                                  "refine_3d_delta", "refine_3d_ncells_cone", "refine_2d_triangle", "refine_3d_polytopes"])
+                                  "refine_3d_delta", "refine_3d_ncells_cone", "refine_2d_triangle", "refine_3d_polytopes",
+                                  "refine_2d_polygon"])
 def test_refine_matches_reference_gpu(name):
     """cell ids / levels / centres / faces / vertices / per-cell metric + gain: bit-exact vs the real reference"""
     import sparsespatialsampling_amd.s_cube as s_cube

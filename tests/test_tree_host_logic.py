@@ -73,7 +73,8 @@ def test_uniform_tables(oracle_backend, d):
 
 
 @pytest.mark.parametrize("name", ["refine_2d_metric", "refine_2d_ncells", "refine_2d_delta", "refine_3d_metric",
-                                  "refine_3d_delta", "refine_3d_ncells_cone", "refine_2d_triangle", "refine_3d_polytopes"])
+                                  "refine_3d_delta", "refine_3d_ncells_cone", "refine_2d_triangle", "refine_3d_polytopes",
+                                  "refine_2d_polygon"])
 def test_refine_matches_reference(oracle_backend, name):
     z = load(name)
     x, y, geos, kw = refine_inputs(name, geometry)

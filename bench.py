@@ -184,7 +184,7 @@ def main():
 
     # ---- KNN cache (once) -------------------------------------------------------------------------------------
     t0 = time.perf_counter()
-    knn = hipops.KnnIndex(x)
+    knn = hipops.KnnIndex(x, hipops.knn_occupancy(k, 3))
     idx, dist_ = knn.query(centers, k)
     w = hipops.idw_weights(dist_)
     pt.cuda.synchronize()

@@ -332,14 +332,32 @@ __device__ __forceinline__ void kb_offer(KBest &b, double d, int32_t p, const in
 template <int DIM>
 __device__ __forceinline__ void scan_range(KBest &b, const double *__restrict__ pts, const int32_t *__restrict__ orig,
                                            const double (&q)[DIM], int32_t p0, int32_t p1) {
+    if (p0 >= p1) return;
+    // the coordinates of the next two points are requested before the current one is offered to the list (whose
+    // insertion is a data-dependent LDS loop the compiler does not move loads across): the search is bound by the
+    // latency of these loads
+    double c0[DIM], c1[DIM];
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) {
+        c0[j] = pts[(int64_t)p0 * DIM + j];
+        c1[j] = pts[(int64_t)min(p0 + 1, p1 - 1) * DIM + j];
+    }
     for (int32_t p = p0; p < p1; ++p) {
+        double c2[DIM];
+#pragma unroll
+        for (int j = 0; j < DIM; ++j) c2[j] = pts[(int64_t)min(p + 2, p1 - 1) * DIM + j];
         double d = 0.0;
 #pragma unroll
         for (int j = 0; j < DIM; ++j) {
-            double t = q[j] - pts[(int64_t)p * DIM + j];
+            double t = q[j] - c0[j];
             d += t * t;
         }
         kb_offer(b, d, p, orig);
+#pragma unroll
+        for (int j = 0; j < DIM; ++j) {
+            c0[j] = c1[j];
+            c1[j] = c2[j];
+        }
     }
 }
 

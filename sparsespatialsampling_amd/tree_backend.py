@@ -27,7 +27,7 @@ class HipTreeBackend:
     def __init__(self, vertices, target, k):
         self.dev = hipops.device()
         self.k = int(k)
-        self.knn = hipops.KnnIndex(vertices)
+        self.knn = hipops.KnnIndex(vertices, hipops.knn_occupancy(int(k), int(vertices.shape[1])))
         self.knn.set_values(target)
         self.dim = self.knn.dim
         self.nch = 2 ** self.dim

@@ -41,6 +41,7 @@ def _cpu_ops():
     ops.InterpPlan = type("InterpPlan", (), {"__init__": lambda self, *a, **k: None,
                                             "supports": staticmethod(lambda k, d: False)})
     ops.padded_rows = None      # never reached: supports() is False on the CPU stand-in
+    ops.knn_occupancy = lambda k, dim: 0.0
     ops.upload_rows = lambda host, rows: rows.copy_(host)
     ops.upload_rows_indexed = lambda host, ids, rows: rows.copy_(host[pt.from_numpy(np.asarray(ids)).long()])
     ops.snapshot_major = lambda v, n_comp, n_snap: v.reshape(v.shape[0], n_comp, n_snap).permute(2, 0, 1).contiguous()

@@ -25,5 +25,10 @@ c = rng.random((40_000, 3)) * [2.4, 2.0, 0.314]
 d = np.array([[0, 0, 0]] + [[sx, sy, sz] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)], dtype=np.float64) * 0.002
 qc = pt.from_numpy((c[:, None, :] + d[None]).reshape(-1, 3)).cuda()
 print(f"idw_predict 40k x 9 grouped queries k=26: {timeit(lambda: knn.predict(qc, 26)):.3f} ms", flush=True)
+# the same groups visited in a spatially coherent order (what sorting a refine batch by cell position would give)
+key = (np.floor(c[:, 2] / 0.314 * 16) * 256 + np.floor(c[:, 1] / 2.0 * 16)) * 256 + np.floor(c[:, 0] / 2.4 * 256)
+cs_ = c[np.argsort(key, kind="stable")]
+qs = pt.from_numpy((cs_[:, None, :] + d[None]).reshape(-1, 3)).cuda()
+print(f"idw_predict 40k x 9 grouped queries, cells sorted by position: {timeit(lambda: knn.predict(qs, 26)):.3f} ms", flush=True)
 qq = pt.from_numpy(rng.random((461_130, 3)) * [2.4, 2.0, 0.314]).cuda()
 print(f"knn query 461k k=26: {timeit(lambda: knn.query(qq, 26)):.3f} ms", flush=True)

@@ -20,3 +20,24 @@ def test_fuzz_tool(tool, seed, cases):
                          capture_output=True, text=True, timeout=600)
     tail = "\n".join((run.stdout + run.stderr).splitlines()[-15:])
     assert run.returncode == 0 and f"{cases} cases, 0 mismatches" in run.stdout, tail
+
+
+@pytest.mark.gpu
+def test_bench_contract_small_workload():
+    """bench.py on the reduced workload: exactly one line on stdout, valid JSON, the keys of the driver's contract plus the
+    roofline and cpu_baseline objects"""
+    import json
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "cylinder3D_small", "--steps", "3",
+                          "--warmup", "1"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stderr[-2000:]
+    lines = run.stdout.strip().splitlines()
+    assert len(lines) == 1, run.stdout[-2000:]
+    res = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in res, key
+    assert res["n_gpus"] == 1 and res["steps"] == 3 and res["warmup"] == 1 and res["higher_is_better"] is True
+    assert res["scaling"] == "weak" and res["vs_baseline"] is None and res["data"] == "synthetic" and "workload" in res["config"]
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(res["roofline"])
+    assert res["roofline"]["bound"] == "hbm" and 0 < res["roofline"]["frac"] < 1 and res["value"] > 0
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(res["cpu_baseline"]) and res["cpu_baseline"]["kind"] == "port"

@@ -392,20 +392,39 @@ __device__ __forceinline__ void ring_search(const Lattice<DIM> &L, const double 
     const int c2 = DIM == 3 ? c[DIM - 1] : 0;
     const int res2 = DIM == 3 ? L.res[DIM - 1] : 1;
 
+    // squared distance from q to the slab of bucket index i along axis j, shrunk a little to stay conservative (0 inside)
+    auto gap2 = [&](int j, int i) {
+        const double lo_i = L.lo[j] + (double)i * L.h[j];
+        const double g = fmax(lo_i - q[j], q[j] - (lo_i + L.h[j])) - 1e-9 * hmin;
+        return g > 0.0 ? g * g : 0.0;
+    };
     for (int r = 0; r <= rmax; ++r) {
         const int x0 = max(c[0] - r, 0), x1 = min(c[0] + r, L.res[0] - 1);
         const int y0 = max(c[1] - r, 0), y1 = min(c[1] + r, L.res[1] - 1);
         const int z0 = DIM == 3 ? max(c2 - r, 0) : 0, z1 = DIM == 3 ? min(c2 + r, res2 - 1) : 0;
         for (int z = z0; z <= z1; ++z) {
             const int dz = DIM == 3 ? abs(z - c2) : 0;
+            const double gz2 = DIM == 3 ? gap2(DIM - 1, z) : 0.0;
             for (int y = y0; y <= y1; ++y) {
                 const int dy = abs(y - c[1]);
                 const int64_t row = ((int64_t)z * L.res[1] + y) * L.res[0];
+                // once the list is full, a bucket whose box lies farther away than the current worst entry cannot
+                // contribute (the cube of a ring has eight times the volume of the sphere that matters): rows are
+                // skipped and runs clipped by that test -- a superset of the needed buckets is still visited, the result
+                // does not change
+                const bool full = b.cnt == b.k;
+                const double rest2 = gz2 + gap2(1, y);
+                if (full && rest2 > b.worst) continue;
                 if (max(dz, dy) == r) {
-                    run(row, y, z, x0, x1);            // the whole x-run of this row belongs to the ring
+                    int xa = x0, xb = x1;             // the whole x-run of this row belongs to the ring
+                    if (full) {
+                        while (xa <= xb && rest2 + gap2(0, xa) > b.worst) ++xa;
+                        while (xb >= xa && rest2 + gap2(0, xb) > b.worst) --xb;
+                    }
+                    if (xa <= xb) run(row, y, z, xa, xb);
                 } else {
-                    if (c[0] - r >= 0) run(row, y, z, c[0] - r, c[0] - r);
-                    if (c[0] + r < L.res[0]) run(row, y, z, c[0] + r, c[0] + r);
+                    if (c[0] - r >= 0 && !(full && rest2 + gap2(0, c[0] - r) > b.worst)) run(row, y, z, c[0] - r, c[0] - r);
+                    if (c[0] + r < L.res[0] && !(full && rest2 + gap2(0, c[0] + r) > b.worst)) run(row, y, z, c[0] + r, c[0] + r);
                 }
             }
         }

@@ -612,6 +612,12 @@ class SamplingTree(object):
             self.data_final_mesh["t_geometry"] = None
             self.data_final_mesh["t_adaptive"] = t["t_start_renumber"] - t["t_start_adaptive"]
 
+    def close(self) -> None:
+        """release the device arrays, the KNN index and the native topology tables now instead of at garbage collection
+        (the result tensors ``all_centers``, ``all_levels``, ``all_nodes``, ``face_ids`` stay valid)"""
+        self._backend.close()
+        self._topo.close()
+
     def __len__(self):
         return self._n_cells
 

@@ -75,6 +75,7 @@ class SparseSpatialSampling:
         self.size_initial_cell = tree.data_final_mesh["size_initial_cell"]
 
         # drop the tree: frees the device arrays and leaves a CPU-only, picklable object
+        tree.close()
         self._sampling = None
         pt.save(self, os.path.join(self.save_path, f"s_cube_{self.save_name}.pt"))
 

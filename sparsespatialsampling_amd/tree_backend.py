@@ -146,4 +146,10 @@ class HipTreeBackend:
                     center=self.center[:n_cells].cpu().numpy(), level=self.level[:n_cells].cpu().numpy())
 
     def close(self):
+        """release the KNN index and every device array now (the owning tree may sit in a reference cycle that the
+        garbage collector only breaks later)"""
         self.knn.close()
+        self.center = self.level = self.metric = self.gain = self.leaf = None
+        self._parents = self._last_invalid = None
+        self._sumsq_out = self._sumsq_scratch = self.level_factor = None
+        self._poly_cache = {}

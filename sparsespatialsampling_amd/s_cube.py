@@ -17,6 +17,7 @@ The reference rejects nothing on the CPU; this implementation has no CPU compute
 """
 import ctypes as C
 import logging
+import threading
 from time import time
 from typing import Union
 
@@ -270,7 +271,8 @@ class SamplingTree(object):
         self._backend = _make_backend(vertices.detach().cpu().to(pt.float64).numpy(),
                                       target.detach().cpu().to(pt.float64).numpy(), self._k)
         self._values = None
-        self._topo = None
+        self._topo_engine = None
+        self._topo_pending = None        # join() of a topology update still running in its helper thread
         self._cells = _CellList(self)
         self._create_first_cell()
         # like the reference (s_cube.py:205) the norm is taken in the dtype the user passed (a float32 metric gives a
@@ -306,9 +308,18 @@ class SamplingTree(object):
             gain = 1.0
         self._gain0 = float(gain)
         self._n_cells += 1
-        self._topo = _Topology(nd, self._width, root)
+        self._topo_engine = _Topology(nd, self._width, root)
         self._backend.start(root, self._width, self._gain0, metric[0], self._gain0)
         self._leaf_cells.add(0)
+
+    @property
+    def _topo(self):
+        """the native topology tables; waits for an update that is still running (``_refine_batch``)"""
+        pending = self._topo_pending
+        if pending is not None:
+            self._topo_pending = None
+            pending()
+        return self._topo_engine
 
     def _cell_values(self):
         """metric / gain of all cells on the host (lazy download; used by the ``Cell`` views and the parity tests)"""
@@ -362,15 +373,36 @@ class SamplingTree(object):
     # ------------------------------------------------------------------------------------------------------------
     def _refine_batch(self, order: np.ndarray, uniform: bool):
         """create the children of the ordered parents: topology on the host, geometry + metric + gain on the device
-        (body shared by s_cube.py:531-555 and 879-900).  Returns (first new id, number of new cells)."""
+        (body shared by s_cube.py:531-555 and 879-900).  Returns (first new id, number of new cells): the ids of the new
+        cells are known up front (children are numbered consecutively from the current cell count), so the kernels are
+        launched first, the native topology engine then works in a helper thread (the foreign call releases the
+        interpreter lock) while the caller carries on with its set bookkeeping, the geometry masks, ...; the next access
+        to ``self._topo`` waits for it."""
         nch = 2 ** self._n_dimensions
-        # the ids of the new cells are known up front (children are numbered consecutively from the current cell count),
-        # so the kernels are launched first and the host topology work overlaps them
-        first = self._topo.n_cells
+        engine = self._topo                       # joins an earlier update
+        first = engine.n_cells
         n_new = self._backend.refine_batch(order, first)
-        first_topo = self._topo.refine(order, relink=uniform)
-        if first_topo != first or n_new != len(order) * nch or self._topo.n_cells != first + n_new:
+        if n_new != len(order) * nch:
             raise RuntimeError("host topology and device cell arrays disagree about the ids of the new cells")
+        result = {}
+
+        def work():
+            try:
+                result["first"] = engine.refine(order, relink=uniform)
+            except BaseException as err:          # handed to the caller by join()
+                result["error"] = err
+
+        worker = threading.Thread(target=work)
+        worker.start()
+
+        def join():
+            worker.join()
+            if "error" in result:
+                raise result["error"]
+            if result["first"] != first or engine.n_cells != first + n_new:
+                raise RuntimeError("host topology and device cell arrays disagree about the ids of the new cells")
+
+        self._topo_pending = join                 # taken by the next access to self._topo
         self._n_cells += n_new
         self._values = None
         return first, n_new
@@ -382,9 +414,9 @@ class SamplingTree(object):
         for j in range(self._min_level):
             logger.info(f"\r\tStarting iteration no. {j}, N_cells = {len(self._leaf_cells)}")
             order = np.fromiter(self._leaf_cells, dtype=np.int64, count=len(self._leaf_cells))
+            first, n_new = self._refine_batch(order, uniform=True)
             all_parents, all_children = set(), set()
             all_parents.update(order.tolist())
-            first, n_new = self._refine_batch(order, uniform=True)
             all_children.update(range(first, first + n_new))
             self._update_leaf_cells(all_parents, all_children)
             self._current_min_level += 1
@@ -396,12 +428,12 @@ class SamplingTree(object):
     def _refine_cells(self, to_refine: set):
         """s_cube.py:865-902; returns the id range of the new cells"""
         order = np.fromiter(to_refine, dtype=np.int64, count=len(to_refine))
+        if len(order):                            # levels of the parents, read before the tables start to change
+            self._current_max_level = max(self._current_max_level, int(self._topo.level[order].max()) + 1)
+        first, n_new = self._refine_batch(order, uniform=False)
         all_parents, all_children = set(), set()
         all_parents.update(order.tolist())
-        first, n_new = self._refine_batch(order, uniform=False)
         all_children.update(range(first, first + n_new))
-        if len(order):
-            self._current_max_level = max(self._current_max_level, int(self._topo.level[order].max()) + 1)
         self._update_leaf_cells(all_parents, all_children)
         return first, n_new
 
@@ -616,7 +648,7 @@ class SamplingTree(object):
         """release the device arrays, the KNN index and the native topology tables now instead of at garbage collection
         (the result tensors ``all_centers``, ``all_levels``, ``all_nodes``, ``face_ids`` stay valid)"""
         self._backend.close()
-        self._topo.close()
+        self._topo.close()                        # (waits for a running update first)
 
     def __len__(self):
         return self._n_cells

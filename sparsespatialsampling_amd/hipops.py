@@ -61,7 +61,10 @@ def to_device(x, dtype=None):
     flat_h, flat_d = x.reshape(-1), out.reshape(-1)
     row = (1 << 20) // x.element_size()                     # 1-MiB rows, pitch = row length
     n_full = flat_h.numel() // row
-    upload_rows(flat_h[:n_full * row].view(n_full, row), flat_d[:n_full * row].view(n_full, row))
+    try:
+        upload_rows(flat_h[:n_full * row].view(n_full, row), flat_d[:n_full * row].view(n_full, row))
+    except _lib.S3HipError:                                 # no page-locked staging memory on this host: plain copy
+        n_full = 0
     if n_full * row < flat_h.numel():
         flat_d[n_full * row:].copy_(flat_h[n_full * row:])
     synchronize()                                           # the caller may release or overwrite x

@@ -61,11 +61,23 @@ class _Topology:
             raise RuntimeError("topology engine: could not be created (dimension must be 2 or 3)")
 
     def close(self):
-        if self._h is not None and self._h.value:
-            self._lib.s3t_destroy(self._h)
-            self._h = None
+        h = getattr(self, "_h_raw", None)
+        if h is not None and h.value:
+            self._lib.s3t_destroy(h)
+        self._h_raw = None
 
     __del__ = close
+
+    @property
+    def _h(self):
+        h = getattr(self, "_h_raw", None)
+        if h is None:
+            raise RuntimeError("topology closed")
+        return h
+
+    @_h.setter
+    def _h(self, value):
+        self._h_raw = value
 
     @property
     def n_cells(self):

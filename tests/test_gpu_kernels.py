@@ -251,9 +251,11 @@ def test_knn_small_and_degenerate(ops, orc):
     x = rng.random((30, 3))
     x[:, 2] = 0.25                                   # flat cloud: zero extent in z
     knn = ops.KnnIndex(x)
-    idx, dist = knn.query(rng.random((40, 3)), 26)
-    idx_o, dist_o = orc.knn(x, np.random.default_rng(3).random((30 + 40, 3))[30:], 26)
+    q = rng.random((40, 3))
+    idx, dist = knn.query(q, 26)
+    idx_o, dist_o = orc.knn(x, q, 26)
     assert idx.shape == (40, 26)
+    assert np.array_equal(idx.cpu().numpy(), idx_o) and np.array_equal(dist.cpu().numpy(), dist_o)
     with pytest.raises(S3HipError):
         knn.query(rng.random((4, 3)), 31)            # k > n
     knn.close()

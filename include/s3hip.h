@@ -179,7 +179,10 @@ int s3_row_moments(const void *d_data, int dtype, int64_t n_rows, int64_t row_le
 /* Planned form of a17 for a static neighbour table (the table ExportData caches at export.py:431-432 and reuses for
  * every snapshot batch and field): the plan de-duplicates the source rows of spatially adjacent cells once (built on the
  * device; Hilbert order of d_centers[nc,dim] when given), the kernel then stages each distinct row once per tile in LDS.
- * Same results as s3_interp.  Rows must be 16-byte aligned (row_len % 4 == 0 for f32, % 2 == 0 for f64). */
+ * Same results as s3_interp.  Source rows must start on 16-byte boundaries and be readable up to the next multiple of
+ * 16 bytes (in_stride % 4 == 0 for f32 / % 2 == 0 for f64, in_stride >= row_len rounded up to that multiple); the row
+ * length itself is arbitrary (25-snapshot batches of examples/s3_for_cylinder3D_Re3900.py:28-69: pitch 28 or 32).
+ * Rows of up to 64 bytes take a short-row kernel (several workgroups per CU, no chunk pipeline). */
 typedef struct s3_interp_plan s3_interp_plan;
 int s3_interp_plan_create(const int32_t *d_idx /*[nc,k]*/, int64_t nc, int k, int64_t n_src,
                           const double *d_centers /*[nc,dim] or NULL*/, int dim, int tile_cells /*0 (=64), 64 or 128*/,
@@ -188,8 +191,30 @@ void s3_interp_plan_destroy(s3_interp_plan *plan);
 int s3_interp_plan_info(const s3_interp_plan *plan, int64_t *h_n_tiles, int64_t *h_total_rows);
 /* in_stride: elements between consecutive source rows of d_data (>= row_len; 0 = row_len).  Rows padded to a multiple
  * of 128 bytes keep every staged segment on one cache line. */
-int s3_interp_planned(const s3_interp_plan *plan, const double *d_w /*[nc,k]*/, const void *d_data, int dtype,
+/* the weights of the table, [nc,k] in the caller's cell order, are kept inside the plan in tile order (one contiguous
+ * stream per tile): set them once per KNN cache, then pass d_w = NULL to s3_interp_planned; a non-NULL d_w re-attaches
+ * the weights before the launch (one extra pass over the table) */
+int s3_interp_plan_set_weights(s3_interp_plan *plan, const double *d_w /*[nc,k]*/, s3_stream stream);
+int s3_interp_planned(s3_interp_plan *plan, const double *d_w /*[nc,k] or NULL*/, const void *d_data, int dtype,
                       int64_t row_len, int64_t in_stride, double *d_out /*[nc,row_len]*/, s3_stream stream);
+
+
+/* ---- device-side bookkeeping of the KNN cache (replaces torch.unique / fancy indexing on the a16 path) ----------
+ * A generated grid that is sparser than the CFD mesh references only part of the source rows (export.py:403-444 keeps
+ * the full table; here only the referenced rows are uploaded per batch):
+ *   s3_mark_rows     d_flag[idx[i]] = 1 for every entry of a neighbour table (d_flag zeroed by the caller, int32[n_src])
+ *   s3_compact_rows  d_flag -> remap in place (position among the marked rows, ascending row id; -1 = unused),
+ *                    d_used[0..n_used) = the marked row ids ascending; *h_n_used = their number
+ *   s3_remap_indices idx[i] = d_remap[idx[i]] in place
+ *   s3_gather_rows   d_dst row i (pitch dst_pitch_bytes) = d_src row ids[i] (ids NULL: row i), row_bytes % 4 == 0:
+ *                    the device-side form of the indexed upload for batches that already live in HBM, and the re-pitch
+ *                    of dense ragged rows for s3_interp_planned */
+int s3_mark_rows(const int32_t *d_idx, int64_t n, int64_t n_src, int32_t *d_flag, s3_stream stream);
+int s3_compact_rows(int32_t *d_flag_remap /*[n_src] in: 0/1, out: remap*/, int64_t n_src, int32_t *d_used /*[n_src]*/,
+                    int64_t *h_n_used, s3_stream stream);
+int s3_remap_indices(int32_t *d_idx, int64_t n, const int32_t *d_remap, int64_t n_src, s3_stream stream);
+int s3_gather_rows(const void *d_src, int64_t n_src_rows, int64_t row_bytes, int64_t src_pitch_bytes,
+                   const int32_t *d_ids /*[n] or NULL*/, int64_t n, void *d_dst, int64_t dst_pitch_bytes, s3_stream stream);
 
 #ifdef __cplusplus
 }

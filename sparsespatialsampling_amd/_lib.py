@@ -70,7 +70,12 @@ HIP_SIGNATURES = {
     "s3_interp_plan_create": (c_int, [c_vp, c_i64, c_int, c_i64, c_vp, c_int, c_int, c_vp, C.POINTER(c_vp)]),
     "s3_interp_plan_destroy": (None, [c_vp]),
     "s3_interp_plan_info": (c_int, [c_vp, C.POINTER(c_i64), C.POINTER(c_i64)]),
+    "s3_interp_plan_set_weights": (c_int, [c_vp, c_vp, c_vp]),
     "s3_interp_planned": (c_int, [c_vp, c_vp, c_vp, c_int, c_i64, c_i64, c_vp, c_vp]),
+    "s3_mark_rows": (c_int, [c_vp, c_i64, c_i64, c_vp, c_vp]),
+    "s3_compact_rows": (c_int, [c_vp, c_i64, c_vp, C.POINTER(c_i64), c_vp]),
+    "s3_remap_indices": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp]),
+    "s3_gather_rows": (c_int, [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp]),
 }
 
 TOPO_SIGNATURES = {

@@ -24,11 +24,14 @@
 #include "common.h"
 #include "plan_build.h"
 
+#include <cstdlib>
 #include <exception>
 
 struct s3_interp_plan : s3::PlanTables {
     int64_t nc = 0, n_src = 0;
     int k = 0, ucap = 0, tc = 64;
+    double *wp = nullptr;                // [nc*k] weights in the layout of `loc`: per tile [m][cell in tile]
+    bool has_weights = false;
 };
 
 namespace s3 {
@@ -40,11 +43,137 @@ template <typename T>
 struct Vec16;
 template <> struct Vec16<float> { using type = float4; static constexpr int N = 4; };
 template <> struct Vec16<double> { using type = double2; static constexpr int N = 2; };
+
+// `left` = elements of the output row at and after p (may be <= 0 or < N for the ragged tail of a row); full pieces of
+// rows with an even length are written as double2 (the row starts are then 16-byte aligned), everything else per element
+template <int N>
+__device__ __forceinline__ void store_piece(double *__restrict__ p, const double (&a)[N], int64_t left, bool even_rows) {
+    if (left >= N && even_rows) {
+#pragma unroll
+        for (int i = 0; i < N; i += 2) *reinterpret_cast<double2 *>(p + i) = make_double2(a[i], a[i + 1]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            if (i < left) p[i] = a[i];
+    }
+}
+
+// the tile's weights and LDS row positions: `n` consecutive entries of the plan-ordered streams ([m][cell in tile]) ->
+// LDS, same layout; eight loads per lane are in flight before the first LDS store
+__device__ __forceinline__ void stage_tile_tables(const double *__restrict__ wp, const uint16_t *__restrict__ loc, int n,
+                                                  double *__restrict__ s_w, uint16_t *__restrict__ s_loc, int block) {
+    constexpr int UN = 8;
+    for (int base = 0; base < n; base += block * UN) {
+        double wr[UN];
+        uint16_t lr[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int i = min(base + u * block + (int)threadIdx.x, n - 1);
+            wr[u] = wp[i];
+            lr[u] = loc[i];
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int i = base + u * block + (int)threadIdx.x;
+            if (i < n) {
+                s_w[i] = wr[u];
+                s_loc[i] = lr[u];
+            }
+        }
+    }
+}
+
+// weights of the caller's table [nc][k] -> plan order (one workgroup per tile)
+__global__ void __launch_bounds__(256)
+permute_weights_kernel(const int32_t *__restrict__ perm, const int32_t *__restrict__ tile_cell_begin,
+                       const double *__restrict__ w, int k, double *__restrict__ wp) {
+    const int c_begin = tile_cell_begin[blockIdx.x], n_c = tile_cell_begin[blockIdx.x + 1] - c_begin;
+    for (int i = threadIdx.x; i < n_c * k; i += 256) {
+        const int m = i / n_c, j = i - m * n_c;
+        wp[(int64_t)c_begin * k + i] = w[(int64_t)perm[c_begin + j] * k + m];
+    }
+}
+
+// Short rows (a few 128-byte lines: small snapshot batches such as the 16- or 25-snapshot batches of the reference's
+// cylinder3D script, examples/s3_for_cylinder3D_Re3900.py:28-69).  The per-tile start-up (weights, positions, row ids) is
+// most of the traffic here and there is no chunk sweep to pipeline, so this variant keeps its register count low enough
+// for three or four workgroups per CU, stages whole row pieces of `vc` <= 8 vectors with `vc` lanes per row and gives
+// every (cell, vector) pair of the tile to one lane.  Same plan tables, same arithmetic (f64 FMA in neighbour order).
+template <typename T, int TC>
+__global__ void __launch_bounds__(256, 3)
+interp_planned_short_kernel(const int32_t *__restrict__ perm, const int32_t *__restrict__ tile_cell_begin,
+                            const int32_t *__restrict__ tile_row_begin, const int32_t *__restrict__ rows,
+                            const uint16_t *__restrict__ loc, const double *__restrict__ w /*plan order*/, int k, int ucap,
+                            const T *__restrict__ data, int64_t row_len, int64_t in_stride, double *__restrict__ out,
+                            int64_t n_tiles, int64_t tiles_per_xcd, int vpr, int pitch) {
+    using V = typename Vec16<T>::type;
+    constexpr int EPV = Vec16<T>::N;
+    constexpr int BLOCK = 256;
+    constexpr int UN = 8;                                        // row pieces in flight per lane while staging
+    extern __shared__ float4 lds_raw[];
+    V *s_data = reinterpret_cast<V *>(lds_raw);                                  // [ucap][pitch] 16-byte vectors
+    double *s_w = reinterpret_cast<double *>(lds_raw + (size_t)ucap * pitch);    // [k][TC]
+    uint16_t *s_loc = reinterpret_cast<uint16_t *>(s_w + (size_t)k * TC);        // [k][TC]
+    int32_t *s_cell = reinterpret_cast<int32_t *>(s_loc + (size_t)k * TC);       // [TC] output rows of the tile's cells
+
+    const int64_t b = blockIdx.x;
+    const int64_t tile = (b & 7) * tiles_per_xcd + (b >> 3);     // XCD-aware (speed only)
+    if (tile >= n_tiles) return;
+    const int c_begin = tile_cell_begin[tile], n_c = tile_cell_begin[tile + 1] - c_begin;
+    const int r_begin = tile_row_begin[tile], n_r = tile_row_begin[tile + 1] - r_begin;
+    const bool even_rows = (row_len & 1) == 0;
+    if ((int)threadIdx.x < n_c) s_cell[threadIdx.x] = perm[c_begin + threadIdx.x];
+
+    for (int v_begin = 0; v_begin < vpr; v_begin += pitch) {
+        const int vc = min(pitch, vpr - v_begin);                // vectors of this piece
+        if (v_begin) __syncthreads();                            // the previous piece has been consumed
+        // stage the piece of every distinct row: UN independent 16-byte loads per lane before the LDS stores
+        const int n_items = n_r * vc;
+        for (int base = 0; base < n_items; base += BLOCK * UN) {
+            V reg[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int item = min(base + u * BLOCK + (int)threadIdx.x, n_items - 1);
+                const int r = item / vc, v = item - r * vc;
+                reg[u] = *reinterpret_cast<const V *>(data + (int64_t)rows[r_begin + r] * in_stride + (int64_t)(v_begin + v) * EPV);
+            }
+            if (base == 0 && v_begin == 0)     // issued behind the first row loads
+                stage_tile_tables(w + (int64_t)c_begin * k, loc + (int64_t)c_begin * k, n_c * k, s_w, s_loc, BLOCK);
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int item = base + u * BLOCK + (int)threadIdx.x;
+                if (item < n_items) {
+                    const int r = item / vc, v = item - r * vc;
+                    s_data[r * pitch + v] = reg[u];
+                }
+            }
+        }
+        __syncthreads();
+        for (int item = threadIdx.x; item < n_c * vc; item += BLOCK) {
+            const int cl = item / vc, v = item - cl * vc;
+            double acc[EPV];
+#pragma unroll
+            for (int i = 0; i < EPV; ++i) acc[i] = 0.0;
+#pragma unroll 8
+            for (int m = 0; m < k; ++m) {
+                const int pos = s_loc[m * n_c + cl];
+                const double wm = s_w[m * n_c + cl];
+                const V a = s_data[pos * pitch + v];
+                const T *ae = reinterpret_cast<const T *>(&a);
+#pragma unroll
+                for (int i = 0; i < EPV; ++i) acc[i] = fma(wm, (double)ae[i], acc[i]);
+            }
+            const int64_t col = (int64_t)(v_begin + v) * EPV;
+            store_piece<EPV>(out + (int64_t)s_cell[cl] * row_len + col, acc, row_len - col, even_rows);
+        }
+    }
+}
+
 template <typename T, int TC>
 __global__ void __launch_bounds__(TC * 4, 2)  // 226 VGPRs: two waves per SIMD
 interp_planned_kernel(const int32_t *__restrict__ perm, const int32_t *__restrict__ tile_cell_begin,
                       const int32_t *__restrict__ tile_row_begin, const int32_t *__restrict__ rows,
-                      const uint16_t *__restrict__ loc, const double *__restrict__ w, int k, int ucap,
+                      const uint16_t *__restrict__ loc, const double *__restrict__ w /*plan order*/, int k, int ucap,
                       const T *__restrict__ data, int64_t row_len, int64_t in_stride, double *__restrict__ out,
                       int64_t n_tiles, int64_t tiles_per_xcd, int chunks_per_block, int n_chunks) {
     using V = typename Vec16<T>::type;
@@ -62,14 +191,10 @@ interp_planned_kernel(const int32_t *__restrict__ perm, const int32_t *__restric
     if (tile >= n_tiles) return;
     const int c_begin = tile_cell_begin[tile], n_c = tile_cell_begin[tile + 1] - c_begin;
     const int r_begin = tile_row_begin[tile], n_r = tile_row_begin[tile + 1] - r_begin;
+    const bool even_rows = (row_len & 1) == 0;                   // output rows 16-byte aligned -> double2 stores
 
     // the tile's weights and LDS row positions, [neighbour][cell] so that a wavefront reads consecutive words
-    for (int i = threadIdx.x; i < k * TC; i += BLOCK) {
-        const int m = i / TC, j = i - m * TC;
-        const bool ok = j < n_c;
-        s_w[i] = ok ? w[(int64_t)perm[c_begin + j] * k + m] : 0.0;
-        s_loc[i] = ok ? loc[(int64_t)c_begin * k + (int64_t)m * n_c + j] : (uint16_t)0;
-    }
+    stage_tile_tables(w + (int64_t)c_begin * k, loc + (int64_t)c_begin * k, n_c * k, s_w, s_loc, BLOCK);
 
     // this thread's cell: 4 lanes per cell, each lane two 16-byte vectors of the chunk (v0 and v0+4)
     const int cl = threadIdx.x >> 2, v0 = threadIdx.x & 3;
@@ -96,7 +221,7 @@ interp_planned_kernel(const int32_t *__restrict__ perm, const int32_t *__restric
 #define S3_ISSUE(SET, CH)                                            \
     do {                                                             \
         const int64_t c0_ = (int64_t)(CH) * EPC;                     \
-        const bool ok_ = c0_ + (int64_t)(svec + 1) * EPV <= row_len; \
+        const bool ok_ = c0_ + (int64_t)svec * EPV < row_len;        \
         const T *seg_ = data + c0_ + (ok_ ? svec : 0) * EPV;         \
         S3_REP16(S3_LOAD_##SET)                                      \
     } while (0)
@@ -112,8 +237,8 @@ interp_planned_kernel(const int32_t *__restrict__ perm, const int32_t *__restric
         for (int i = 0; i < EPV; ++i) acc0[i] = acc1[i] = 0.0;
 #pragma unroll 4
         for (int m = 0; m < k; ++m) {
-            const int pos = s_loc[m * TC + cl];
-            const double wm = s_w[m * TC + cl];
+            const int pos = s_loc[m * n_c + cl];
+            const double wm = s_w[m * n_c + cl];
             const V a = s_data[pos * 8 + v0];
             const V c = s_data[pos * 8 + v0 + 4];
             const T *ae = reinterpret_cast<const T *>(&a);
@@ -125,16 +250,8 @@ interp_planned_kernel(const int32_t *__restrict__ perm, const int32_t *__restric
             }
         }
         double *o = out + cell * row_len + col0;
-        if (col0 + (int64_t)(v0 + 1) * EPV <= row_len) {
-#pragma unroll
-            for (int i = 0; i < EPV; i += 2)
-                *reinterpret_cast<double2 *>(o + v0 * EPV + i) = make_double2(acc0[i], acc0[i + 1]);
-        }
-        if (col0 + (int64_t)(v0 + 5) * EPV <= row_len) {
-#pragma unroll
-            for (int i = 0; i < EPV; i += 2)
-                *reinterpret_cast<double2 *>(o + (v0 + 4) * EPV + i) = make_double2(acc1[i], acc1[i + 1]);
-        }
+        store_piece<EPV>(o + v0 * EPV, acc0, row_len - col0 - (int64_t)v0 * EPV, even_rows);
+        store_piece<EPV>(o + (v0 + 4) * EPV, acc1, row_len - col0 - (int64_t)(v0 + 4) * EPV, even_rows);
     };
 
     if (chunk0 < chunk1) S3_ISSUE(A, chunk0);
@@ -164,6 +281,17 @@ interp_planned_kernel(const int32_t *__restrict__ perm, const int32_t *__restric
 
 // distinct rows a tile of `tc` cells may hold: what is left of the LDS budget (80 KiB -> two 256-thread workgroups per CU
 // for tc = 64; 160 KiB -> one 512-thread workgroup per CU for tc = 128) after the tile's weights and positions
+// rows of at most this many 16-byte vectors take the short-row kernel (S3_SHORT_ROW_VECS overrides, for A/B runs).
+// Measured on MI355X, cylinder3D grid (461 130 cells, k = 26, fp32): 16 snapshots (4 vectors) 0.139 ms short / 0.162 ms
+// chunk kernel / 0.170 ms direct gather; from 25 snapshots on the chunk kernel is faster (0.189 vs 0.282 ms)
+static int short_row_vecs() {
+    static const int v = [] {
+        const char *e = getenv("S3_SHORT_ROW_VECS");
+        return e ? atoi(e) : 4;
+    }();
+    return v;
+}
+
 static int plan_ucap(int k, int tc) {
     const int budget = (tc == 128 ? 160 : 80) * 1024;
     int u = (budget - k * tc * (int)(sizeof(double) + sizeof(uint16_t))) / PL_SEG;
@@ -177,12 +305,27 @@ static int plan_ucap(int k, int tc) {
 using namespace s3;
 
 template <typename T>
-static int launch_planned(const s3_interp_plan *p, const double *w, const void *data, int64_t row_len,
+static int launch_planned(const s3_interp_plan *p, const void *data, int64_t row_len,
                           int64_t in_stride, double *out, hipStream_t st) {
     constexpr int EPC = PL_SEG / (int)sizeof(T);
+    constexpr int EPV = 16 / (int)sizeof(T);
     const int n_chunks = (int)((row_len + EPC - 1) / EPC);
     const int64_t tiles_per_xcd = (p->n_tiles + 7) / 8;
     const int64_t gx = tiles_per_xcd * 8;
+    S3_REQUIRE(gx < ((int64_t)1 << 31), "s3_interp_planned: too many tiles");
+    if ((row_len + EPV - 1) / EPV <= s3::short_row_vecs() && p->tc == 64) {
+        const int vpr = (int)((row_len + EPV - 1) / EPV);
+        const int pitch = vpr < 8 ? vpr : 8;
+        const size_t lds = (size_t)p->ucap * pitch * 16 + (size_t)p->k * p->tc * (sizeof(double) + sizeof(uint16_t)) +
+                           (size_t)p->tc * sizeof(int32_t);
+        auto kern = interp_planned_short_kernel<T, 64>;
+        S3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        kern<<<dim3((unsigned)gx), 256, lds, st>>>(p->perm, p->tile_cell_begin, p->tile_row_begin, p->rows, p->loc, p->wp, p->k,
+                                                   p->ucap, static_cast<const T *>(data), row_len, in_stride, out, p->n_tiles,
+                                                   tiles_per_xcd, vpr, pitch);
+        S3_LAUNCH_CHECK();
+        return S3_OK;
+    }
     // the column chunks are split over blockIdx.y (x = tile runs fastest in dispatch order) only when there are too few
     // tiles to fill the chip: one workgroup per tile over ALL chunks is fastest (MI355X, cylinder3D workload: 3.7 ms vs
     // 4.4 ms with 4 chunks per workgroup)
@@ -198,13 +341,13 @@ static int launch_planned(const s3_interp_plan *p, const double *w, const void *
     if (p->tc == 128) {
         auto kern = interp_planned_kernel<T, 128>;
         S3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        kern<<<grid, 512, lds, st>>>(p->perm, p->tile_cell_begin, p->tile_row_begin, p->rows, p->loc, w, p->k, p->ucap,
+        kern<<<grid, 512, lds, st>>>(p->perm, p->tile_cell_begin, p->tile_row_begin, p->rows, p->loc, p->wp, p->k, p->ucap,
                                      static_cast<const T *>(data), row_len, in_stride, out, p->n_tiles, tiles_per_xcd,
                                      chunks_per_block, n_chunks);
     } else {
         auto kern = interp_planned_kernel<T, 64>;
         S3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        kern<<<grid, 256, lds, st>>>(p->perm, p->tile_cell_begin, p->tile_row_begin, p->rows, p->loc, w, p->k, p->ucap,
+        kern<<<grid, 256, lds, st>>>(p->perm, p->tile_cell_begin, p->tile_row_begin, p->rows, p->loc, p->wp, p->k, p->ucap,
                                      static_cast<const T *>(data), row_len, in_stride, out, p->n_tiles, tiles_per_xcd,
                                      chunks_per_block, n_chunks);
     }
@@ -221,6 +364,7 @@ void s3_interp_plan_destroy(s3_interp_plan *p) {
     if (p->tile_row_begin) (void)hipFree(p->tile_row_begin);
     if (p->rows) (void)hipFree(p->rows);
     if (p->loc) (void)hipFree(p->loc);
+    if (p->wp) (void)hipFree(p->wp);
     delete p;
 }
 
@@ -260,21 +404,45 @@ int s3_interp_plan_info(const s3_interp_plan *p, int64_t *n_tiles, int64_t *tota
     return S3_OK;
 }
 
-int s3_interp_planned(const s3_interp_plan *p, const double *d_w, const void *d_data, int dtype, int64_t row_len,
+int s3_interp_plan_set_weights(s3_interp_plan *p, const double *d_w, s3_stream stream) {
+    S3_REQUIRE(p != nullptr && d_w != nullptr, "s3_interp_plan_set_weights: null argument");
+    if (!p->wp) {
+        const hipError_t e = hipMalloc(reinterpret_cast<void **>(&p->wp), sizeof(double) * (size_t)p->nc * p->k);
+        if (e != hipSuccess) {
+            p->wp = nullptr;
+            s3::set_error("s3_interp_plan_set_weights: hipMalloc failed: %s", hipGetErrorString(e));
+            return e == hipErrorOutOfMemory ? S3_ENOMEM : S3_EHIP;
+        }
+    }
+    permute_weights_kernel<<<(unsigned)p->n_tiles, 256, 0, as_stream(stream)>>>(p->perm, p->tile_cell_begin, d_w, p->k, p->wp);
+    S3_LAUNCH_CHECK();
+    p->has_weights = true;
+    return S3_OK;
+}
+
+int s3_interp_planned(s3_interp_plan *p, const double *d_w, const void *d_data, int dtype, int64_t row_len,
                       int64_t in_stride, double *d_out, s3_stream stream) {
     S3_REQUIRE(p != nullptr, "s3_interp_planned: null plan");
+    if (d_w != nullptr) {                            // weights handed over with the call: bring them into plan order first
+        const int rc = s3_interp_plan_set_weights(p, d_w, stream);
+        if (rc != S3_OK) return rc;
+    }
+    S3_REQUIRE(p->has_weights, "s3_interp_planned: no weights (pass d_w or call s3_interp_plan_set_weights first)");
     S3_REQUIRE(dtype == S3_DTYPE_F32 || dtype == S3_DTYPE_F64, "s3_interp_planned: unknown dtype %d", dtype);
     S3_REQUIRE(row_len >= 0, "s3_interp_planned: bad row_len");
     if (row_len == 0) return S3_OK;
-    S3_REQUIRE(d_w && d_data && d_out, "s3_interp_planned: null array");
+    S3_REQUIRE(d_data && d_out, "s3_interp_planned: null array");
     const int epv = dtype == S3_DTYPE_F32 ? 4 : 2;
     const uintptr_t a_in = reinterpret_cast<uintptr_t>(d_data), a_out = reinterpret_cast<uintptr_t>(d_out);
     if (in_stride <= 0) in_stride = row_len;
     S3_REQUIRE(in_stride >= row_len, "s3_interp_planned: in_stride %lld < row_len %lld", (long long)in_stride, (long long)row_len);
-    S3_REQUIRE(row_len % epv == 0 && in_stride % epv == 0 && a_in % 16 == 0 && a_out % 16 == 0,
-               "s3_interp_planned: rows must be 16-byte aligned (row_len %% %d == 0); use s3_interp for ragged rows", epv);
-    if (dtype == S3_DTYPE_F32) return launch_planned<float>(p, d_w, d_data, row_len, in_stride, d_out, as_stream(stream));
-    return launch_planned<double>(p, d_w, d_data, row_len, in_stride, d_out, as_stream(stream));
+    // every source row starts on a 16-byte boundary and is readable up to the next multiple of 16 bytes (the ragged tail
+    // of a row is loaded as a whole vector, the surplus lanes are never stored)
+    S3_REQUIRE(in_stride % epv == 0 && in_stride >= (row_len + epv - 1) / epv * epv && a_in % 16 == 0 && a_out % 16 == 0,
+               "s3_interp_planned: source rows must be 16-byte aligned with a pitch >= the row length rounded up to %d "
+               "elements (row_len %lld, in_stride %lld)", epv, (long long)row_len, (long long)in_stride);
+    if (dtype == S3_DTYPE_F32) return launch_planned<float>(p, d_data, row_len, in_stride, d_out, as_stream(stream));
+    return launch_planned<double>(p, d_data, row_len, in_stride, d_out, as_stream(stream));
 }
 
 }  // extern "C"

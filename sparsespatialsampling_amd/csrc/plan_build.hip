@@ -220,6 +220,8 @@ gather_kernel(const int32_t *__restrict__ blk_rows, const int32_t *__restrict__ 
     }
 }
 
+}  // namespace
+
 struct Scratch {                           // frees whatever was allocated when it goes out of scope
     std::vector<void *> ptrs;
     ~Scratch() { for (void *p : ptrs) (void)hipFree(p); }
@@ -229,8 +231,6 @@ struct Scratch {                           // frees whatever was allocated when 
         return e;
     }
 };
-
-}  // namespace
 
 #define S3_PB_CHECK(expr)                                                                             \
     do {                                                                                              \
@@ -338,3 +338,158 @@ int build_plan_tables(const int32_t *d_idx, int64_t nc, int k, int64_t n_src, co
 }
 
 }  // namespace s3
+
+// ---- referenced-row bookkeeping of the KNN cache (include/s3hip.h) ---------------------------------------------
+namespace {
+
+__global__ void mark_rows_kernel(const int32_t *__restrict__ idx, int64_t n, int32_t n_src, int32_t *__restrict__ flag,
+                                 int32_t *__restrict__ bad) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t r = idx[i];
+    if (r < 0 || r >= n_src) { atomicExch(bad, 1); return; }
+    if (flag[r] == 0) flag[r] = 1;              // benign race: every writer stores the same value
+}
+
+__global__ void compact_rows_kernel(int32_t *__restrict__ flag_remap, const int32_t *__restrict__ pos, int64_t n_src,
+                                    int32_t *__restrict__ used) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n_src) return;
+    if (flag_remap[i]) {
+        used[pos[i]] = (int32_t)i;
+        flag_remap[i] = pos[i];
+    } else {
+        flag_remap[i] = -1;
+    }
+}
+
+__global__ void remap_kernel(int32_t *__restrict__ idx, int64_t n, const int32_t *__restrict__ remap, int32_t n_src,
+                             int32_t *__restrict__ bad) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t r = idx[i];
+    if (r < 0 || r >= n_src || remap[r] < 0) { atomicExch(bad, 1); return; }
+    idx[i] = remap[r];
+}
+
+// one wavefront per row: 16-byte pieces when source and destination rows are 16-byte aligned, 4-byte pieces otherwise
+template <typename P>
+__global__ void __launch_bounds__(256)
+gather_rows_kernel(const char *__restrict__ src, int64_t src_pitch, const int32_t *__restrict__ ids, int64_t n,
+                   int64_t row_bytes, char *__restrict__ dst, int64_t dst_pitch) {
+    const int lane = threadIdx.x & 63;
+    const int64_t pieces = row_bytes / (int64_t)sizeof(P);
+    for (int64_t row = blockIdx.x * 4ll + (threadIdx.x >> 6); row < n; row += (int64_t)gridDim.x * 4) {
+        const P *s = reinterpret_cast<const P *>(src + (ids ? (int64_t)ids[row] : row) * src_pitch);
+        P *d = reinterpret_cast<P *>(dst + row * dst_pitch);
+        for (int64_t i = lane; i < pieces; i += 64) d[i] = s[i];
+    }
+}
+
+__global__ void check_ids_kernel(const int32_t *__restrict__ ids, int64_t n, int32_t n_rows, int32_t *__restrict__ bad) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n && (ids[i] < 0 || ids[i] >= n_rows)) atomicExch(bad, 1);
+}
+
+int read_flag(int32_t *d_bad, hipStream_t st, int32_t *h) {
+    S3_HIP_CHECK(hipMemcpyAsync(h, d_bad, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    S3_HIP_CHECK(hipStreamSynchronize(st));
+    return S3_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int s3_mark_rows(const int32_t *d_idx, int64_t n, int64_t n_src, int32_t *d_flag, s3_stream stream) {
+    S3_REQUIRE(n >= 0 && n_src >= 1 && n_src < ((int64_t)1 << 31), "s3_mark_rows: bad sizes");
+    if (n == 0) return S3_OK;
+    S3_REQUIRE(d_idx && d_flag, "s3_mark_rows: null array");
+    hipStream_t st = s3::as_stream(stream);
+    s3::Scratch tmp;
+    int32_t *d_bad = nullptr, bad = 0;
+    S3_HIP_CHECK(tmp.alloc(&d_bad, 1));
+    S3_HIP_CHECK(hipMemsetAsync(d_bad, 0, sizeof(int32_t), st));
+    mark_rows_kernel<<<s3::grid_for(n, 256), 256, 0, st>>>(d_idx, n, (int32_t)n_src, d_flag, d_bad);
+    S3_LAUNCH_CHECK();
+    const int rc = read_flag(d_bad, st, &bad);
+    if (rc != S3_OK) return rc;
+    S3_REQUIRE(bad == 0, "s3_mark_rows: neighbour index outside [0, %lld)", (long long)n_src);
+    return S3_OK;
+}
+
+int s3_compact_rows(int32_t *d_flag_remap, int64_t n_src, int32_t *d_used, int64_t *h_n_used, s3_stream stream) {
+    S3_REQUIRE(n_src >= 1 && n_src < ((int64_t)1 << 31) && d_flag_remap && d_used && h_n_used, "s3_compact_rows: bad arguments");
+    hipStream_t st = s3::as_stream(stream);
+    s3::Scratch tmp;
+    int32_t *pos = nullptr;
+    S3_HIP_CHECK(tmp.alloc(&pos, (size_t)n_src));
+    size_t bytes = 0;
+    S3_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, d_flag_remap, pos, (int)n_src, st));
+    char *d_scan = nullptr;
+    S3_HIP_CHECK(tmp.alloc(&d_scan, bytes));
+    S3_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(d_scan, bytes, d_flag_remap, pos, (int)n_src, st));
+    int32_t last_pos = 0, last_flag = 0;
+    S3_HIP_CHECK(hipMemcpyAsync(&last_pos, pos + n_src - 1, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    S3_HIP_CHECK(hipMemcpyAsync(&last_flag, d_flag_remap + n_src - 1, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    compact_rows_kernel<<<s3::grid_for(n_src, 256), 256, 0, st>>>(d_flag_remap, pos, n_src, d_used);
+    S3_LAUNCH_CHECK();
+    S3_HIP_CHECK(hipStreamSynchronize(st));
+    *h_n_used = (int64_t)last_pos + (last_flag ? 1 : 0);
+    return S3_OK;
+}
+
+int s3_remap_indices(int32_t *d_idx, int64_t n, const int32_t *d_remap, int64_t n_src, s3_stream stream) {
+    S3_REQUIRE(n >= 0 && n_src >= 1 && n_src < ((int64_t)1 << 31), "s3_remap_indices: bad sizes");
+    if (n == 0) return S3_OK;
+    S3_REQUIRE(d_idx && d_remap, "s3_remap_indices: null array");
+    hipStream_t st = s3::as_stream(stream);
+    s3::Scratch tmp;
+    int32_t *d_bad = nullptr, bad = 0;
+    S3_HIP_CHECK(tmp.alloc(&d_bad, 1));
+    S3_HIP_CHECK(hipMemsetAsync(d_bad, 0, sizeof(int32_t), st));
+    remap_kernel<<<s3::grid_for(n, 256), 256, 0, st>>>(d_idx, n, d_remap, (int32_t)n_src, d_bad);
+    S3_LAUNCH_CHECK();
+    const int rc = read_flag(d_bad, st, &bad);
+    if (rc != S3_OK) return rc;
+    S3_REQUIRE(bad == 0, "s3_remap_indices: index without a position in the remap table");
+    return S3_OK;
+}
+
+int s3_gather_rows(const void *d_src, int64_t n_src_rows, int64_t row_bytes, int64_t src_pitch_bytes, const int32_t *d_ids,
+                   int64_t n, void *d_dst, int64_t dst_pitch_bytes, s3_stream stream) {
+    S3_REQUIRE(n >= 0 && row_bytes >= 0 && n_src_rows >= 0 && n_src_rows < ((int64_t)1 << 31), "s3_gather_rows: bad sizes");
+    if (n == 0 || row_bytes == 0) return S3_OK;
+    S3_REQUIRE(d_src && d_dst, "s3_gather_rows: null array");
+    S3_REQUIRE(row_bytes % 4 == 0 && src_pitch_bytes >= row_bytes && dst_pitch_bytes >= row_bytes &&
+               src_pitch_bytes % 4 == 0 && dst_pitch_bytes % 4 == 0 &&
+               reinterpret_cast<uintptr_t>(d_src) % 4 == 0 && reinterpret_cast<uintptr_t>(d_dst) % 4 == 0,
+               "s3_gather_rows: rows must be multiples of 4 bytes on 4-byte boundaries");
+    S3_REQUIRE(d_ids != nullptr || n <= n_src_rows, "s3_gather_rows: more rows requested than the source holds");
+    hipStream_t st = s3::as_stream(stream);
+    if (d_ids) {
+        s3::Scratch tmp;
+        int32_t *d_bad = nullptr, bad = 0;
+        S3_HIP_CHECK(tmp.alloc(&d_bad, 1));
+        S3_HIP_CHECK(hipMemsetAsync(d_bad, 0, sizeof(int32_t), st));
+        check_ids_kernel<<<s3::grid_for(n, 256), 256, 0, st>>>(d_ids, n, (int32_t)n_src_rows, d_bad);
+        S3_LAUNCH_CHECK();
+        const int rc = read_flag(d_bad, st, &bad);
+        if (rc != S3_OK) return rc;
+        S3_REQUIRE(bad == 0, "s3_gather_rows: row id outside [0, %lld)", (long long)n_src_rows);
+    }
+    const bool wide = row_bytes % 16 == 0 && src_pitch_bytes % 16 == 0 && dst_pitch_bytes % 16 == 0 &&
+                      reinterpret_cast<uintptr_t>(d_src) % 16 == 0 && reinterpret_cast<uintptr_t>(d_dst) % 16 == 0;
+    const unsigned grid = s3::grid_for((n + 3) / 4, 1, 1 << 20);
+    if (wide)
+        gather_rows_kernel<float4><<<grid, 256, 0, st>>>(static_cast<const char *>(d_src), src_pitch_bytes, d_ids, n, row_bytes,
+                                                         static_cast<char *>(d_dst), dst_pitch_bytes);
+    else
+        gather_rows_kernel<float><<<grid, 256, 0, st>>>(static_cast<const char *>(d_src), src_pitch_bytes, d_ids, n, row_bytes,
+                                                        static_cast<char *>(d_dst), dst_pitch_bytes);
+    S3_LAUNCH_CHECK();
+    return S3_OK;
+}
+
+}  // extern "C"
+

@@ -183,12 +183,38 @@ class InterpPlan:
         nt, nr = C.c_int64(0), C.c_int64(0)
         check(_lib.hip_lib().s3_interp_plan_info(self._handle, C.byref(nt), C.byref(nr)), "s3_interp_plan_info")
         self.n_tiles, self.total_rows = nt.value, nr.value
+        self._w_key = None
+
+    def set_weights(self, w):
+        """attach the weights of the table ([nc, k] float64, caller's cell order); the plan keeps them in tile order"""
+        if not (w.is_cuda and w.dtype == pt.float64 and w.is_contiguous() and tuple(w.shape) == (self.nc, self.k)):
+            raise TypeError("InterpPlan: weights must be a contiguous float64 [nc, k] device tensor")
+        check(_lib.hip_lib().s3_interp_plan_set_weights(self._handle, _ptr(w), _stream()), "s3_interp_plan_set_weights")
+        self._w_key = (w.data_ptr(), w._version)
+
+    @staticmethod
+    def _layout(data):
+        """(row_len, in_stride) of a data matrix the planned kernel can read, None otherwise: every source row starts on
+        a 16-byte boundary and is readable up to the next multiple of 16 bytes (``padded_rows`` views always are; dense
+        rows when their length is a multiple of 16 bytes)"""
+        if data.dtype not in DTYPE_CODE or data.dim() < 1:
+            return None
+        epv = 16 // data.element_size()
+        row_len = int(np.prod(data.shape[1:])) if data.dim() > 1 else 1
+        if data.is_contiguous():
+            in_stride = row_len
+        elif data.dim() == 2 and data.stride(1) == 1 and data.stride(0) >= row_len:
+            in_stride = int(data.stride(0))
+        else:
+            return None
+        padded = (row_len + epv - 1) // epv * epv
+        if in_stride % epv or in_stride < padded or (data.is_cuda and data.data_ptr() % 16):
+            return None
+        return row_len, in_stride
 
     @staticmethod
     def supports(k, data):
-        """the planned kernel needs 16-byte aligned rows"""
-        row_len = int(np.prod(data.shape[1:])) if data.dim() > 1 else 1
-        return k <= 64 and data.dtype in DTYPE_CODE and row_len % (4 if data.dtype == pt.float32 else 2) == 0
+        return k <= 64 and InterpPlan._layout(data) is not None
 
     def close(self):
         if getattr(self, "_handle", None) is not None and self._handle.value:
@@ -207,19 +233,18 @@ class InterpPlan:
         if not (w.dtype == pt.float64 and tuple(w.shape) == (self.nc, self.k) and int(data.shape[0]) == self.n_src
                 and data.dtype in DTYPE_CODE):
             raise TypeError("InterpPlan.interp: weights / data do not match the plan")
-        row_len = int(np.prod(data.shape[1:])) if data.dim() > 1 else 1
-        if data.is_contiguous():
-            in_stride = row_len
-        elif data.dim() == 2 and data.stride(1) == 1 and data.stride(0) >= row_len:
-            in_stride = int(data.stride(0))
-        else:
-            raise TypeError("InterpPlan.interp: unsupported data layout")
+        layout = self._layout(data)
+        if layout is None:
+            raise TypeError("InterpPlan.interp: source rows must be 16-byte aligned (see padded_rows / repitch_rows)")
+        row_len, in_stride = layout
         if out is None:
             out = pt.empty((self.nc,) + tuple(data.shape[1:]), dtype=pt.float64, device=data.device)
         if not (data.is_cuda and out.is_cuda and out.is_contiguous() and out.dtype == pt.float64
                 and out.numel() == self.nc * row_len):
             raise TypeError("InterpPlan.interp: device tensors required, out must be contiguous float64 [nc, ...]")
-        check(_lib.hip_lib().s3_interp_planned(self._handle, _ptr(w), C.c_void_p(data.data_ptr()),
+        if self._w_key != (w.data_ptr(), w._version):            # new or modified weights: re-attach
+            self.set_weights(w)
+        check(_lib.hip_lib().s3_interp_planned(self._handle, C.c_void_p(0), C.c_void_p(data.data_ptr()),
                                                DTYPE_CODE[data.dtype], row_len, in_stride, _ptr(out), _stream()),
               "s3_interp_planned")
         return out
@@ -257,6 +282,43 @@ def upload_rows_indexed(host, row_ids, rows):
     return rows
 
 
+def gather_rows(src, ids, dst):
+    """device rows: ``dst[i, :] = src[ids[i], :]`` (``ids`` int32 device tensor) or ``dst[i, :] = src[i, :]`` (``ids``
+    None: a re-pitch).  ``src`` / ``dst`` are 2-D device tensors (or ``padded_rows`` views) with unit inner stride."""
+    if not (src.is_cuda and dst.is_cuda and src.dim() == 2 and dst.dim() == 2 and src.stride(1) == 1 and dst.stride(1) == 1
+            and src.dtype == dst.dtype and src.shape[1] == dst.shape[1]):
+        raise TypeError("gather_rows: 2-D device tensors of one dtype and row length with unit inner stride required")
+    n = int(dst.shape[0])
+    if ids is not None and not (ids.is_cuda and ids.dtype == pt.int32 and ids.is_contiguous() and ids.numel() == n):
+        raise TypeError("gather_rows: ids must be a contiguous int32 device tensor with one entry per destination row")
+    item = src.element_size()
+    check(_lib.hip_lib().s3_gather_rows(C.c_void_p(src.data_ptr()), int(src.shape[0]), int(src.shape[1]) * item,
+                                        int(src.stride(0)) * item, _ptr(ids), n, C.c_void_p(dst.data_ptr()),
+                                        int(dst.stride(0)) * item, _stream()), "s3_gather_rows")
+    return dst
+
+
+def referenced_rows(tables, n_src):
+    """the source rows the neighbour tables (int32 device tensors) reference: (used ids ascending int32 [n_used] device,
+    remap int32 [n_src] device: position among the used rows or -1) -- mark / scan / compact on the device"""
+    dev = tables[0].device
+    remap = pt.zeros(int(n_src), dtype=pt.int32, device=dev)
+    for t in tables:
+        check(_lib.hip_lib().s3_mark_rows(_ptr(t), int(t.numel()), int(n_src), _ptr(remap), _stream()), "s3_mark_rows")
+    used = pt.empty(int(n_src), dtype=pt.int32, device=dev)
+    n_used = C.c_int64(0)
+    check(_lib.hip_lib().s3_compact_rows(_ptr(remap), int(n_src), _ptr(used), C.byref(n_used), _stream()),
+          "s3_compact_rows")
+    return used[:n_used.value], remap
+
+
+def remap_indices(idx, remap):
+    """``idx[i] = remap[idx[i]]`` in place (int32 device tensors)"""
+    check(_lib.hip_lib().s3_remap_indices(_ptr(idx), int(idx.numel()), _ptr(remap), int(remap.numel()), _stream()),
+          "s3_remap_indices")
+    return idx
+
+
 def padded_rows(n_rows, row_len, dtype, dev, extra_lines=0):
     """[n_rows, row_len] view of a device buffer whose row pitch is a whole number of 128-byte lines (upload target for
     snapshot batches: every 128-B segment the planned kernel stages then sits on exactly one cache line).  For long rows
@@ -264,7 +326,12 @@ def padded_rows(n_rows, row_len, dtype, dev, extra_lines=0):
     time, and with a pitch of 2^n or 2^n + 1 lines those addresses load the memory channels unevenly (MI355X, 4000-B
     rows, same process: 32 lines 3.69 ms, 33: 3.66, 34: 3.41*, 35: 3.37*/3.54, 37..47: 3.52-3.53, 64: 3.44*; * = a
     faster box of the pool)"""
-    per_line = 128 // pt.empty((), dtype=dtype).element_size()
+    item = pt.empty((), dtype=dtype).element_size()
+    if row_len * item <= 64 and not extra_lines:
+        # short rows (16 snapshots of a scalar field): whole 64-byte sectors, two rows per line -- half the footprint
+        pitch = 16 // item if row_len * item <= 16 else (32 // item if row_len * item <= 32 else 64 // item)
+        return pt.empty((n_rows, pitch), dtype=dtype, device=dev)[:, :row_len]
+    per_line = 128 // item
     lines = (row_len + per_line - 1) // per_line
     if lines >= 16:
         while lines % 4 != 3 or lines % 32 == 31:

@@ -40,7 +40,22 @@ def _cpu_ops():
                                                                           data.numpy()))
     ops.InterpPlan = type("InterpPlan", (), {"__init__": lambda self, *a, **k: None,
                                             "supports": staticmethod(lambda k, d: False)})
-    ops.padded_rows = None      # never reached: supports() is False on the CPU stand-in
+    ops.padded_rows = lambda n_rows, row_len, dtype, dev, extra_lines=0: pt.empty((n_rows, row_len + 3), dtype=dtype)[:, :row_len]
+
+    def referenced_rows(tables, n_src):
+        used = np.unique(np.concatenate([t.numpy().ravel() for t in tables])).astype(np.int32)
+        remap = np.full(n_src, -1, dtype=np.int32)
+        remap[used] = np.arange(len(used), dtype=np.int32)
+        return pt.from_numpy(used), pt.from_numpy(remap)
+
+    def remap_indices(idx, remap):
+        idx.copy_(remap[idx.long()])
+        return idx
+
+    def gather_rows(src, ids, dst):
+        dst.copy_(src if ids is None else src[ids.long()])
+        return dst
+    ops.referenced_rows, ops.remap_indices, ops.gather_rows = referenced_rows, remap_indices, gather_rows
     ops.knn_occupancy = lambda k, dim: 0.0
     ops.upload_rows = lambda host, rows: rows.copy_(host)
     ops.upload_rows_indexed = lambda host, ids, rows: rows.copy_(host[pt.from_numpy(np.asarray(ids)).long()])

@@ -140,10 +140,62 @@ def test_interp_planned_random_table_no_centers(ops, orc):
     ref = orc.interp(w, idx, data)
     assert np.abs(out - ref).max() <= 1e-13 * np.abs(ref).max()
     from sparsespatialsampling_amd._lib import S3HipError
-    with pytest.raises(S3HipError):
-        plan.interp(dev(w), dev(rng.standard_normal((n, 1, 25)).astype(np.float32)))     # ragged rows -> s3_interp
+    with pytest.raises(TypeError):
+        plan.interp(dev(w), dev(rng.standard_normal((n, 1, 25)).astype(np.float32)))     # dense ragged rows: not aligned
     with pytest.raises(S3HipError):
         ops.InterpPlan(dev(np.full((4, 8), n), pt.int32), n)                              # index out of range
+
+
+@pytest.mark.parametrize("row_len,dtype", [(16, pt.float32), (25, pt.float32), (48, pt.float32), (75, pt.float32),
+                                           (100, pt.float32), (128, pt.float32), (131, pt.float32), (200, pt.float32),
+                                           (1001, pt.float32), (7, pt.float64), (16, pt.float64), (33, pt.float64),
+                                           (250, pt.float64), (1, pt.float32)])
+def test_interp_planned_short_and_ragged_rows(ops, orc, row_len, dtype):
+    """snapshot batches of any length run the tiled kernels (short-row variant up to 64-byte rows, chunk pipeline
+    beyond; ragged tails are loaded from the padded pitch and stored per element): bit-equal to the direct gather kernel,
+    1e-13 against the oracle.  16 / 25 snapshots per batch are the reference's own batch sizes
+    (examples/s3_for_cylinder3D_Re3900.py:28-69)."""
+    rng = np.random.default_rng(row_len)
+    n, nc, k = 20_000, 3_333, 26
+    x, c = rng.random((n, 3)), rng.random((nc, 3))
+    knn = ops.KnnIndex(x)
+    idx, dist = knn.query(c, k)
+    w = ops.idw_weights(dist)
+    plan = ops.InterpPlan(idx, n, c)
+    data = ops.padded_rows(n, row_len, dtype, "cuda")
+    data.normal_()
+    assert data.stride(0) > row_len or row_len % (16 // data.element_size()) == 0
+    got = plan.interp(w, data)
+    dense = data.contiguous()
+    assert got.shape == (nc, row_len) and pt.equal(got, ops.interp(w, idx, dense))
+    ref = orc.interp(w.cpu().numpy(), idx.cpu().numpy(), dense.cpu().numpy().reshape(n, 1, row_len)).reshape(nc, row_len)
+    assert np.abs(got.cpu().numpy() - ref).max() <= 1e-13 * np.abs(ref).max()
+    plan.close(); knn.close()
+
+
+def test_referenced_rows_and_gather(ops):
+    """device-side bookkeeping of the KNN cache: mark / scan / compact of the referenced source rows, index remap, row
+    gather -- against numpy"""
+    rng = np.random.default_rng(5)
+    n_src = 100_000
+    a = rng.integers(0, n_src // 3, (5000, 26)).astype(np.int32)
+    b = rng.integers(n_src // 2, n_src, (777, 8)).astype(np.int32)
+    ta, tb = dev(a), dev(b)
+    used, remap = ops.referenced_rows([ta, tb], n_src)
+    want = np.unique(np.concatenate([a.ravel(), b.ravel()]))
+    assert used.dtype == pt.int32 and np.array_equal(used.cpu().numpy(), want)
+    r = remap.cpu().numpy()
+    assert np.array_equal(r[want], np.arange(len(want))) and (np.delete(r, want) == -1).all()
+    ops.remap_indices(ta, remap)
+    assert np.array_equal(want[ta.cpu().numpy()], a)
+    for row_len, dtype in ((25, pt.float32), (64, pt.float32), (3, pt.float64), (1, pt.float64)):
+        src = pt.randn((n_src, row_len), dtype=dtype, device="cuda")
+        dst = ops.gather_rows(src, used, ops.padded_rows(len(want), row_len, dtype, "cuda"))
+        assert pt.equal(dst, src[used.long()])
+        assert pt.equal(ops.gather_rows(src, None, ops.padded_rows(n_src, row_len, dtype, "cuda")), src)
+    from sparsespatialsampling_amd._lib import S3HipError
+    with pytest.raises(S3HipError):
+        ops.referenced_rows([dev(np.array([[0, n_src]], dtype=np.int32))], n_src)
 
 
 @pytest.mark.parametrize("n,row_len,dtype", [(70_000, 25, pt.float32), (3_000, 1000, pt.float32), (50_000, 7, pt.float64),

@@ -17,8 +17,9 @@ for case in range(n_cases):
     epv = 2 if f64 else 4
     ncomp = int(rng.integers(1, 4))
     t = int(rng.integers(1, 70))
-    row_len = ncomp * t
-    row_len += (-row_len) % epv                          # planned kernel: 16-byte aligned rows
+    row_len = ncomp * t                                  # any length: ragged rows live in a padded pitch
+    if rng.random() < 0.25:
+        row_len = int(rng.integers(1, 700))              # also rows long enough for the chunk-pipelined kernel
     structure = rng.integers(0, 3)
     x = rng.random((n, d))
     if structure == 0:                                   # real neighbour table
@@ -35,7 +36,7 @@ for case in range(n_cases):
         w = pt.from_numpy(rng.random((nc, k))).cuda()
         centers = rng.random((nc, d)) if rng.random() < 0.5 else None
     dtype = pt.float64 if f64 else pt.float32
-    pad = bool(rng.random() < 0.6)
+    pad = bool(rng.random() < 0.6) or row_len % epv != 0
     if pad:
         data = hipops.padded_rows(n, row_len, dtype, "cuda", int(rng.integers(0, 3)))
     else:

@@ -98,6 +98,23 @@ TOPO_SIGNATURES = {
     "s3t_face_ids": (c_vp, [c_vp]),
     "s3t_unique_nodes": (c_vp, [c_vp]),
     "s3t_selfcheck": (c_int, [c_int]),
+    "s3t_submit": (c_int, [c_vp, c_int, c_vp, c_i64, c_int]),
+    "s3t_sync": (c_int, [c_vp]),
+    "s3set_create": (c_vp, []),
+    "s3set_destroy": (None, [c_vp]),
+    "s3set_len": (c_i64, [c_vp]),
+    "s3set_mask": (c_i64, [c_vp]),
+    "s3set_fill": (c_i64, [c_vp]),
+    "s3set_table": (c_vp, [c_vp]),
+    "s3set_contains": (c_int, [c_vp, c_i64]),
+    "s3set_add": (c_int, [c_vp, c_i64]),
+    "s3set_discard": (None, [c_vp, c_i64]),
+    "s3set_update_ids": (c_int, [c_vp, c_vp, c_i64]),
+    "s3set_update_range": (c_int, [c_vp, c_i64, c_i64]),
+    "s3set_update_set": (c_int, [c_vp, c_vp]),
+    "s3set_difference_update": (c_int, [c_vp, c_vp]),
+    "s3set_to_array": (None, [c_vp, c_vp]),
+    "s3set_update_flagged": (c_int, [c_vp, c_vp, c_vp, c_i64]),
 }
 
 

@@ -16,9 +16,13 @@
 // refreshes them, because the shared-node numbering depends on that staleness.
 #include <algorithm>
 #include <cmath>
+#include <condition_variable>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -214,6 +218,39 @@ struct Topo {
         }
     }
 
+    // ---- command queue: with max_delta_level=False nothing the refine loop decides depends on the links or node ids
+    // (SURVEY.md section 7.4), so the host submits its batches and carries on; one worker thread applies them in order
+    struct Cmd { int kind; int relink; std::vector<int64_t> ids; };     // kind 0 refine, 1 relink parents, 2 mark invalid
+    std::deque<Cmd> queue;
+    std::mutex mtx;
+    std::condition_variable cv_work, cv_idle;
+    std::thread worker;
+    bool busy = false, stop = false;
+    int error = 0;                       // first failure of a queued command: -1 not a leaf, -2 out of memory
+
+    void worker_loop();
+    void submit(Cmd &&c) {
+        {
+            std::lock_guard<std::mutex> lk(mtx);
+            if (!worker.joinable()) worker = std::thread([this] { worker_loop(); });
+            queue.push_back(std::move(c));
+        }
+        cv_work.notify_one();
+    }
+    int wait_idle() {
+        std::unique_lock<std::mutex> lk(mtx);
+        cv_idle.wait(lk, [this] { return queue.empty() && !busy; });
+        return error;
+    }
+    ~Topo() {
+        {
+            std::lock_guard<std::mutex> lk(mtx);
+            stop = true;
+        }
+        cv_work.notify_one();
+        if (worker.joinable()) worker.join();
+    }
+
     // one parent of _refine_cells / the uniform loop: children, neighbour links, node ids
     void refine_one(int32_t P) {
         const int32_t fc = (int32_t)n_cells();
@@ -256,8 +293,8 @@ void *s3t_create(int dim, double width, const double *root_center) try {
 
 void s3t_destroy(void *h) { delete static_cast<Topo *>(h); }
 
-int64_t s3t_n_cells(void *h) { return static_cast<Topo *>(h)->n_cells(); }
-int64_t s3t_n_nodes(void *h) { return static_cast<Topo *>(h)->n_nodes(); }
+int64_t s3t_n_cells(void *h) { static_cast<Topo *>(h)->wait_idle(); return static_cast<Topo *>(h)->n_cells(); }
+int64_t s3t_n_nodes(void *h) { static_cast<Topo *>(h)->wait_idle(); return static_cast<Topo *>(h)->n_nodes(); }
 
 // raw views for the Python host (valid until the next mutating call)
 int32_t *s3t_level(void *h) { return static_cast<Topo *>(h)->level.data(); }
@@ -271,8 +308,7 @@ double *s3t_nodes(void *h) { return static_cast<Topo *>(h)->nodes.data(); }
 // refine the listed parents in order (s_cube.py:879-895 / 531-544).  relink != 0 additionally re-runs the neighbour
 // assignment of every parent of the batch afterwards (the "update all nb" pass of the uniform loop, s_cube.py:547-549).
 // Returns the id of the first new cell, -1 if a parent is not a leaf, -2 if the tables could not grow.
-int64_t s3t_refine(void *h, const int64_t *parents, int64_t n, int relink) try {
-    Topo *t = static_cast<Topo *>(h);
+static int64_t refine_batch(Topo *t, const int64_t *parents, int64_t n, int relink) {
     const int64_t first = t->n_cells();
     t->reserve_cells(n * t->nch);
     // the work per parent is a few dozen dependent look-ups in tables far larger than the caches; two software
@@ -318,22 +354,32 @@ int64_t s3t_refine(void *h, const int64_t *parents, int64_t n, int relink) try {
     if (relink)
         for (int64_t i = 0; i < n; ++i) t->assign_neighbors((int32_t)parents[i]);
     return first;
+}
+
+int64_t s3t_refine(void *h, const int64_t *parents, int64_t n, int relink) try {
+    Topo *t = static_cast<Topo *>(h);
+    if (t->wait_idle() != 0) return t->error;
+    return refine_batch(t, parents, n, relink);
 } catch (...) {
     return -2;
 }
 
 // cell.parent.children = _assign_neighbors(cell.parent, children=cell.parent.children)   (s_cube.py:609, 834, 494)
-void s3t_relink_parent_of(void *h, const int64_t *cells, int64_t n) {
-    Topo *t = static_cast<Topo *>(h);
+static void relink_parents(Topo *t, const int64_t *cells, int64_t n) {
     for (int64_t i = 0; i < n; ++i) {
         int32_t p = t->parent[cells[i]];
         if (p >= 0) t->assign_neighbors(p);
     }
 }
 
-// s_cube.py:721-728: children = [], and the cell disappears from its neighbours' nb lists
-void s3t_mark_invalid(void *h, const int64_t *cells, int64_t n) {
+void s3t_relink_parent_of(void *h, const int64_t *cells, int64_t n) {
     Topo *t = static_cast<Topo *>(h);
+    t->wait_idle();
+    relink_parents(t, cells, n);
+}
+
+// s_cube.py:721-728: children = [], and the cell disappears from its neighbours' nb lists
+static void mark_invalid_cells(Topo *t, const int64_t *cells, int64_t n) {
     for (int64_t i = 0; i < n; ++i) {
         const int32_t x = (int32_t)cells[i];
         t->first_child[x] = INVALID;
@@ -347,9 +393,70 @@ void s3t_mark_invalid(void *h, const int64_t *cells, int64_t n) {
     }
 }
 
+void s3t_mark_invalid(void *h, const int64_t *cells, int64_t n) {
+    Topo *t = static_cast<Topo *>(h);
+    t->wait_idle();
+    mark_invalid_cells(t, cells, n);
+}
+
+// ---- asynchronous forms: the ids are copied, the call returns at once, one worker applies the commands in order.
+// s3t_sync waits for the queue to drain and reports the first failure (0 ok, -1 a parent was not a leaf, -2 out of
+// memory); every synchronous entry point and every table view drains the queue first.
+int s3t_submit(void *h, int kind, const int64_t *ids, int64_t n, int relink) try {
+    Topo *t = static_cast<Topo *>(h);
+    if (kind < 0 || kind > 2) return -3;
+    Topo::Cmd c{kind, relink, std::vector<int64_t>(ids, ids + n)};
+    t->submit(std::move(c));
+    return 0;
+} catch (...) {
+    return -2;
+}
+
+int s3t_sync(void *h) { return static_cast<Topo *>(h)->wait_idle(); }
+
+}  // extern "C"
+
+void Topo::worker_loop() {
+    while (true) {
+        Cmd c;
+        {
+            std::unique_lock<std::mutex> lk(mtx);
+            cv_work.wait(lk, [this] { return stop || !queue.empty(); });
+            if (queue.empty()) return;                       // stop requested and nothing left
+            c = std::move(queue.front());
+            queue.pop_front();
+            busy = true;
+        }
+        int rc = 0;
+        if (error == 0) {
+            try {
+                if (c.kind == 0) {
+                    const int64_t first = refine_batch(this, c.ids.data(), (int64_t)c.ids.size(), c.relink);
+                    if (first < 0) rc = (int)first;
+                } else if (c.kind == 1) {
+                    relink_parents(this, c.ids.data(), (int64_t)c.ids.size());
+                } else {
+                    mark_invalid_cells(this, c.ids.data(), (int64_t)c.ids.size());
+                }
+            } catch (...) {
+                rc = -2;
+            }
+        }
+        {
+            std::lock_guard<std::mutex> lk(mtx);
+            if (rc != 0 && error == 0) error = rc;
+            busy = false;
+        }
+        cv_idle.notify_all();
+    }
+}
+
+extern "C" {
+
 // _check_nb, s_cube.py:463-464: leaf neighbours with a lower level; returns the count, ids in slot order
 int s3t_check_nb(void *h, int64_t cell, int64_t *out) {
     Topo *t = static_cast<Topo *>(h);
+    t->wait_idle();
     int cnt = 0;
     for (int s = 0; s < t->nnb; ++s) {
         int32_t q = t->nb[(size_t)cell * t->nnb + s];
@@ -362,6 +469,7 @@ int s3t_check_nb(void *h, int64_t cell, int64_t *out) {
 // are read through s3t_face_ids / s3t_unique_nodes.
 int64_t s3t_finalize(void *h, int64_t *n_unique_nodes) try {
     Topo *t = static_cast<Topo *>(h);
+    if (t->wait_idle() != 0) return -1;
     const int nch = t->nch;
     t->face_ids.clear();
     for (int64_t c = 0; c < t->n_cells(); ++c)

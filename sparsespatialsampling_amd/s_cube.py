@@ -8,16 +8,18 @@ Division of labour:
   centres, inverse-distance metric prediction at every new cell centre and its 2^d candidate child centres, the gain,
   the geometry predicates, the captured-metric reduction and the top-N gain selection.
 * **host, native** (``csrc/topology.cpp`` -> libs3topo.so): neighbour links, shared-node numbering, renumbering.
-* **host, Python** (this file): the control flow of ``refine()`` and -- deliberately -- every ``set`` the reference
-  uses, because the ids of new cells follow CPython's set iteration order (hard part 1).  Using
-  the same set operations in the same sequence reproduces the reference's cell numbering bit for bit.
+* **host, Python** (this file): the control flow of ``refine()``.  The ids of new cells follow the iteration order of the
+  reference's Python sets (hard part 1): the same set operations are issued in the same sequence on
+  ``IntSet`` objects (``csrc/pyset.cpp``: CPython's set of small ints restated natively, slot-for-slot equal to the
+  interpreter's tables), a batch of ids per call, so the numbering is reproduced bit for bit without a Python object per
+  cell.  Only the optional 2:1-balance mode (``max_delta_level=True``), which adds ids one by one between topology
+  queries, still uses the interpreter's own sets.
 
 The reference rejects nothing on the CPU; this implementation has no CPU compute path: constructing a
 ``SamplingTree`` without a HIP device raises ``HipUnavailableError``.
 """
 import ctypes as C
 import logging
-import threading
 from time import time
 from typing import Union
 
@@ -25,6 +27,7 @@ import numpy as np
 import torch as pt
 
 from . import _lib
+from .intset import IntSet
 
 logger = logging.getLogger(__name__)
 logging.basicConfig(level=logging.INFO, format='[%(asctime)s] %(levelname)-8s %(message)s', datefmt='%Y-%m-%d %H:%M:%S',
@@ -49,6 +52,13 @@ def _make_backend(vertices, target, k):
     return HipTreeBackend(vertices, target, k)
 
 
+def _ordered(ids):
+    """the elements of an ``IntSet`` / ``set`` in iteration order, int64"""
+    if isinstance(ids, IntSet):
+        return ids.to_array()
+    return np.fromiter(ids, dtype=np.int64, count=len(ids))
+
+
 class _Topology:
     """numpy-facing wrapper of the native topology engine (csrc/topology.cpp)."""
 
@@ -59,6 +69,52 @@ class _Topology:
         self._h = C.c_void_p(self._lib.s3t_create(dim, float(width), rc.ctypes.data_as(C.c_void_p)))
         if not self._h.value:
             raise RuntimeError("topology engine: could not be created (dimension must be 2 or 3)")
+        # host-side shadow of what the refine loop itself needs (cell count, levels): the engine applies submitted
+        # batches in its own thread and is only waited for when its tables are read
+        self.n_created = 1
+        self._level_shadow = np.zeros(4096, dtype=np.int32)
+
+    # -- asynchronous updates (applied in submission order by the engine's worker thread) ----------------------------
+    def _submit(self, kind, ids, relink=0):
+        a = self._ids(ids)
+        rc = self._lib.s3t_submit(self._h, kind, a.ctypes.data_as(C.c_void_p), len(a), int(relink))
+        if rc != 0:
+            raise MemoryError("topology engine: out of host memory")
+
+    def submit_refine(self, parents, relink):
+        """children of the ordered parents (ids known up front: consecutive from the current cell count); returns the id
+        of the first new cell"""
+        p = self._ids(parents)
+        first, n_new = self.n_created, len(p) * self.nch
+        if first + n_new > len(self._level_shadow):
+            grown = np.zeros(max(2 * len(self._level_shadow), first + n_new), dtype=np.int32)
+            grown[:first] = self._level_shadow[:first]
+            self._level_shadow = grown
+        self._level_shadow[first:first + n_new] = np.repeat(self._level_shadow[p] + 1, self.nch)
+        self.n_created = first + n_new
+        self._submit(0, p, relink)
+        return first
+
+    def submit_relink_parent_of(self, cells):
+        self._submit(1, cells)
+
+    def submit_mark_invalid(self, cells):
+        self._submit(2, cells)
+
+    def sync(self):
+        """wait for the submitted updates; raises if one of them failed"""
+        rc = self._lib.s3t_sync(self._h)
+        if rc == -2:
+            raise MemoryError("topology engine: out of host memory")
+        if rc != 0:
+            raise RuntimeError("topology engine: tried to refine a cell that is not a leaf")
+        if self._lib.s3t_n_cells(self._h) != self.n_created:
+            raise RuntimeError("host topology and device cell arrays disagree about the ids of the new cells")
+
+    @property
+    def level_now(self):
+        """levels of all cells created so far, including batches the engine has not applied yet"""
+        return self._level_shadow[:self.n_created]
 
     def close(self):
         h = getattr(self, "_h_raw", None)
@@ -129,12 +185,9 @@ class _Topology:
         return np.ascontiguousarray(a, dtype=np.int64)
 
     def refine(self, parents, relink):
-        p = self._ids(parents)
-        first = self._lib.s3t_refine(self._h, p.ctypes.data_as(C.c_void_p), len(p), int(relink))
-        if first == -2:
-            raise MemoryError("topology engine: out of host memory")
-        if first < 0:
-            raise RuntimeError("topology engine: tried to refine a cell that is not a leaf")
+        """synchronous form of ``submit_refine``"""
+        first = self.submit_refine(parents, relink)
+        self.sync()
         return first
 
     def relink_parent_of(self, cells):
@@ -261,7 +314,10 @@ class SamplingTree(object):
         self._width = None
         self._n_dimensions = vertices.size(-1)
         self._k = 8 if self._n_dimensions == 2 else 26
-        self._leaf_cells = set()
+        # IntSet = CPython's set restated natively (same iteration order); the 2:1-balance mode interleaves single
+        # insertions with topology queries and stays on the interpreter's sets
+        self._new_set = set if max_delta_level else IntSet
+        self._leaf_cells = self._new_set()
         self._n_cells_after_uniform = None
         self._N_cells_per_iter = []
         self._final_nodes = None
@@ -284,7 +340,6 @@ class SamplingTree(object):
                                       target.detach().cpu().to(pt.float64).numpy(), self._k)
         self._values = None
         self._topo_engine = None
-        self._topo_pending = None        # join() of a topology update still running in its helper thread
         self._cells = _CellList(self)
         self._create_first_cell()
         # like the reference (s_cube.py:205) the norm is taken in the dtype the user passed (a float32 metric gives a
@@ -326,17 +381,16 @@ class SamplingTree(object):
 
     @property
     def _topo(self):
-        """the native topology tables; waits for an update that is still running (``_refine_batch``)"""
-        pending = self._topo_pending
-        if pending is not None:
-            self._topo_pending = None
-            pending()
-        return self._topo_engine
+        """the native topology tables, up to date: waits for the batches the engine has not applied yet"""
+        engine = self._topo_engine
+        if engine is not None:
+            engine.sync()
+        return engine
 
     def _cell_values(self):
         """metric / gain of all cells on the host (lazy download; used by the ``Cell`` views and the parity tests)"""
-        if self._values is None or len(self._values["metric"]) != self._topo.n_cells:
-            self._values = self._backend.download(self._topo.n_cells)
+        if self._values is None or len(self._values["metric"]) != self._topo_engine.n_created:
+            self._values = self._backend.download(self._topo_engine.n_created)
         return self._values
 
     def _update_leaf_cells(self, idx_parents: set, idx_children: set) -> None:
@@ -344,8 +398,8 @@ class SamplingTree(object):
         self._leaf_cells.update(idx_children)
 
     def _update_min_ref_level(self) -> None:
-        level = self._topo.level
-        leaves = np.fromiter(self._leaf_cells, dtype=np.int64, count=len(self._leaf_cells))
+        level = self._topo_engine.level_now
+        leaves = _ordered(self._leaf_cells)
         self._current_min_level = max(self._current_min_level, int(level[leaves].min()))
 
     def _check_stopping_criteria(self) -> bool:
@@ -377,7 +431,7 @@ class SamplingTree(object):
         when the cell was created (the reference recomputes the identical values); the sum of squares is one device
         reduction.  Multi-GPU runs split the reduction range across ranks and all-reduce (parallel.py)."""
         from . import parallel
-        sumsq = parallel.allreduce_sumsq(self._backend, self._topo.n_cells)
+        sumsq = parallel.allreduce_sumsq(self._backend, self._topo_engine.n_created)
         _ratio = float(np.sqrt(sumsq)) / self._target_norm
         self._metric.append(_ratio)
         return _ratio < self._min_metric
@@ -385,36 +439,19 @@ class SamplingTree(object):
     # ------------------------------------------------------------------------------------------------------------
     def _refine_batch(self, order: np.ndarray, uniform: bool):
         """create the children of the ordered parents: topology on the host, geometry + metric + gain on the device
-        (body shared by s_cube.py:531-555 and 879-900).  Returns (first new id, number of new cells): the ids of the new
-        cells are known up front (children are numbered consecutively from the current cell count), so the kernels are
-        launched first, the native topology engine then works in a helper thread (the foreign call releases the
-        interpreter lock) while the caller carries on with its set bookkeeping, the geometry masks, ...; the next access
-        to ``self._topo`` waits for it."""
+        (body shared by s_cube.py:531-555 and 879-900).  Returns (first new id, number of new cells).  The ids of the new
+        cells are known up front (children are numbered consecutively from the current cell count): the kernels are
+        launched, the batch is handed to the topology engine's worker thread, and the caller carries on -- nothing the
+        refine loop decides depends on the links or node ids (only the 2:1-balance mode reads them, through
+        ``self._topo``, which waits)."""
         nch = 2 ** self._n_dimensions
-        engine = self._topo                       # joins an earlier update
-        first = engine.n_cells
+        engine = self._topo_engine
+        first = engine.n_created
         n_new = self._backend.refine_batch(order, first)
         if n_new != len(order) * nch:
             raise RuntimeError("host topology and device cell arrays disagree about the ids of the new cells")
-        result = {}
-
-        def work():
-            try:
-                result["first"] = engine.refine(order, relink=uniform)
-            except BaseException as err:          # handed to the caller by join()
-                result["error"] = err
-
-        worker = threading.Thread(target=work)
-        worker.start()
-
-        def join():
-            worker.join()
-            if "error" in result:
-                raise result["error"]
-            if result["first"] != first or engine.n_cells != first + n_new:
-                raise RuntimeError("host topology and device cell arrays disagree about the ids of the new cells")
-
-        self._topo_pending = join                 # taken by the next access to self._topo
+        if engine.submit_refine(order, relink=uniform) != first:
+            raise RuntimeError("host topology and device cell arrays disagree about the ids of the new cells")
         self._n_cells += n_new
         self._values = None
         return first, n_new
@@ -425,26 +462,26 @@ class SamplingTree(object):
         self._times["t_start_uniform"] = time()
         for j in range(self._min_level):
             logger.info(f"\r\tStarting iteration no. {j}, N_cells = {len(self._leaf_cells)}")
-            order = np.fromiter(self._leaf_cells, dtype=np.int64, count=len(self._leaf_cells))
+            order = _ordered(self._leaf_cells)
             first, n_new = self._refine_batch(order, uniform=True)
-            all_parents, all_children = set(), set()
-            all_parents.update(order.tolist())
+            all_parents, all_children = self._new_set(), self._new_set()
+            all_parents.update(order.tolist() if self._new_set is set else order)
             all_children.update(range(first, first + n_new))
             self._update_leaf_cells(all_parents, all_children)
             self._current_min_level += 1
             self._current_max_level += 1
-            self._remove_invalid_cells(set(range(first, first + n_new)), _batch=(first, n_new))
+            self._remove_invalid_cells(self._new_set(range(first, first + n_new)), _batch=(first, n_new))
         logger.info("Finished uniform refinement.")
         self._times["t_end_uniform"] = time()
 
     def _refine_cells(self, to_refine: set):
         """s_cube.py:865-902; returns the id range of the new cells"""
-        order = np.fromiter(to_refine, dtype=np.int64, count=len(to_refine))
-        if len(order):                            # levels of the parents, read before the tables start to change
-            self._current_max_level = max(self._current_max_level, int(self._topo.level[order].max()) + 1)
+        order = _ordered(to_refine)
+        if len(order):
+            self._current_max_level = max(self._current_max_level, int(self._topo_engine.level_now[order].max()) + 1)
         first, n_new = self._refine_batch(order, uniform=False)
-        all_parents, all_children = set(), set()
-        all_parents.update(order.tolist())
+        all_parents, all_children = self._new_set(), self._new_set()
+        all_parents.update(order.tolist() if self._new_set is set else order)
         all_children.update(range(first, first + n_new))
         self._update_leaf_cells(all_parents, all_children)
         return first, n_new
@@ -457,27 +494,32 @@ class SamplingTree(object):
             _geometry_no = [_geometry_no]
         _geometries = [self._geometry[g] for g in _geometry_no] if _geometry_no is not None else self._geometry
 
-        order = np.fromiter(_refined_cells, dtype=np.int64, count=len(_refined_cells))
+        order = _ordered(_refined_cells)
         if self._pre_select:
             # reference quirk (s_cube.py:1832-1836): with pre_select the `elif` never runs, no cell is ever flagged
             flags = np.zeros(len(order), dtype=bool)
             if _batch is not None:
                 self._backend.commit(_batch[0], _batch[1], use_invalid=False)
+                self._last_invalid_range = np.zeros(_batch[1], dtype=bool)
         elif _batch is not None:
             flags_range = self._backend.mask(_geometries, int(_refine_geometry), first=_batch[0], n=_batch[1])
             self._backend.commit(_batch[0], _batch[1], use_invalid=True)
             flags = flags_range[order - _batch[0]]
+            self._last_invalid_range = flags_range
         else:
             flags = self._backend.mask(_geometries, int(_refine_geometry), cells=order)
 
         # set(filter(None, result)): insertion in iteration order, id 0 and None dropped (s_cube.py:709)
-        _idx = set(i for i in order[flags].tolist() if i)
-        if _idx == set():
+        if self._new_set is set:
+            _idx = set(i for i in order[flags].tolist() if i)
+        else:
+            _idx = IntSet().update_flagged(order, flags)
+        if len(_idx) == 0:
             return None
         elif _refine_geometry:
             return _idx
         else:
-            self._topo.mark_invalid(np.fromiter(_idx, dtype=np.int64, count=len(_idx)))
+            self._topo_engine.submit_mark_invalid(_ordered(_idx))
             self._leaf_cells -= _idx
             return None
 
@@ -504,8 +546,8 @@ class SamplingTree(object):
                 self._compute_n_cells_per_iter()
 
             # top-N leaves by (gain, -id) -- radix select on the device (replaces heapq.nlargest, s_cube.py:601-602)
-            _leaf_cells_sorted = self._backend.topn(self._topo.n_cells, min(self._cells_per_iter, self._n_cells))
-            to_refine = set()
+            _leaf_cells_sorted = self._backend.topn(self._topo_engine.n_created, min(self._cells_per_iter, self._n_cells))
+            to_refine = self._new_set()
             if self._max_delta_level:
                 for i in _leaf_cells_sorted.tolist():
                     to_refine.add(i)
@@ -513,11 +555,11 @@ class SamplingTree(object):
                     nb_to_refine_as_well = set(self._check_nb(i))
                     to_refine.update(self._check_constraint(nb_to_refine_as_well))
             else:
-                to_refine.update(_leaf_cells_sorted.tolist())
-                self._topo.relink_parent_of(_leaf_cells_sorted)
+                to_refine.update(_leaf_cells_sorted)
+                self._topo_engine.submit_relink_parent_of(_leaf_cells_sorted)
 
             first, n_new = self._refine_cells(to_refine)
-            self._remove_invalid_cells(set(range(first, first + n_new)), _batch=(first, n_new))
+            self._remove_invalid_cells(self._new_set(range(first, first + n_new)), _batch=(first, n_new))
 
             if self._n_cells_max is None:
                 self._compute_captured_metric()
@@ -572,19 +614,20 @@ class SamplingTree(object):
                 logger.warning("Could not find any cells to refine. Skipping geometry refinement.")
                 logger.info("Finished geometry refinement.")
                 return
-            _all_cells = set(touching)
-            level = self._topo.level
-            _global_min_level = min([int(level[cell]) for cell in _all_cells])
+            _all_cells = self._new_set(touching)
+            level = self._topo_engine.level_now
+            _touching_levels = level[_ordered(_all_cells)]
+            _global_min_level = int(_touching_levels.min())
             if self._geometry[g].min_refinement_level is None:
-                _global_max_level = max([int(level[cell]) for cell in _all_cells])
+                _global_max_level = int(_touching_levels.max())
             else:
                 _global_max_level = self._geometry[g].min_refinement_level
             logger.info(f"Found a minimum cell level of {_global_min_level}. Target level is {_global_max_level}.")
 
             while _global_max_level > _global_min_level:
                 logger.info(f"\r\t\t\t\t\t\t\t\t\tRefining level {_global_min_level+1} / {_global_max_level}.")
-                to_refine, checked = set(), set()
-                level = self._topo.level
+                to_refine, checked = self._new_set(), set()
+                level = self._topo_engine.level_now
                 if self._max_delta_level:
                     for i in _all_cells:
                         if i in checked:
@@ -599,26 +642,30 @@ class SamplingTree(object):
                 else:
                     # same insertion sequence as the loop above, neighbour refresh batched into one native call (the
                     # refresh of one parent does not depend on the refresh of another)
-                    cells = np.fromiter(_all_cells, dtype=np.int64, count=len(_all_cells))
+                    cells = _ordered(_all_cells)
                     cells = cells[level[cells] < _global_max_level]
-                    to_refine.update(cells.tolist())
-                    self._topo.relink_parent_of(cells)
+                    to_refine.update(cells)
+                    self._topo_engine.submit_relink_parent_of(cells)
 
                 first, n_new = self._refine_cells(to_refine)
-                _idx_new = set(range(first, first + n_new))
+                _idx_new = self._new_set(range(first, first + n_new))
                 self._remove_invalid_cells(_idx_new, _geometry_no=g, _batch=(first, n_new))
 
-                # among the new *valid* cells, which ones still touch the geometry?
-                fc = self._topo.first_child
-                still_leaf = {i for i in _idx_new if fc[i] == -1}
+                # among the new *valid* cells, which ones still touch the geometry?  ({i for i in _idx_new if ...}: a
+                # new set filled in the iteration order of _idx_new; a new cell is a leaf unless the geometry check above
+                # removed it)
+                _new_ids = _ordered(_idx_new)
+                _new_ids = _new_ids[~self._last_invalid_range[_new_ids - first]]
+                still_leaf = self._new_set()
+                still_leaf.update(_new_ids.tolist() if self._new_set is set else _new_ids)
                 touching = self._remove_invalid_cells(still_leaf, _refine_geometry=True, _geometry_no=g)
                 if touching is None:
                     raise TypeError("'NoneType' object is not iterable")    # reference behaviour at s_cube.py:855
-                _all_cells = set(touching)
+                _all_cells = self._new_set(touching)
                 _global_min_level += 1
 
-        level = self._topo.level
-        leaves = np.fromiter(self._leaf_cells, dtype=np.int64, count=len(self._leaf_cells))
+        level = self._topo_engine.level_now
+        leaves = _ordered(self._leaf_cells)
         self._current_max_level = int(level[leaves].max())
         logger.info("Finished geometry refinement.")
 
@@ -630,7 +677,7 @@ class SamplingTree(object):
         faces, nodes = self._topo.finalize()
         self.face_ids = pt.from_numpy(faces.astype(dtype))
         self._final_nodes = pt.from_numpy(nodes)
-        leaves = np.fromiter(self._leaf_cells, dtype=np.int64, count=len(self._leaf_cells))
+        leaves = _ordered(self._leaf_cells)
         self.all_centers = pt.from_numpy(self._topo.center[leaves].copy())
         self.all_levels = pt.from_numpy(self._topo.level[leaves].astype(np.int64)).unsqueeze(-1)
         self._times["t_end_renumber"] = time()

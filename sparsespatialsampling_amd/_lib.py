@@ -95,8 +95,8 @@ TOPO_SIGNATURES = {
     "s3t_mark_invalid": (None, [c_vp, c_vp, c_i64]),
     "s3t_check_nb": (c_int, [c_vp, c_i64, c_vp]),
     "s3t_finalize": (c_i64, [c_vp, C.POINTER(c_i64)]),
-    "s3t_face_ids": (c_vp, [c_vp]),
-    "s3t_unique_nodes": (c_vp, [c_vp]),
+    "s3t_export_grid": (None, [c_vp, c_vp, c_int, c_vp]),
+    "s3t_gather_cells": (None, [c_vp, c_vp, c_i64, c_vp, c_vp]),
     "s3t_selfcheck": (c_int, [c_int]),
     "s3t_submit": (c_int, [c_vp, c_int, c_vp, c_i64, c_int]),
     "s3t_sync": (c_int, [c_vp]),

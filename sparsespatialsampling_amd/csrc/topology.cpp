@@ -15,12 +15,14 @@
 // current: like the reference they are written when children are created and refreshed only where the reference
 // refreshes them, because the shared-node numbering depends on that staleness.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <condition_variable>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <functional>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -67,6 +69,84 @@ int dir_child(int dim, const int d[3]) {
     return -1;
 }
 
+// minimal fork-join pool: run(n, grain, fn) calls fn(begin, end) over [0, n) in chunks of `grain` on the pool's threads
+// and the caller; returns when every chunk is done
+struct Pool {
+    std::vector<std::thread> threads;
+    std::mutex m;
+    std::condition_variable cv_start, cv_done;
+    const std::function<void(int64_t, int64_t)> *fn = nullptr;
+    int64_t n = 0, grain = 1;
+    std::atomic<int64_t> next{0};
+    int working = 0;
+    uint64_t epoch = 0;
+    bool stop = false;
+
+    explicit Pool(int n_threads) {
+        for (int i = 1; i < n_threads; ++i) threads.emplace_back([this] { loop(); });
+    }
+    ~Pool() {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            stop = true;
+        }
+        cv_start.notify_all();
+        for (auto &t : threads) t.join();
+    }
+    void drain() {
+        while (true) {
+            const int64_t b = next.fetch_add(grain);
+            if (b >= n) return;
+            (*fn)(b, std::min(n, b + grain));
+        }
+    }
+    void loop() {
+        uint64_t seen = 0;
+        while (true) {
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv_start.wait(lk, [&] { return stop || epoch != seen; });
+                if (stop) return;
+                seen = epoch;
+            }
+            drain();
+            {
+                std::lock_guard<std::mutex> lk(m);
+                --working;
+            }
+            cv_done.notify_one();
+        }
+    }
+    void run(int64_t n_, int64_t grain_, const std::function<void(int64_t, int64_t)> &f) {
+        if (threads.empty() || n_ <= grain_) {
+            if (n_ > 0) f(0, n_);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> lk(m);
+            fn = &f;
+            n = n_;
+            grain = grain_;
+            next.store(0);
+            working = (int)threads.size();
+            ++epoch;
+        }
+        cv_start.notify_all();
+        drain();
+        std::unique_lock<std::mutex> lk(m);
+        cv_done.wait(lk, [&] { return working == 0; });
+    }
+};
+
+// transient encodings of a node id while a batch is assembled in parallel (final ids are >= 0)
+constexpr int64_t REF_BASE = (int64_t)1 << 20;
+inline int64_t enc_new(int local) { return -(int64_t)(1 + local); }                      // l-th new node of this parent
+inline bool is_new(int64_t v) { return v < 0 && v > -REF_BASE; }
+inline int dec_new(int64_t v) { return (int)(-v - 1); }
+inline int64_t enc_ref(int64_t entry) { return -(REF_BASE + entry); }                     // entry = cell * nch + node
+inline bool is_ref(int64_t v) { return v <= -REF_BASE; }
+inline int64_t dec_ref(int64_t v) { return -v - REF_BASE; }
+
 struct NbEntry { int8_t pslot; int8_t target; };   // pslot < 0: sibling `target`; else parent's neighbour slot + its child
 
 // node-sharing rules of _assign_indices.  For child i the entries are processed in order; an entry either looks the
@@ -112,11 +192,13 @@ struct Topo {
     std::vector<double> nodes;        // [n_nodes][dim]
     std::vector<NbEntry> nb_table;    // [nch][nnb]
     // finalize() results
-    std::vector<int64_t> face_ids;
-    std::vector<double> unique_nodes;
-    int64_t n_leaf = 0;
+    std::vector<int64_t> face_ids;    // after finalize(): old node id -> new node id (-1 = dropped)
+    int64_t n_leaf = 0, n_unique = 0;
 
-    int64_t n_cells() const { return (int64_t)level.size(); }
+    int64_t n_used = 0;               // cells created so far; the cell tables are sized to their capacity
+    double half_width[64], quarter_width[64];   // (0.5 * width) / 2^level, (0.25 * width) / 2^level
+
+    int64_t n_cells() const { return n_used; }
     int64_t n_nodes() const { return (int64_t)(nodes.size() / dim); }
     const int *dir(int c) const { return dim == 2 ? DIR2[c] : DIR3[c]; }
 
@@ -144,26 +226,27 @@ struct Topo {
     }
 
     void push_cell(int32_t lvl, int32_t par, const double *c) {
-        level.push_back(lvl);
-        parent.push_back(par);
-        first_child.push_back(LEAF);
-        nb.insert(nb.end(), nnb, -1);
-        node_idx.insert(node_idx.end(), nch, 0);
-        center.insert(center.end(), c, c + dim);
+        const size_t i = (size_t)n_used++;
+        level[i] = lvl;
+        parent[i] = par;
+        first_child[i] = LEAF;
+        for (int s = 0; s < nnb; ++s) nb[i * nnb + s] = -1;
+        for (int s = 0; s < nch; ++s) node_idx[i * nch + s] = 0;
+        for (int j = 0; j < dim; ++j) center[i * dim + j] = c[j];
     }
 
-    // room for `extra` more cells (one geometric growth step instead of one reallocation check per vector per cell)
+    // room for `extra` more cells: the tables grow geometrically and are indexed directly (no per-cell push_back)
     void reserve_cells(int64_t extra) {
         const size_t want = (size_t)(n_cells() + extra);
-        if (want <= level.capacity()) return;
-        const size_t cap = std::max(want, level.capacity() * 2);
-        level.reserve(cap);
-        parent.reserve(cap);
-        first_child.reserve(cap);
-        nb.reserve(cap * nnb);
-        node_idx.reserve(cap * nch);
-        center.reserve(cap * dim);
         nodes.reserve(std::max(nodes.capacity(), (size_t)(nodes.size() + (size_t)extra * dim)));
+        if (want <= level.size()) return;
+        const size_t cap = std::max<size_t>(std::max(want, level.size() * 2), 64);
+        level.resize(cap);
+        parent.resize(cap);
+        first_child.resize(cap);
+        nb.resize(cap * nnb);
+        node_idx.resize(cap * nch);
+        center.resize(cap * dim);
     }
 
     // _assign_neighbors(cell, children=existing children)
@@ -171,14 +254,18 @@ struct Topo {
         const int32_t fc = first_child[P];
         if (fc < 0) return;
         const int32_t *pnb = &nb[(size_t)P * nnb];
+        int32_t q_of[26], fc_of[26];                                   // the parent's neighbours and their first child
+        for (int s = 0; s < nnb; ++s) {
+            q_of[s] = pnb[s];
+            fc_of[s] = q_of[s] >= 0 ? first_child[q_of[s]] : -1;
+        }
+        const NbEntry *tab = nb_table.data();
         for (int c = 0; c < nch; ++c) {
             int32_t *cnb = &nb[(size_t)(fc + c) * nnb];
             for (int s = 0; s < nnb; ++s) {
-                const NbEntry e = nb_table[(size_t)c * nnb + s];
+                const NbEntry e = tab[c * nnb + s];
                 if (e.pslot < 0) { cnb[s] = fc + e.target; continue; }
-                int32_t q = pnb[e.pslot];
-                if (q >= 0 && first_child[q] >= 0) q = first_child[q] + e.target;     // parent_or_child
-                cnb[s] = q;
+                cnb[s] = fc_of[e.pslot] >= 0 ? fc_of[e.pslot] + e.target : q_of[e.pslot];     // parent_or_child
             }
         }
     }
@@ -189,7 +276,7 @@ struct Topo {
     }
 
     int64_t new_node(int32_t cell, int node) {
-        const double off = (0.5 * width) / std::ldexp(1.0, level[cell]);
+        const double off = half_width[level[cell]];
         for (int j = 0; j < dim; ++j) nodes.push_back(center[(size_t)cell * dim + j] + dir(node)[j] * off);
         return n_nodes() - 1;
     }
@@ -216,6 +303,211 @@ struct Topo {
                 if (!found) ni[r.node] = new_node(cell, r.node);
             }
         }
+    }
+
+    // ---- a whole batch at once, on several threads, with the result of the sequential procedure ------------------
+    // Sequentially, parent i sees the parents before it in the batch as refined and their children as existing leaves,
+    // and new node ids are handed out in processing order.  Because the ids of the children are known up front
+    // (first + 2^d * position) all of that can be evaluated per parent from the state before the batch plus the
+    // position table: pass A builds the children of every parent independently (links; node entries as final id /
+    // l-th new node of this parent / reference to an entry of an earlier parent's child), an exclusive scan of the
+    // new-node counts gives every parent its id range, pass C turns "l-th new node" into ids and writes the
+    // coordinates, pass D follows the references (a lattice point is shared by at most 2^d cells: short chains).
+    std::vector<int32_t> batch_pos;      // cell -> position in the current batch, -1 otherwise
+    std::vector<int32_t> new_count;      // per parent of the batch: nodes it creates
+    std::vector<int64_t> new_base;       // exclusive scan of new_count
+    Pool *pool = nullptr;
+    int n_threads = 1;
+    int64_t par_min = 64;                // smaller batches take the sequential procedure (S3_TOPO_PAR_MIN)
+
+    const std::vector<NodeRule> &rules_of(int child) const { return dim == 2 ? NODE_RULES_2D[child] : NODE_RULES_3D[child]; }
+
+    void build_children(int64_t i, const int64_t *parents, int64_t first) {
+        const int32_t P = (int32_t)parents[i];
+        const int32_t fc = (int32_t)(first + i * nch);
+        const int32_t lvl = level[P] + 1;
+        const double off = quarter_width[level[P]];
+        for (int c = 0; c < nch; ++c) {
+            const size_t cell = (size_t)fc + c;
+            level[cell] = lvl;
+            parent[cell] = P;
+            first_child[cell] = LEAF;
+            for (int j = 0; j < dim; ++j) center[cell * dim + j] = center[(size_t)P * dim + j] + dir(c)[j] * off;
+            for (int m = 0; m < nch; ++m) node_idx[cell * nch + m] = 0;
+        }
+        // links: a neighbour of the parent counts as refined when it was before the batch or comes earlier in it
+        const int32_t *pnb = &nb[(size_t)P * nnb];
+        int32_t q_of[26], fc_of[26];
+        for (int s = 0; s < nnb; ++s) {
+            const int32_t q = pnb[s];
+            int32_t f = -1;
+            if (q >= 0) {
+                f = first_child[q];
+                if (f == LEAF && batch_pos[q] >= 0 && batch_pos[q] < i) f = (int32_t)(first + (int64_t)batch_pos[q] * nch);
+            }
+            q_of[s] = q;
+            fc_of[s] = f;
+        }
+        const NbEntry *tab = nb_table.data();
+        for (int c = 0; c < nch; ++c) {
+            int32_t *cnb = &nb[(size_t)(fc + c) * nnb];
+            for (int s = 0; s < nnb; ++s) {
+                const NbEntry e = tab[c * nnb + s];
+                if (e.pslot < 0) { cnb[s] = fc + e.target; continue; }
+                cnb[s] = fc_of[e.pslot] >= 0 ? fc_of[e.pslot] + e.target : q_of[e.pslot];
+            }
+        }
+        // node entries
+        int local = 0;
+        for (int k = 0; k < nch; ++k) {
+            const int32_t cell = fc + k;
+            int64_t *ni = &node_idx[(size_t)cell * nch];
+            const int32_t *cnb = &nb[(size_t)cell * nnb];
+            ni[k] = node_idx[(size_t)P * nch + k];
+            for (const NodeRule &r : rules_of(k)) {
+                if (r.n_cand < 0) {
+                    ni[r.node] = node_idx[(size_t)(fc + r.cand[0][0]) * nch + r.cand[0][1]];
+                    continue;
+                }
+                bool found = false;
+                for (int a = 0; a < r.n_cand && !found; ++a) {
+                    const int32_t q = cnb[r.cand[a][0]];
+                    if (q < 0) continue;
+                    const int64_t entry = (int64_t)q * nch + r.cand[a][1];
+                    if (q >= first) {
+                        // a cell of this batch: a leaf by construction; its level is its parent's + 1
+                        const int64_t j = (q - first) / nch;
+                        if (level[parents[j]] + 1 != lvl) continue;
+                        ni[r.node] = j == i ? node_idx[entry] : enc_ref(entry);      // own sibling: entry as it stands
+                        found = true;
+                    } else if (first_child[q] == LEAF && !(batch_pos[q] >= 0 && batch_pos[q] < i) && level[q] == lvl) {
+                        ni[r.node] = node_idx[entry];
+                        found = true;
+                    }
+                }
+                if (!found) ni[r.node] = enc_new(local++);
+            }
+        }
+        new_count[i] = local;
+    }
+
+    // pass C: the parent's new nodes get their ids (in the order pass A met them) and their coordinates
+    void number_new_nodes(int64_t i, int64_t first, int64_t nodes_before) {
+        const int32_t fc = (int32_t)(first + i * nch);
+        const int64_t base = nodes_before + new_base[i];
+        int seen = 0;
+        for (int k = 0; k < nch; ++k) {
+            const int32_t cell = fc + k;
+            int64_t *ni = &node_idx[(size_t)cell * nch];
+            auto fix = [&](int node) {
+                const int64_t v = ni[node];
+                if (!is_new(v)) return;
+                const int l = dec_new(v);
+                if (l == seen) {
+                    const double off = half_width[level[cell]];
+                    for (int j = 0; j < dim; ++j)
+                        nodes[(size_t)(base + l) * dim + j] = center[(size_t)cell * dim + j] + dir(node)[j] * off;
+                    ++seen;
+                }
+                ni[node] = base + l;
+            };
+            fix(k);
+            for (const NodeRule &r : rules_of(k)) fix(r.node);
+        }
+    }
+
+    // pass D: follow references into earlier parents' children until a final id is met
+    void resolve_refs(int64_t i, int64_t first) {
+        int64_t *ni = &node_idx[(size_t)(first + i * nch) * nch];
+        for (int e = 0; e < nch * nch; ++e) {
+            int64_t v = ni[e];
+            if (!is_ref(v)) continue;
+            while (is_ref(v)) v = __atomic_load_n(&node_idx[(size_t)dec_ref(v)], __ATOMIC_RELAXED);
+            __atomic_store_n(&ni[e], v, __ATOMIC_RELAXED);
+        }
+    }
+
+    void prefetch_parent(int32_t P) const {
+        const int32_t *row = &nb[(size_t)P * nnb];
+        __builtin_prefetch(row);
+        __builtin_prefetch(row + 16);
+        __builtin_prefetch(&node_idx[(size_t)P * nch]);
+        __builtin_prefetch(&center[(size_t)P * dim]);
+        __builtin_prefetch(&level[P]);
+    }
+    void prefetch_neighbours(int32_t P) const {
+        const int32_t *row = &nb[(size_t)P * nnb];
+        for (int s = 0; s < nnb; ++s) {
+            const int32_t q = row[s];
+            if (q < 0) continue;
+            __builtin_prefetch(&first_child[q]);
+            __builtin_prefetch(&level[q]);
+            __builtin_prefetch(&batch_pos[q]);
+            __builtin_prefetch(&node_idx[(size_t)q * nch]);
+        }
+    }
+    void prefetch_neighbour_children(int32_t P) const {
+        const int32_t *row = &nb[(size_t)P * nnb];
+        for (int s = 0; s < nnb; ++s) {
+            const int32_t q = row[s];
+            if (q < 0) continue;
+            const int32_t fc = first_child[q];
+            if (fc < 0) continue;
+            __builtin_prefetch(&first_child[fc]);
+            __builtin_prefetch(&level[fc]);
+            __builtin_prefetch(&batch_pos[fc]);
+            for (int c = 0; c < nch; ++c) __builtin_prefetch(&node_idx[(size_t)(fc + c) * nch]);
+        }
+    }
+
+    // returns the id of the first new cell, -1 if a parent is not a leaf (or listed twice)
+    int64_t refine_batch_parallel(const int64_t *parents, int64_t n, int relink) {
+        const int64_t first = n_cells(), nodes_before = n_nodes();
+        reserve_cells(n * nch);
+        if (batch_pos.size() < level.size()) batch_pos.resize(level.size(), -1);
+        int64_t bad = -1;
+        for (int64_t i = 0; i < n; ++i) {
+            const int64_t P = parents[i];
+            if (P < 0 || P >= first || first_child[P] != LEAF || batch_pos[P] >= 0) { bad = i; break; }
+            batch_pos[P] = (int32_t)i;
+        }
+        if (bad >= 0) {
+            for (int64_t i = 0; i < bad; ++i) batch_pos[parents[i]] = -1;
+            return -1;
+        }
+        new_count.assign((size_t)n, 0);
+        new_base.assign((size_t)n, 0);
+        const int64_t grain = 128;
+        pool->run(n, grain, [&](int64_t b, int64_t e) {
+            for (int64_t i = b; i < e; ++i) {
+                if (i + 4 < e) prefetch_parent((int32_t)parents[i + 4]);
+                if (i + 2 < e) prefetch_neighbours((int32_t)parents[i + 2]);
+                if (i + 1 < e) prefetch_neighbour_children((int32_t)parents[i + 1]);
+                build_children(i, parents, first);
+            }
+        });
+        int64_t total = 0;
+        for (int64_t i = 0; i < n; ++i) {
+            new_base[i] = total;
+            total += new_count[i];
+        }
+        nodes.resize((size_t)(nodes_before + total) * dim);
+        pool->run(n, 512, [&](int64_t b, int64_t e) {
+            for (int64_t i = b; i < e; ++i) number_new_nodes(i, first, nodes_before);
+        });
+        pool->run(n, 512, [&](int64_t b, int64_t e) {
+            for (int64_t i = b; i < e; ++i) resolve_refs(i, first);
+        });
+        for (int64_t i = 0; i < n; ++i) {
+            first_child[parents[i]] = (int32_t)(first + i * nch);
+            batch_pos[parents[i]] = -1;
+        }
+        n_used = first + n * nch;
+        if (relink)
+            pool->run(n, 256, [&](int64_t b, int64_t e) {
+                for (int64_t i = b; i < e; ++i) assign_neighbors((int32_t)parents[i]);
+            });
+        return first;
     }
 
     // ---- command queue: with max_delta_level=False nothing the refine loop decides depends on the links or node ids
@@ -249,12 +541,13 @@ struct Topo {
         }
         cv_work.notify_one();
         if (worker.joinable()) worker.join();
+        delete pool;
     }
 
     // one parent of _refine_cells / the uniform loop: children, neighbour links, node ids
     void refine_one(int32_t P) {
         const int32_t fc = (int32_t)n_cells();
-        const double off = (0.25 * width) / std::ldexp(1.0, level[P]);
+        const double off = quarter_width[level[P]];
         for (int c = 0; c < nch; ++c) {
             double x[3];
             for (int j = 0; j < dim; ++j) x[j] = center[(size_t)P * dim + j] + dir(c)[j] * off;
@@ -280,7 +573,22 @@ void *s3t_create(int dim, double width, const double *root_center) try {
     t->nnb = dim == 2 ? 8 : 26;
     t->width = width;
     t->build_nb_table();
+    for (int l = 0; l < 64; ++l) {
+        t->half_width[l] = (0.5 * width) / std::ldexp(1.0, l);
+        t->quarter_width[l] = (0.25 * width) / std::ldexp(1.0, l);
+    }
+    t->reserve_cells(1);
     t->push_cell(0, -1, root_center);
+    {
+        // worker threads of a batch: S3_TOPO_THREADS, else up to 8 of the cores this process may use
+        const char *env = std::getenv("S3_TOPO_THREADS");
+        int nt = env ? std::atoi(env) : (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency() / 2));
+        if (nt < 1) nt = 1;
+        if (nt > 64) nt = 64;
+        t->n_threads = nt;
+        if (nt > 1) t->pool = new Pool(nt);
+        if (const char *pm = std::getenv("S3_TOPO_PAR_MIN")) t->par_min = std::max(1, std::atoi(pm));
+    }
     // root nodes, s_cube.py:368,386-394: centre + dir * 0.5 * width, ids 0..2^d-1
     for (int c = 0; c < t->nch; ++c) {
         for (int j = 0; j < dim; ++j) t->nodes.push_back(root_center[j] + t->dir(c)[j] * 0.5 * width);
@@ -309,6 +617,7 @@ double *s3t_nodes(void *h) { return static_cast<Topo *>(h)->nodes.data(); }
 // assignment of every parent of the batch afterwards (the "update all nb" pass of the uniform loop, s_cube.py:547-549).
 // Returns the id of the first new cell, -1 if a parent is not a leaf, -2 if the tables could not grow.
 static int64_t refine_batch(Topo *t, const int64_t *parents, int64_t n, int relink) {
+    if (t->pool && n >= t->par_min) return t->refine_batch_parallel(parents, n, relink);
     const int64_t first = t->n_cells();
     t->reserve_cells(n * t->nch);
     // the work per parent is a few dozen dependent look-ups in tables far larger than the caches; two software
@@ -366,7 +675,27 @@ int64_t s3t_refine(void *h, const int64_t *parents, int64_t n, int relink) try {
 
 // cell.parent.children = _assign_neighbors(cell.parent, children=cell.parent.children)   (s_cube.py:609, 834, 494)
 static void relink_parents(Topo *t, const int64_t *cells, int64_t n) {
+    // stays sequential: a listed cell's parent may itself be a child of another listed cell's parent, whose refresh
+    // rewrites the row this one reads -- the result depends on the order of the list.  Software prefetch runs ahead:
+    // the parent id eight positions ahead, its neighbour row four ahead, the neighbours' first-child entries two ahead
     for (int64_t i = 0; i < n; ++i) {
+        if (i + 8 < n) __builtin_prefetch(&t->parent[cells[i + 8]]);
+        if (i + 4 < n) {
+            const int32_t p4 = t->parent[cells[i + 4]];
+            if (p4 >= 0) {
+                __builtin_prefetch(&t->nb[(size_t)p4 * t->nnb]);
+                __builtin_prefetch(&t->nb[(size_t)p4 * t->nnb] + 16);
+                __builtin_prefetch(&t->first_child[p4]);
+            }
+        }
+        if (i + 2 < n) {
+            const int32_t p2 = t->parent[cells[i + 2]];
+            if (p2 >= 0) {
+                const int32_t *row = &t->nb[(size_t)p2 * t->nnb];
+                for (int s_ = 0; s_ < t->nnb; ++s_)
+                    if (row[s_] >= 0) __builtin_prefetch(&t->first_child[row[s_]]);
+            }
+        }
         int32_t p = t->parent[cells[i]];
         if (p >= 0) t->assign_neighbors(p);
     }
@@ -471,40 +800,69 @@ int64_t s3t_finalize(void *h, int64_t *n_unique_nodes) try {
     Topo *t = static_cast<Topo *>(h);
     if (t->wait_idle() != 0) return -1;
     const int nch = t->nch;
-    t->face_ids.clear();
-    for (int64_t c = 0; c < t->n_cells(); ++c)
-        if (t->first_child[c] == LEAF)
-            t->face_ids.insert(t->face_ids.end(), &t->node_idx[(size_t)c * nch], &t->node_idx[(size_t)c * nch] + nch);
-    t->n_leaf = (int64_t)t->face_ids.size() / nch;
-    const int64_t nn = t->n_nodes();
+    const int64_t nc = t->n_cells(), nn = t->n_nodes();
     std::vector<uint8_t> used(nn, 0);
-    int64_t lo = INT64_MAX, hi = -1;
-    for (int64_t v : t->face_ids) {
-        used[v] = 1;
-        if (v < lo) lo = v;
-        if (v > hi) hi = v;
+    int64_t lo = INT64_MAX, hi = -1, n_leaf = 0;
+    for (int64_t c = 0; c < nc; ++c) {
+        if (t->first_child[c] != LEAF) continue;
+        ++n_leaf;
+        const int64_t *ni = &t->node_idx[(size_t)c * nch];
+        for (int s = 0; s < nch; ++s) {
+            const int64_t v = ni[s];
+            used[v] = 1;
+            if (v < lo) lo = v;
+            if (v > hi) hi = v;
+        }
     }
+    t->n_leaf = n_leaf;
     // unused = ids in {0..2^d-1} U [min, max] that no leaf references; everything else keeps a slot (reference quirk)
-    std::vector<int64_t> mapping(nn, -1);
+    t->face_ids.assign((size_t)nn, -1);                 // old node id -> new node id
     int64_t counter = 0;
     for (int64_t i = 0; i < nn; ++i) {
-        bool available = i < nch || (i >= lo && i <= hi);
-        bool unused = available && !used[i];
-        if (!unused) mapping[i] = counter++;
+        const bool available = i < nch || (i >= lo && i <= hi);
+        if (!(available && !used[i])) t->face_ids[i] = counter++;
     }
-    t->unique_nodes.assign((size_t)counter * t->dim, 0.0);
-    for (int64_t i = 0; i < nn; ++i)
-        if (mapping[i] >= 0)
-            for (int j = 0; j < t->dim; ++j) t->unique_nodes[(size_t)mapping[i] * t->dim + j] = t->nodes[(size_t)i * t->dim + j];
-    for (int64_t &v : t->face_ids) v = mapping[v];
+    t->n_unique = counter;
     *n_unique_nodes = counter;
-    return t->n_leaf;
+    return n_leaf;
 } catch (...) {
     return -1;
 }
 
-int64_t *s3t_face_ids(void *h) { return static_cast<Topo *>(h)->face_ids.data(); }
-double *s3t_unique_nodes(void *h) { return static_cast<Topo *>(h)->unique_nodes.data(); }
+// the assembled grid after s3t_finalize: faces [n_leaf][2^d] (int32 when as32, else int64; leaves in ascending cell id)
+// and nodes [n_unique][dim], written into the caller's arrays
+void s3t_export_grid(void *h, void *faces_out, int as32, double *nodes_out) {
+    Topo *t = static_cast<Topo *>(h);
+    const int nch = t->nch, dim = t->dim;
+    const int64_t nc = t->n_cells(), nn = t->n_nodes();
+    const int64_t *map = t->face_ids.data();
+    int64_t row = 0;
+    for (int64_t c = 0; c < nc; ++c) {
+        if (t->first_child[c] != LEAF) continue;
+        const int64_t *ni = &t->node_idx[(size_t)c * nch];
+        if (as32) {
+            int32_t *o = static_cast<int32_t *>(faces_out) + row * nch;
+            for (int s = 0; s < nch; ++s) o[s] = (int32_t)map[ni[s]];
+        } else {
+            int64_t *o = static_cast<int64_t *>(faces_out) + row * nch;
+            for (int s = 0; s < nch; ++s) o[s] = map[ni[s]];
+        }
+        ++row;
+    }
+    for (int64_t i = 0; i < nn; ++i)
+        if (map[i] >= 0)
+            for (int j = 0; j < dim; ++j) nodes_out[(size_t)map[i] * dim + j] = t->nodes[(size_t)i * dim + j];
+}
+
+// centres / levels of the listed cells (the leaves in the host's set order), gathered natively
+void s3t_gather_cells(void *h, const int64_t *ids, int64_t n, double *centers_out, int64_t *levels_out) {
+    Topo *t = static_cast<Topo *>(h);
+    t->wait_idle();
+    for (int64_t i = 0; i < n; ++i) {
+        for (int j = 0; j < t->dim; ++j) centers_out[i * t->dim + j] = t->center[(size_t)ids[i] * t->dim + j];
+        levels_out[i] = t->level[ids[i]];
+    }
+}
 
 // geometric self-check of the node rule tables: every (slot, nb_node) candidate and every sibling copy must name the
 // same lattice point as the node it supplies.  Returns the number of inconsistent entries (0 expected).

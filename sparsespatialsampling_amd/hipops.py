@@ -17,7 +17,12 @@ DTYPE_CODE = {pt.float32: 0, pt.float64: 1}
 
 
 def _stream():
-    return C.c_void_p(pt.cuda.current_stream().cuda_stream)
+    """torch's current HIP stream of the current device as a raw handle (the private getters skip the availability
+    checks of ``torch.cuda.current_stream()``, which cost more than a small kernel launch)"""
+    try:
+        return C.c_void_p(pt._C._cuda_getCurrentRawStream(pt._C._cuda_getDevice()))
+    except AttributeError:          # other torch build
+        return C.c_void_p(pt.cuda.current_stream().cuda_stream)
 
 
 def _ptr(t):

@@ -203,14 +203,26 @@ class _Topology:
         n = self._lib.s3t_check_nb(self._h, int(cell), out.ctypes.data_as(C.c_void_p))
         return out[:n].tolist()
 
-    def finalize(self):
+    def finalize(self, dtype=np.int64):
+        """renumbered grid: faces [n_leaf, 2^d] (``dtype`` int32 / int64), nodes [n_nodes, d]"""
+        self.sync()
         n_nodes = C.c_int64(0)
         n_leaf = self._lib.s3t_finalize(self._h, C.byref(n_nodes))
         if n_leaf < 0:
             raise MemoryError("topology engine: out of host memory")
-        faces = self._view(self._lib.s3t_face_ids, np.int64, (n_leaf, self.nch)).copy()
-        nodes = self._view(self._lib.s3t_unique_nodes, np.float64, (n_nodes.value, self.dim)).copy()
+        faces = np.empty((n_leaf, self.nch), dtype=dtype)
+        nodes = np.empty((n_nodes.value, self.dim), dtype=np.float64)
+        self._lib.s3t_export_grid(self._h, faces.ctypes.data_as(C.c_void_p), int(np.dtype(dtype) == np.int32),
+                                  nodes.ctypes.data_as(C.c_void_p))
         return faces, nodes
+
+    def gather_cells(self, ids):
+        """(centres [n, d] float64, levels [n] int64) of the listed cells"""
+        a = self._ids(ids)
+        centers, levels = np.empty((len(a), self.dim), dtype=np.float64), np.empty(len(a), dtype=np.int64)
+        self._lib.s3t_gather_cells(self._h, a.ctypes.data_as(C.c_void_p), len(a), centers.ctypes.data_as(C.c_void_p),
+                                   levels.ctypes.data_as(C.c_void_p))
+        return centers, levels
 
 
 class Cell(object):
@@ -674,12 +686,12 @@ class SamplingTree(object):
         logger.info("Starting renumbering final mesh.")
         self._times["t_start_renumber"] = time()
         dtype = np.int32 if self._n_cells < pt.iinfo(pt.int32).max else np.int64
-        faces, nodes = self._topo.finalize()
-        self.face_ids = pt.from_numpy(faces.astype(dtype))
+        faces, nodes = self._topo.finalize(dtype)
+        self.face_ids = pt.from_numpy(faces)
         self._final_nodes = pt.from_numpy(nodes)
-        leaves = _ordered(self._leaf_cells)
-        self.all_centers = pt.from_numpy(self._topo.center[leaves].copy())
-        self.all_levels = pt.from_numpy(self._topo.level[leaves].astype(np.int64)).unsqueeze(-1)
+        centers, levels = self._topo.gather_cells(_ordered(self._leaf_cells))
+        self.all_centers = pt.from_numpy(centers)
+        self.all_levels = pt.from_numpy(levels).unsqueeze(-1)
         self._times["t_end_renumber"] = time()
 
     def _create_mesh_info(self, counter: int) -> None:

@@ -100,6 +100,7 @@ TOPO_SIGNATURES = {
     "s3t_selfcheck": (c_int, [c_int]),
     "s3t_submit": (c_int, [c_vp, c_int, c_vp, c_i64, c_int]),
     "s3t_sync": (c_int, [c_vp]),
+    "s3t_stats": (None, [c_vp, c_vp]),
     "s3set_create": (c_vp, []),
     "s3set_destroy": (None, [c_vp]),
     "s3set_len": (c_i64, [c_vp]),

@@ -16,6 +16,7 @@
 // refreshes them, because the shared-node numbering depends on that staleness.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <cstdint>
@@ -147,6 +148,30 @@ inline int64_t enc_ref(int64_t entry) { return -(REF_BASE + entry); }           
 inline bool is_ref(int64_t v) { return v <= -REF_BASE; }
 inline int64_t dec_ref(int64_t v) { return -v - REF_BASE; }
 
+// growable table without value initialisation: growth is a realloc (for tables of this size an address-space remap, no
+// copy) and the new part is first touched by whichever thread fills it
+template <typename T>
+struct Buf {
+    T *p = nullptr;
+    size_t cap = 0;
+    Buf() = default;
+    Buf(const Buf &) = delete;
+    Buf &operator=(const Buf &) = delete;
+    ~Buf() { std::free(p); }
+    void grow(size_t want) {
+        if (want <= cap) return;
+        const size_t nc = std::max<size_t>(std::max(want, cap * 2), 1024);
+        T *q = static_cast<T *>(std::realloc(p, nc * sizeof(T)));
+        if (!q) throw std::bad_alloc();
+        p = q;
+        cap = nc;
+    }
+    T &operator[](size_t i) { return p[i]; }
+    const T &operator[](size_t i) const { return p[i]; }
+    T *data() { return p; }
+    const T *data() const { return p; }
+};
+
 struct NbEntry { int8_t pslot; int8_t target; };   // pslot < 0: sibling `target`; else parent's neighbour slot + its child
 
 // node-sharing rules of _assign_indices.  For child i the entries are processed in order; an entry either looks the
@@ -185,11 +210,13 @@ const std::vector<NodeRule> NODE_RULES_3D[8] = {
 struct Topo {
     int dim, nch, nnb;
     double width;
-    std::vector<int32_t> level, parent, first_child;
-    std::vector<int32_t> nb;          // [n_cells][nnb]
-    std::vector<int64_t> node_idx;    // [n_cells][nch]
-    std::vector<double> center;       // [n_cells][dim]
-    std::vector<double> nodes;        // [n_nodes][dim]
+    Buf<int32_t> level, parent, first_child;
+    Buf<int32_t> nb;                  // [n_cells][nnb]
+    Buf<int64_t> node_idx;            // [n_cells][nch]
+    Buf<double> center;               // [n_cells][dim]
+    Buf<double> nodes;                // [n_nodes][dim]
+    int64_t n_nodes_used = 0;
+    size_t cell_cap = 0;              // cells the cell tables have room for
     std::vector<NbEntry> nb_table;    // [nch][nnb]
     // finalize() results
     std::vector<int64_t> face_ids;    // after finalize(): old node id -> new node id (-1 = dropped)
@@ -199,7 +226,7 @@ struct Topo {
     double half_width[64], quarter_width[64];   // (0.5 * width) / 2^level, (0.25 * width) / 2^level
 
     int64_t n_cells() const { return n_used; }
-    int64_t n_nodes() const { return (int64_t)(nodes.size() / dim); }
+    int64_t n_nodes() const { return n_nodes_used; }
     const int *dir(int c) const { return dim == 2 ? DIR2[c] : DIR3[c]; }
 
     // lattice rule behind the reference's hand-written neighbour table (verified against the reference's tables,
@@ -235,18 +262,23 @@ struct Topo {
         for (int j = 0; j < dim; ++j) center[i * dim + j] = c[j];
     }
 
-    // room for `extra` more cells: the tables grow geometrically and are indexed directly (no per-cell push_back)
+    // room for `extra` more cells (and as many new nodes at most: every new cell brings at most 2^d - 1 of them... the
+    // node table is grown again where a batch needs more): geometric growth, no initialisation
     void reserve_cells(int64_t extra) {
         const size_t want = (size_t)(n_cells() + extra);
-        nodes.reserve(std::max(nodes.capacity(), (size_t)(nodes.size() + (size_t)extra * dim)));
-        if (want <= level.size()) return;
-        const size_t cap = std::max<size_t>(std::max(want, level.size() * 2), 64);
-        level.resize(cap);
-        parent.resize(cap);
-        first_child.resize(cap);
-        nb.resize(cap * nnb);
-        node_idx.resize(cap * nch);
-        center.resize(cap * dim);
+        nodes.grow((size_t)(n_nodes_used + extra * nch) * dim);
+        if (want <= cell_cap) return;
+        const size_t cap = std::max<size_t>(std::max(want, cell_cap * 2), 1024);
+        level.grow(cap);
+        parent.grow(cap);
+        first_child.grow(cap);
+        nb.grow(cap * nnb);
+        node_idx.grow(cap * nch);
+        center.grow(cap * dim);
+        const size_t old = batch_pos.cap;
+        batch_pos.grow(cap);
+        for (size_t i = old; i < batch_pos.cap; ++i) batch_pos[i] = -1;
+        cell_cap = cap;
     }
 
     // _assign_neighbors(cell, children=existing children)
@@ -277,8 +309,9 @@ struct Topo {
 
     int64_t new_node(int32_t cell, int node) {
         const double off = half_width[level[cell]];
-        for (int j = 0; j < dim; ++j) nodes.push_back(center[(size_t)cell * dim + j] + dir(node)[j] * off);
-        return n_nodes() - 1;
+        nodes.grow((size_t)(n_nodes_used + 1) * dim);
+        for (int j = 0; j < dim; ++j) nodes[(size_t)n_nodes_used * dim + j] = center[(size_t)cell * dim + j] + dir(node)[j] * off;
+        return n_nodes_used++;
     }
 
     // _assign_indices(children of P)
@@ -313,11 +346,15 @@ struct Topo {
     // l-th new node of this parent / reference to an entry of an earlier parent's child), an exclusive scan of the
     // new-node counts gives every parent its id range, pass C turns "l-th new node" into ids and writes the
     // coordinates, pass D follows the references (a lattice point is shared by at most 2^d cells: short chains).
-    std::vector<int32_t> batch_pos;      // cell -> position in the current batch, -1 otherwise
+    Buf<int32_t> batch_pos;              // cell -> position in the current batch, -1 otherwise (sized with the cell tables)
     std::vector<int32_t> new_count;      // per parent of the batch: nodes it creates
     std::vector<int64_t> new_base;       // exclusive scan of new_count
     Pool *pool = nullptr;
     int n_threads = 1;
+    // seconds spent per phase (s3t_stats): 0 validate, 1 pass A, 2 scan + node table growth, 3 pass C, 4 pass D,
+    // 5 finish, 6 relink pass of uniform levels, 7 relink_parent_of, 8 mark_invalid, 9 table growth, 10 sequential batches
+    double phase_s[12] = {0};
+    static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
     int64_t par_min = 64;                // smaller batches take the sequential procedure (S3_TOPO_PAR_MIN)
 
     const std::vector<NodeRule> &rules_of(int child) const { return dim == 2 ? NODE_RULES_2D[child] : NODE_RULES_3D[child]; }
@@ -463,8 +500,9 @@ struct Topo {
     // returns the id of the first new cell, -1 if a parent is not a leaf (or listed twice)
     int64_t refine_batch_parallel(const int64_t *parents, int64_t n, int relink) {
         const int64_t first = n_cells(), nodes_before = n_nodes();
+        double t0 = now(), t1;
         reserve_cells(n * nch);
-        if (batch_pos.size() < level.size()) batch_pos.resize(level.size(), -1);
+        t1 = now(); phase_s[9] += t1 - t0; t0 = t1;
         int64_t bad = -1;
         for (int64_t i = 0; i < n; ++i) {
             const int64_t P = parents[i];
@@ -477,6 +515,7 @@ struct Topo {
         }
         new_count.assign((size_t)n, 0);
         new_base.assign((size_t)n, 0);
+        t1 = now(); phase_s[0] += t1 - t0; t0 = t1;
         const int64_t grain = 128;
         pool->run(n, grain, [&](int64_t b, int64_t e) {
             for (int64_t i = b; i < e; ++i) {
@@ -486,27 +525,34 @@ struct Topo {
                 build_children(i, parents, first);
             }
         });
+        t1 = now(); phase_s[1] += t1 - t0; t0 = t1;
         int64_t total = 0;
         for (int64_t i = 0; i < n; ++i) {
             new_base[i] = total;
             total += new_count[i];
         }
-        nodes.resize((size_t)(nodes_before + total) * dim);
+        nodes.grow((size_t)(nodes_before + total) * dim);
+        n_nodes_used = nodes_before + total;
+        t1 = now(); phase_s[2] += t1 - t0; t0 = t1;
         pool->run(n, 512, [&](int64_t b, int64_t e) {
             for (int64_t i = b; i < e; ++i) number_new_nodes(i, first, nodes_before);
         });
+        t1 = now(); phase_s[3] += t1 - t0; t0 = t1;
         pool->run(n, 512, [&](int64_t b, int64_t e) {
             for (int64_t i = b; i < e; ++i) resolve_refs(i, first);
         });
+        t1 = now(); phase_s[4] += t1 - t0; t0 = t1;
         for (int64_t i = 0; i < n; ++i) {
             first_child[parents[i]] = (int32_t)(first + i * nch);
             batch_pos[parents[i]] = -1;
         }
         n_used = first + n * nch;
+        t1 = now(); phase_s[5] += t1 - t0; t0 = t1;
         if (relink)
             pool->run(n, 256, [&](int64_t b, int64_t e) {
                 for (int64_t i = b; i < e; ++i) assign_neighbors((int32_t)parents[i]);
             });
+        phase_s[6] += now() - t0;
         return first;
     }
 
@@ -591,9 +637,10 @@ void *s3t_create(int dim, double width, const double *root_center) try {
     }
     // root nodes, s_cube.py:368,386-394: centre + dir * 0.5 * width, ids 0..2^d-1
     for (int c = 0; c < t->nch; ++c) {
-        for (int j = 0; j < dim; ++j) t->nodes.push_back(root_center[j] + t->dir(c)[j] * 0.5 * width);
+        for (int j = 0; j < dim; ++j) t->nodes[(size_t)c * dim + j] = root_center[j] + t->dir(c)[j] * 0.5 * width;
         t->node_idx[c] = c;
     }
+    t->n_nodes_used = t->nch;
     return t;
 } catch (...) {
     return nullptr;
@@ -616,8 +663,16 @@ double *s3t_nodes(void *h) { return static_cast<Topo *>(h)->nodes.data(); }
 // refine the listed parents in order (s_cube.py:879-895 / 531-544).  relink != 0 additionally re-runs the neighbour
 // assignment of every parent of the batch afterwards (the "update all nb" pass of the uniform loop, s_cube.py:547-549).
 // Returns the id of the first new cell, -1 if a parent is not a leaf, -2 if the tables could not grow.
+static int64_t refine_batch_sequential(Topo *t, const int64_t *parents, int64_t n, int relink);
 static int64_t refine_batch(Topo *t, const int64_t *parents, int64_t n, int relink) {
     if (t->pool && n >= t->par_min) return t->refine_batch_parallel(parents, n, relink);
+    const double t0 = Topo::now();
+    const int64_t r = refine_batch_sequential(t, parents, n, relink);
+    t->phase_s[10] += Topo::now() - t0;
+    return r;
+}
+
+static int64_t refine_batch_sequential(Topo *t, const int64_t *parents, int64_t n, int relink) {
     const int64_t first = t->n_cells();
     t->reserve_cells(n * t->nch);
     // the work per parent is a few dozen dependent look-ups in tables far larger than the caches; two software
@@ -709,7 +764,21 @@ void s3t_relink_parent_of(void *h, const int64_t *cells, int64_t n) {
 
 // s_cube.py:721-728: children = [], and the cell disappears from its neighbours' nb lists
 static void mark_invalid_cells(Topo *t, const int64_t *cells, int64_t n) {
+    // sequential on purpose (two removed cells that are neighbours: the first removes itself from the second's row, the
+    // second then no longer visits the first); the rows ahead are prefetched
     for (int64_t i = 0; i < n; ++i) {
+        if (i + 4 < n) {
+            __builtin_prefetch(&t->nb[(size_t)cells[i + 4] * t->nnb]);
+            __builtin_prefetch(&t->nb[(size_t)cells[i + 4] * t->nnb] + 16);
+        }
+        if (i + 2 < n) {
+            const int32_t *row = &t->nb[(size_t)cells[i + 2] * t->nnb];
+            for (int s_ = 0; s_ < t->nnb; ++s_)
+                if (row[s_] >= 0) {
+                    __builtin_prefetch(&t->nb[(size_t)row[s_] * t->nnb]);
+                    __builtin_prefetch(&t->nb[(size_t)row[s_] * t->nnb] + 16);
+                }
+        }
         const int32_t x = (int32_t)cells[i];
         t->first_child[x] = INVALID;
         for (int s = 0; s < t->nnb; ++s) {
@@ -743,6 +812,13 @@ int s3t_submit(void *h, int kind, const int64_t *ids, int64_t n, int relink) try
 
 int s3t_sync(void *h) { return static_cast<Topo *>(h)->wait_idle(); }
 
+// seconds per phase of the engine so far (development aid; see Topo::phase_s), out[12]
+void s3t_stats(void *h, double *out) {
+    Topo *t = static_cast<Topo *>(h);
+    t->wait_idle();
+    for (int i = 0; i < 12; ++i) out[i] = t->phase_s[i];
+}
+
 }  // extern "C"
 
 void Topo::worker_loop() {
@@ -763,9 +839,13 @@ void Topo::worker_loop() {
                     const int64_t first = refine_batch(this, c.ids.data(), (int64_t)c.ids.size(), c.relink);
                     if (first < 0) rc = (int)first;
                 } else if (c.kind == 1) {
+                    const double t0 = now();
                     relink_parents(this, c.ids.data(), (int64_t)c.ids.size());
+                    phase_s[7] += now() - t0;
                 } else {
+                    const double t0 = now();
                     mark_invalid_cells(this, c.ids.data(), (int64_t)c.ids.size());
+                    phase_s[8] += now() - t0;
                 }
             } catch (...) {
                 rc = -2;

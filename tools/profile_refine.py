@@ -1,7 +1,8 @@
 """dev helper: host-side profile of SamplingTree.refine() on the bench workload (not part of the product)"""
 import cProfile, pstats, sys, time, logging
 import numpy as np, torch as pt
-sys.path.insert(0, ".")  # run from the repo root
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from sparsespatialsampling_amd import geometry
 from sparsespatialsampling_amd.s_cube import SamplingTree

@@ -1,0 +1,56 @@
+"""dev helper: wall-clock per hipops / IntSet / topology call inside one SamplingTree.refine() of a bench workload (no
+profiler: plain perf_counter wrappers), to see where the host blocks"""
+import os, sys, time, logging, collections
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch as pt
+import bench
+from sparsespatialsampling_amd import geometry, hipops, s_cube, tree_backend, intset
+logging.getLogger().setLevel(logging.WARNING)
+acc = collections.defaultdict(lambda: [0, 0.0])
+
+
+def wrap(obj, name, label):
+    fn = getattr(obj, name)
+
+    def timed(*a, **k):
+        t0 = time.perf_counter()
+        try:
+            return fn(*a, **k)
+        finally:
+            e = acc[label]
+            e[0] += 1
+            e[1] += time.perf_counter() - t0
+    setattr(obj, name, timed)
+
+
+for n in ("make_children", "child_gain", "mask_box", "mask_cylinder", "commit_batch", "sumsq_leaf", "topn_leaf", "topn_scratch", "to_device"):
+    wrap(hipops, n, "hipops." + n)
+for n in ("update", "update_flagged", "__isub__", "to_array"):
+    wrap(intset.IntSet, n, "IntSet." + n)
+for n in ("submit_refine", "submit_relink_parent_of", "submit_mark_invalid", "sync", "finalize", "gather_cells"):
+    wrap(s_cube._Topology, n, "topo." + n)
+for n in ("mask", "refine_batch", "topn", "sumsq", "commit"):
+    wrap(tree_backend.HipTreeBackend, n, "backend." + n)
+for n in ("_remove_invalid_cells", "_refine_cells", "_compute_captured_metric", "_refine_uniform", "_refine_geometries", "_resort_nodes_and_indices_of_grid"):
+    wrap(s_cube.SamplingTree, n, "tree." + n)
+
+cfg = dict(bench.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "cylinder3D_Re3900"])
+x, metric = bench.synthetic_cylinder3d(cfg)
+geos = [geometry.CubeGeometry("domain", True, cfg["lo"], [float(v) for v in cfg["hi"]]),
+        geometry.CylinderGeometry3D("cylinder", False, [(0.8, 1.0, -1.0), (0.8, 1.0, 1.0)], 0.05, refine=True)]
+for rep in range(2):
+    acc.clear()
+    tree = s_cube.SamplingTree(pt.from_numpy(x), pt.from_numpy(metric), geos, uniform_level=cfg["uniform_levels"], min_metric=cfg["min_metric"])
+    pt.cuda.synchronize()
+    t0 = time.perf_counter()
+    tree.refine()
+    pt.cuda.synchronize()
+    print(f"rep {rep}: refine {time.perf_counter() - t0:.4f} s", {k: round(v, 4) for k, v in tree.data_final_mesh.items() if k.startswith("t_")})
+    import ctypes as C
+    st = np.zeros(12)
+    tree._topo_engine._lib.s3t_stats(tree._topo_engine._h, st.ctypes.data_as(C.c_void_p))
+    names = ["validate", "passA", "scan", "passC", "passD", "finish", "relink pass", "relink_parent_of", "mark_invalid", "growth", "sequential batches"]
+    print("  engine phases [ms]:", {n: round(v * 1e3, 2) for n, v in zip(names, st)}, "sum", round(st.sum() * 1e3, 1))
+    tree.close()
+for k, (n, t) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
+    print(f"{k:42s} {n:5d} calls {t * 1e3:9.2f} ms")

@@ -37,7 +37,19 @@ WORKLOADS = {
                               uniform_levels=5, min_metric=0.75, seed=2),
     "cylinder3D_small": dict(n=300_000, lo=[0.0, 0.0, 0.0], hi=[2.4, 2.0, 0.1 * np.pi], t_batch=256,
                              uniform_levels=4, min_metric=0.6, seed=2),
+    # HBM stress -- random centroids in the unit box, cell budget, batches of 16 snapshots (64-byte rows)
+    "box5e7": dict(kind="box", n=50_000_000, t_batch=16, uniform_levels=5, n_cells_max=10_000_000, seed=3),
+    "box5e7_small": dict(kind="box", n=5_000_000, t_batch=16, uniform_levels=4, n_cells_max=1_000_000, seed=3),
 }
+
+
+def synthetic_box(cfg):
+    """uniform random centroids in the unit box, smooth metric peaking at the centre with short waves on top (C4)"""
+    rng = np.random.default_rng(cfg["seed"])
+    x = rng.random((cfg["n"], 3))
+    r = np.sqrt(((x - 0.5) ** 2).sum(1))
+    metric = 0.05 + np.exp(-6 * r) * (1 + 0.5 * np.sin(25 * x[:, 0]) * np.cos(17 * x[:, 1]))
+    return x, metric
 
 
 def synthetic_cylinder3d(cfg):

@@ -254,6 +254,47 @@ def gen_c1():
          iterations=np.array(tree.data_final_mesh["iterations"]))
 
 
+def gen_c2():
+    """full-size C2 run of the reference (OAT15-like: 3*10^5 clustered points, refined NACA outline, n_cells_max): metric =
+    std_t(p) + std_t(|U|) over 2000 synthetic snapshots, computed the way the reference's scripts do (torch on the CPU,
+    examples/s3_for_OAT15_airfoil.py:91), then rounded to float16 and stored; grid as checksums + histories.  The polygon
+    predicate the reference gets here is ref_stubs._Polygon (shapely is absent): GEOS semantics are NOT pinned by this."""
+    import sparseSpatialSampling.geometry as ref_geometry
+    from sparseSpatialSampling.s_cube import SamplingTree
+    from inputs import c2_cloud, c2_fields, c2_oat15
+    x, _ = c2_cloud()
+    n_snap, step = 2000, 100
+    # streaming mean / M2 over snapshot blocks in float64 = torch.std(field, dim=-1) up to rounding
+    cnt, mean_p, m2_p, mean_u, m2_u = 0, 0.0, 0.0, 0.0, 0.0
+    for t0 in range(0, n_snap, step):
+        p, u = c2_fields(x, t0, t0 + step)
+        p = pt.from_numpy(p)[:, 0, :].double()
+        un = pt.from_numpy(u).double().norm(dim=1)
+        for name, blk in (("p", p), ("u", un)):
+            b_mean, b_m2, b_n = blk.mean(-1), ((blk - blk.mean(-1, keepdim=True)) ** 2).sum(-1), blk.shape[-1]
+            mean, m2 = (mean_p, m2_p) if name == "p" else (mean_u, m2_u)
+            delta = b_mean - mean
+            tot = cnt + b_n
+            m2 = m2 + b_m2 + delta ** 2 * cnt * b_n / tot
+            mean = mean + delta * b_n / tot
+            if name == "p":
+                mean_p, m2_p = mean, m2
+            else:
+                mean_u, m2_u = mean, m2
+        cnt += step
+    metric = (pt.sqrt(m2_p / (cnt - 1)) + pt.sqrt(m2_u / (cnt - 1))).numpy().astype(np.float16)
+    x, m, geos, kw = c2_oat15(ref_geometry, metric)
+    tree = SamplingTree(pt.from_numpy(x), pt.from_numpy(m), geometry_obj=geos, n_jobs=8, **kw)
+    tree.refine()
+    c, lv, f, nd = tree.all_centers.numpy(), tree.all_levels.numpy(), tree.face_ids.numpy(), tree.all_nodes.numpy()
+    save("c2_oat15", metric_f16=metric, input_sha=np.array(sha(x, m)), n_leaf=np.array(len(c)),
+         sha_centers=np.array(sha(c)), sha_levels=np.array(sha(lv.astype(np.int64))), sha_faces=np.array(sha(f.astype(np.int32))),
+         sha_nodes=np.array(sha(nd)), head_centers=c[:64], head_faces=f[:64], level_hist=np.bincount(lv.reshape(-1)),
+         metric_hist=np.array(tree._metric), n_cells_log=np.array(tree._n_cells_log),
+         iterations=np.array(tree.data_final_mesh["iterations"]))
+    print("C2:", len(x), "points ->", len(c), "cells, levels", np.bincount(lv.reshape(-1)))
+
+
 if __name__ == "__main__":
     groups = sys.argv[1:] or ["interp", "knncache", "predict", "masks", "masks_polytopes", "uniform", "refine", "refine_random", "c1"]
     pt.manual_seed(0)

@@ -275,3 +275,46 @@ def random_refine_case(seed):
     if rng.random() < 0.2:
         kw["pre_select"] = True
     return x, y, random_bodies(rng, d), kw, d
+
+
+# ---- BASELINE config C2 (OAT15-like) at full size ---------------------------------------------------------------------
+def naca_outline(n=200, thickness=0.12):
+    """closed NACA-00xx outline with ``n`` distinct vertices, chord [0, 1] (upper side leading -> trailing edge, then back)"""
+    xs = 0.5 * (1 - np.cos(np.linspace(0, np.pi, n // 2 + 1)))
+    yt = 5 * thickness * (0.2969 * np.sqrt(xs) - 0.126 * xs - 0.3516 * xs ** 2 + 0.2843 * xs ** 3 - 0.1036 * xs ** 4)
+    upper = np.stack([xs, yt], 1)
+    lower = np.stack([xs[::-1], -yt[::-1]], 1)[1:-1]
+    return np.ascontiguousarray(np.concatenate([upper, lower]))
+
+
+def c2_cloud():
+    """3*10^5 points in [-0.2, 1.2] x [-0.5, 0.5]: half uniform, half clustered around the airfoil outline (seed 1)"""
+    rng = np.random.default_rng(1)
+    poly = naca_outline()
+    far = rng.random((150000, 2)) * [1.4, 1.0] + [-0.2, -0.5]
+    near = poly[rng.integers(0, len(poly), 150000)] + 0.02 * rng.standard_normal((150000, 2))
+    x = np.concatenate([far, near])
+    keep = (x[:, 0] >= -0.2) & (x[:, 0] <= 1.2) & (x[:, 1] >= -0.5) & (x[:, 1] <= 0.5)
+    return np.ascontiguousarray(x[keep]), poly
+
+
+def c2_fields(x, t0, t1):
+    """snapshots t0..t1-1 of a buffet-like synthetic flow: p [N, 1, T], U [N, 2, T] float32 (a shock region oscillating on
+    the suction side + a wake shedding behind the trailing edge)"""
+    t = np.arange(t0, t1, dtype=np.float64)[None, :]
+    xx, yy = x[:, :1], x[:, 1:2]
+    shock = np.exp(-((xx - 0.45 - 0.08 * np.sin(2 * np.pi * t / 80.0)) / 0.05) ** 2) * np.exp(-((yy - 0.12) / 0.18) ** 2)
+    wake = np.where(xx > 1.0, np.exp(-(xx - 1.0) / 0.5), 0.0) * np.exp(-(yy / 0.06) ** 2) * np.sin(2 * np.pi * (t / 25.0 - 3 * xx))
+    p = 1.0 + 0.4 * shock + 0.15 * wake
+    u = 1.0 - 0.5 * shock + 0.2 * wake
+    v = 0.3 * wake * np.cos(2 * np.pi * t / 25.0) + 0.1 * shock
+    return p.astype(np.float32)[:, None, :], np.stack([u, v], 1).astype(np.float32)
+
+
+def c2_oat15(geometry, metric):
+    """(x, metric, geometries, SamplingTree kwargs) of the full-size C2 run; ``metric`` comes from the fixture (computed
+    once by gen_golden.py with torch on the CPU, rounded to float16 so that 3*10^5 values stay a small file)"""
+    x, poly = c2_cloud()
+    geos = [geometry.CubeGeometry("domain", True, [-0.2, -0.5], [1.2, 0.5]),
+            geometry.GeometryCoordinates2D("airfoil", False, poly, refine=True)]
+    return x, np.asarray(metric, dtype=np.float64), geos, dict(uniform_level=5, n_cells=25000)

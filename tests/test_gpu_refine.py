@@ -226,6 +226,128 @@ def test_c1_cylinder2d_full_size_matches_reference():
     assert tree.data_final_mesh["iterations"] == int(z["iterations"])
 
 
+def test_c2_oat15_full_size_matches_reference():
+    """BASELINE config C2 at full size (3*10^5 clustered points, refined NACA outline as GeometryCoordinates2D,
+    ``n_cells_max`` stopping; metric = std_t(p) + std_t(|U|) over 2000 snapshots as the reference's OAT15 script computes it):
+    grid of the real reference (tests/golden/gen_golden.py c2; 28 232 cells) as checksums, bit-exact.  The outline predicate
+    on the reference side is the generator's shapely stand-in (ref_stubs._Polygon), so GEOS semantics are not what this
+    pins -- the adversarial predicate cases are in tests/test_polygon_predicate.py.  Then the interpolation at the
+    config's size: 2000 snapshots of a scalar and of a 2-component field through the tiled kernel."""
+    import sparsespatialsampling_amd.s_cube as s_cube
+    from sparsespatialsampling_amd import geometry, hipops, metrics
+    from inputs import c2_fields, c2_oat15
+    from oracle import s3_oracle as orc
+    z = load("c2_oat15")
+    x, m, geos, kw = c2_oat15(geometry, z["metric_f16"])
+    assert sha(x, m) == str(z["input_sha"])
+    tree = s_cube.SamplingTree(pt.from_numpy(x), pt.from_numpy(m), geometry_obj=geos, **kw)
+    tree.refine()
+    centers, levels = tree.all_centers.numpy(), tree.all_levels.numpy()
+    assert len(centers) == int(z["n_leaf"]) == 28232
+    assert np.array_equal(centers[:64], z["head_centers"]) and np.array_equal(tree.face_ids.numpy()[:64], z["head_faces"])
+    assert np.array_equal(np.bincount(levels.reshape(-1)), z["level_hist"])
+    assert sha(centers) == str(z["sha_centers"]) and sha(levels.astype(np.int64)) == str(z["sha_levels"])
+    assert sha(tree.face_ids.numpy().astype(np.int32)) == str(z["sha_faces"]) and sha(tree.all_nodes.numpy()) == str(z["sha_nodes"])
+    assert np.array_equal(np.array(tree._n_cells_log), z["n_cells_log"])
+    np.testing.assert_allclose(np.array(tree._metric), z["metric_hist"], rtol=1e-12)
+    assert tree.data_final_mesh["iterations"] == int(z["iterations"])
+    tree.close()
+
+    # the metric upstream (metrics.temporal_std on the device) on the same synthetic fields, 200 of the 2000 snapshots:
+    # float64 torch on the host is the reference's own computation
+    p, u = c2_fields(x[:20000], 0, 200)
+    got = metrics.temporal_std(pt.from_numpy(p).cuda()).reshape(-1) + metrics.temporal_std(pt.from_numpy(u).cuda().norm(dim=1, keepdim=True)).reshape(-1)
+    want = pt.from_numpy(p)[:, 0].double().std(-1) + pt.from_numpy(u).double().norm(dim=1).std(-1)
+    assert pt.allclose(got.cpu(), want, rtol=1e-5, atol=1e-7)       # |U| is formed in float32 on the device
+
+    # interpolation at the config's size (k = 8): scalar p [N, 1, 2000] and vector U [N, 2, 2000]
+    k, n, nc = 8, len(x), len(centers)
+    knn = hipops.KnnIndex(x, hipops.knn_occupancy(k, 2))
+    idx, dist = knn.query(centers, k)
+    knn.close()
+    w = hipops.idw_weights(dist)
+    plan = hipops.InterpPlan(idx, n, centers)
+    sel = np.random.default_rng(0).choice(nc, 300, replace=False)
+    for ncomp in (1, 2):
+        row_len = ncomp * 2000
+        data = hipops.padded_rows(n, row_len, pt.float32, "cuda")
+        data.normal_()
+        out = plan.interp(w, data)
+        assert pt.equal(out, hipops.interp(w, idx, data.contiguous()))
+        const = hipops.padded_rows(n, row_len, pt.float32, "cuda")
+        const.fill_(0.75)
+        assert pt.allclose(plan.interp(w, const), pt.full((nc, row_len), 0.75, dtype=pt.float64, device="cuda"), rtol=1e-13, atol=0)
+        # oracle on a slice of the cells (the rows they reference only)
+        i_s, w_s = idx[sel].cpu().numpy(), w[sel].cpu().numpy()
+        rows, inv = np.unique(i_s, return_inverse=True)
+        sub = data[pt.from_numpy(rows).cuda().long()].cpu().numpy().reshape(len(rows), ncomp, 2000)
+        ref = orc.interp(w_s, inv.reshape(i_s.shape), sub).reshape(len(sel), row_len)
+        assert np.abs(out[sel].cpu().numpy() - ref).max() <= 1e-13 * np.abs(ref).max()
+
+
+def test_c4_box5e7_full_size_properties():
+    """BASELINE config C4 at full size on one GPU (5*10^7 random centroids in the unit box, ``n_cells_max`` = 10^7, three
+    scalar fields in batches of 16 snapshots): grid properties, stopping rule, planned == direct, constant reproduction,
+    linearity, and the oracle on a slice of the cells -- for 64-byte rows (one scalar field), for the three fields packed
+    as one 3-component batch (192-byte rows) and for a ragged 25-snapshot batch."""
+    import bench
+    import sparsespatialsampling_amd.s_cube as s_cube
+    from sparsespatialsampling_amd import geometry, hipops
+    from oracle import s3_oracle as orc
+    cfg = dict(bench.WORKLOADS["box5e7"])
+    x, metric = bench.synthetic_box(cfg)
+    geos = [geometry.CubeGeometry("domain", True, [0.0, 0.0, 0.0], [1.0, 1.0, 1.0])]
+    tree = s_cube.SamplingTree(pt.from_numpy(x), pt.from_numpy(metric), geos, uniform_level=cfg["uniform_levels"],
+                               n_cells=cfg["n_cells_max"])
+    del metric
+    tree.refine()
+    centers, nodes = tree.all_centers.numpy(), tree.all_nodes.numpy()
+    faces, levels = tree.face_ids.numpy(), tree.all_levels.numpy().reshape(-1)
+    nc = len(centers)
+    assert nc == 10_062_144 and faces.shape == (nc, 8) and tree.face_ids.dtype == pt.int32
+    assert tree._n_cells_log[-1] >= cfg["n_cells_max"] > tree._n_cells_log[-2]              # stopped by the cell budget
+    tree.close()
+    blk = slice(0, nc, 7)                                                                 # every 7th leaf: 1.4*10^6 cells
+    corner = nodes[faces[blk].astype(np.int64)]
+    assert np.abs(corner.mean(1) - centers[blk]).max() <= 4e-16
+    assert np.allclose(corner.max(1) - corner.min(1), (1.0 / 2.0 ** levels[blk])[:, None], rtol=1e-12, atol=0)
+    key = np.round(centers * 2.0 ** 12).astype(np.int64)                                  # centres are dyadic: exact keys
+    key = (key[:, 0] << 28) | (key[:, 1] << 14) | key[:, 2]
+    assert len(np.unique(key)) == nc
+    assert centers.min() > 0 and centers.max() < 1 and levels.min() >= cfg["uniform_levels"]
+    del corner, key, nodes, faces
+
+    k, n = 26, len(x)
+    knn = hipops.KnnIndex(x, hipops.knn_occupancy(k, 3))
+    idx, dist = knn.query(centers, k)
+    knn.close()
+    w = hipops.idw_weights(dist)
+    del dist
+    assert pt.allclose(w.sum(1), pt.ones(nc, dtype=pt.float64, device="cuda"), rtol=1e-14, atol=0)
+    plan = hipops.InterpPlan(idx, n, centers)
+    sel = np.random.default_rng(1).choice(nc, 10_000, replace=False)
+    i_s, w_s = idx[sel].cpu().numpy(), w[sel].cpu().numpy()
+    rows, inv = np.unique(i_s, return_inverse=True)
+    rows_dev = pt.from_numpy(rows).cuda().long()
+    for ncomp, t in ((1, 16), (3, 16), (1, 25)):
+        row_len = ncomp * t
+        a, b = hipops.padded_rows(n, row_len, pt.float32, "cuda"), hipops.padded_rows(n, row_len, pt.float32, "cuda")
+        a.normal_(), b.normal_()
+        fa = plan.interp(w, a)
+        assert pt.equal(fa, hipops.interp(w, idx, a.contiguous()))                        # planned == direct, bit for bit
+        fb = plan.interp(w, b)
+        both = hipops.padded_rows(n, row_len, pt.float64, "cuda")
+        both.copy_(a.double() + 2 * b.double())
+        assert pt.allclose(plan.interp(w, both), fa + 2 * fb, rtol=1e-12, atol=1e-12)
+        del both, fb
+        b.fill_(3.25)
+        assert pt.allclose(plan.interp(w, b), pt.full((nc, row_len), 3.25, dtype=pt.float64, device="cuda"), rtol=1e-13, atol=0)
+        sub = a[rows_dev].cpu().numpy().reshape(len(rows), ncomp, t)
+        ref = orc.interp(w_s, inv.reshape(i_s.shape), sub).reshape(len(sel), row_len)
+        assert np.abs(fa[sel].cpu().numpy() - ref).max() <= 1e-13 * np.abs(ref).max()
+        del a, b, fa
+
+
 def test_full_size_c3_properties():
     """BASELINE's bench configuration at full size (4 991 774 points -> 461 130 cells, k = 26), checked through
     size-independent properties: grid geometry (centres = mean of the cell's vertices, edge length = width / 2^level,

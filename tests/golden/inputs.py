@@ -278,7 +278,7 @@ def random_refine_case(seed):
 
 
 # ---- BASELINE config C2 (OAT15-like) at full size ---------------------------------------------------------------------
-def naca_outline(n=200, thickness=0.12):
+def naca_outline_c2(n=200, thickness=0.12):
     """closed NACA-00xx outline with ``n`` distinct vertices, chord [0, 1] (upper side leading -> trailing edge, then back)"""
     xs = 0.5 * (1 - np.cos(np.linspace(0, np.pi, n // 2 + 1)))
     yt = 5 * thickness * (0.2969 * np.sqrt(xs) - 0.126 * xs - 0.3516 * xs ** 2 + 0.2843 * xs ** 3 - 0.1036 * xs ** 4)
@@ -290,7 +290,7 @@ def naca_outline(n=200, thickness=0.12):
 def c2_cloud():
     """3*10^5 points in [-0.2, 1.2] x [-0.5, 0.5]: half uniform, half clustered around the airfoil outline (seed 1)"""
     rng = np.random.default_rng(1)
-    poly = naca_outline()
+    poly = naca_outline_c2()
     far = rng.random((150000, 2)) * [1.4, 1.0] + [-0.2, -0.5]
     near = poly[rng.integers(0, len(poly), 150000)] + 0.02 * rng.standard_normal((150000, 2))
     x = np.concatenate([far, near])

@@ -3,36 +3,42 @@
 bench.py -- S^3 hot path on MI355X: snapshot interpolation throughput (+ refine wall-clock) on the synthetic
 cylinder3D_Re3900 workload of BASELINE.json / SURVEY.md 8(d).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
 
-A *step* is one pass of the interpolation hot path (`export.interpolate_data` -> s3_interp) over one batch of synthetic
-snapshots: data [N_points, 1, T_batch] fp32 already resident in HBM -> out [N_cells, 1, T_batch] f64 in HBM, with the
-KNN indices/weights of the generated grid resident as well.  The grid itself comes from `SamplingTree.refine()` run on
-the GPU before the timed region; its wall-clock is reported as `refine_wall_s` in the same JSON line.
+A *step* is one pass of the interpolation hot path (ExportData's cached neighbour table -> s3_interp_planned) over one
+batch of synthetic snapshots already resident in HBM: data [N_rows, T_batch] fp32 -> out [N_cells, T_batch] f64 in HBM.
+The grid comes from `SamplingTree.refine()` run on the GPU(s) before the timed region; its wall-clock is reported as
+`refine_wall_s` in the same JSON line.
 
-Multi-GPU (one process per GPU, launched by torch.distributed.run): the path shards over the snapshot axis -- every
-rank holds the (replicated) grid + KNN cache and interpolates its own snapshot batches, no data-path collective
-("scaling": "weak").  refine() runs replicated on every rank with the captured-metric reduction split across ranks
-(one 8-byte RCCL all-reduce per refine iteration).
+Multi-GPU (one process per GPU, launched by torch.distributed.run; the collectives run inside libs3hip.so on RCCL):
+* refine: every rank evaluates the KNN metric / gain of its 1/N slice of each batch of new cells, one grouped all-gather
+  per batch, block-wise captured-metric sums gathered per iteration (bit-identical for any N);
+* interpolation (default `--shard cells`): the generated leaf cells are split into N contiguous ranges, every rank holds
+  the KNN cache / plan of its range and only the source rows that range references, and interpolates the same snapshot
+  batch -- no data-path collective; total work is fixed ("scaling": "strong").  `--shard snapshots` gives every rank
+  all cells and its own snapshot batches instead ("weak").
 
-Prints ONE JSON line (rank 0).
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP events on the launch stream) and, at N = 1,
+`cpu_baseline` (the CPU oracle on a slice of this very workload), `refine_cpu_baseline` and `end_to_end` (host tensors
+in -> host tensors out through ExportData, PCIe included; never `value`).
 """
 import argparse
+import glob
 import json
 import os
 import sys
 import time
+import types
 
 import numpy as np
 import torch as pt
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 WORKLOADS = {
-    # name: (n_points, T_batch, uniform_levels, min_metric)
+    # SURVEY 8(d) C3: the configuration BASELINE.json's metric is quoted on
     "cylinder3D_Re3900": dict(n=5_000_000, lo=[0.0, 0.0, 0.0], hi=[2.4, 2.0, 0.1 * np.pi], t_batch=1000,
                               uniform_levels=5, min_metric=0.75, seed=2),
     "cylinder3D_small": dict(n=300_000, lo=[0.0, 0.0, 0.0], hi=[2.4, 2.0, 0.1 * np.pi], t_batch=256,
@@ -41,15 +47,6 @@ WORKLOADS = {
     "box5e7": dict(kind="box", n=50_000_000, t_batch=16, uniform_levels=5, n_cells_max=10_000_000, seed=3),
     "box5e7_small": dict(kind="box", n=5_000_000, t_batch=16, uniform_levels=4, n_cells_max=1_000_000, seed=3),
 }
-
-
-def synthetic_box(cfg):
-    """uniform random centroids in the unit box, smooth metric peaking at the centre with short waves on top (C4)"""
-    rng = np.random.default_rng(cfg["seed"])
-    x = rng.random((cfg["n"], 3))
-    r = np.sqrt(((x - 0.5) ** 2).sum(1))
-    metric = 0.05 + np.exp(-6 * r) * (1 + 0.5 * np.sin(25 * x[:, 0]) * np.cos(17 * x[:, 1]))
-    return x, metric
 
 
 def synthetic_cylinder3d(cfg):
@@ -66,38 +63,119 @@ def synthetic_cylinder3d(cfg):
     return x, metric
 
 
-def cpu_baseline(x_host, centers, k, t_sample, seconds=12.0):
-    """the CPU oracle (C + OpenMP restatement of export.py:446-468) on a bounded sample of the same workload"""
+def synthetic_box(cfg):
+    """uniform random centroids in the unit box, smooth metric peaking at the centre with short waves on top (C4)"""
+    rng = np.random.default_rng(cfg["seed"])
+    x = rng.random((cfg["n"], 3))
+    r = np.sqrt(((x - 0.5) ** 2).sum(1))
+    metric = 0.05 + np.exp(-6 * r) * (1 + 0.5 * np.sin(25 * x[:, 0]) * np.cos(17 * x[:, 1]))
+    return x, metric
+
+
+def build_case(name, cfg, geometry):
+    """(points, metric, geometry objects, SamplingTree keyword arguments) of a workload"""
+    if cfg.get("kind") == "box":
+        x, metric = synthetic_box(cfg)
+        geos = [geometry.CubeGeometry("domain", True, [0.0, 0.0, 0.0], [1.0, 1.0, 1.0])]
+        return x, metric, geos, dict(uniform_level=cfg["uniform_levels"], n_cells=cfg["n_cells_max"])
+    x, metric = synthetic_cylinder3d(cfg)
+    geos = [geometry.CubeGeometry("domain", True, cfg["lo"], [float(v) for v in cfg["hi"]]),
+            geometry.CylinderGeometry3D("cylinder", False, [(0.8, 1.0, -1.0), (0.8, 1.0, 1.0)], 0.05, refine=True)]
+    return x, metric, geos, dict(uniform_level=cfg["uniform_levels"], min_metric=cfg["min_metric"])
+
+
+# ---- CPU baselines (rank 0, N = 1 only; the oracle is the checker of the tests, used here as the timed CPU port) --------
+def cpu_baseline(w, idx, data, k, seconds=12.0, n_cells=10_000, t_max=64):
+    """the CPU oracle (C + OpenMP restatement of export.py:446-468) on a slice of THIS workload: the first `n_cells` cells of
+    the bench's own neighbour table and the source rows they reference, the first `t_max` snapshots of the bench's batch"""
     from oracle import s3_oracle as orc
-    nc = min(len(centers), 10_000)
-    n_src = min(len(x_host), 200_000)          # brute-force KNN in the oracle: keep the index build of the sample cheap
-    idx, dist = orc.knn(x_host[:n_src], centers[:nc], k)
-    w = orc.idw_weights(dist)
-    data = np.random.default_rng(0).standard_normal((n_src, 1, t_sample)).astype(np.float32)
-    orc.interp(w, idx, data)                   # warm
+    nc = min(int(w.shape[0]), n_cells)
+    i_s, w_s = idx[:nc].cpu().numpy(), w[:nc].cpu().numpy()
+    rows, inv = np.unique(i_s, return_inverse=True)
+    t = min(int(data.shape[1]), t_max)
+    sub = data[pt.from_numpy(rows).to(data.device).long()][:, :t].contiguous().cpu().numpy().reshape(len(rows), 1, t)
+    inv = inv.reshape(i_s.shape)
+    orc.interp(w_s, inv, sub)                  # warm
     reps, t0 = 0, time.perf_counter()
     while time.perf_counter() - t0 < seconds:
-        orc.interp(w, idx, data)
+        orc.interp(w_s, inv, sub)
         reps += 1
     dt = time.perf_counter() - t0
-    return dict(value=nc * t_sample * reps / dt / 1e6, unit="Mcells*snapshots/s", cores=orc.num_threads(), kind="port",
-                sample=f"oracle/s3_oracle.c s3o_interp (OpenMP), {nc} cells x {t_sample} snapshots x {reps} passes, "
-                       f"k={k}, fp32 in / f64 out, {n_src} source points")
+    return dict(value=nc * t * reps / dt / 1e6, unit="Mcells*snapshots/s", cores=orc.num_threads(), kind="port",
+                sample=f"oracle/s3_oracle.c s3o_interp (OpenMP) on the bench's own table: first {nc} cells, the {len(rows)} "
+                       f"source rows they reference, first {t} snapshots, {reps} passes, k={k}, fp32 in / f64 out")
 
 
-def recorded_traffic(workload):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/rNN/summary.json:
-    FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE, separate rocprofv3 --pmc runs of this very
-    command); None when no pass was recorded for this workload string"""
-    import glob
+def refine_cpu_baseline():
+    """`SamplingTree.refine()` with the CPU oracle kernels (tests/oracle_backend.py: brute-force KNN in C + OpenMP) and the
+    same host logic on the cylinder3D_small workload (299 502 points): the CPU port's grid-generation wall-clock"""
+    import sparsespatialsampling_amd.s_cube as s_cube
+    from sparsespatialsampling_amd import geometry
+    from oracle import s3_oracle as orc
+    from tests.oracle_backend import OracleTreeBackend
+    cfg = dict(WORKLOADS["cylinder3D_small"])
+    x, metric, geos, kw = build_case("cylinder3D_small", cfg, geometry)
+    product = s_cube._make_backend
+    s_cube._make_backend = lambda v, t, k: OracleTreeBackend(v, t, k)
+    try:
+        t0 = time.perf_counter()
+        tree = s_cube.SamplingTree(pt.from_numpy(x), pt.from_numpy(metric), geos, **kw)
+        tree.refine()
+        cpu_s = time.perf_counter() - t0
+        n_leaf = len(tree.all_centers)
+        tree.close()
+    finally:
+        s_cube._make_backend = product
+    pt.cuda.synchronize()
+    t0 = time.perf_counter()
+    tree = s_cube.SamplingTree(pt.from_numpy(x), pt.from_numpy(metric), geos, **kw)
+    tree.refine()
+    pt.cuda.synchronize()
+    gpu_s = time.perf_counter() - t0
+    same = len(tree.all_centers) == n_leaf
+    tree.close()
+    return dict(workload=f"cylinder3D_small: {len(x)} points -> {n_leaf} leaf cells", cpu_wall_s=cpu_s, cores=orc.num_threads(),
+                kind="port", gpu_wall_s=gpu_s, speedup=cpu_s / gpu_s, same_grid_size=bool(same))
+
+
+def end_to_end(x, centers, k, batches=(25, 200)):
+    """host tensors in -> host tensors out through ExportData._fit_data (KNN cache built once, then one batch per size;
+    upload of the referenced rows, kernel, transpose, download): PCIe-inclusive rate, never `value`"""
+    from sparsespatialsampling_amd.export import ExportData
+    s = types.SimpleNamespace(n_dimensions=3, faces=None, centers=pt.from_numpy(centers), vertices=None, levels=None,
+                              metric=pt.zeros(len(x), dtype=pt.float64), size_initial_cell=1.0, save_path=".", save_name="bench",
+                              grid_name="g")
+    ex = ExportData(s, write_times=[str(i) for i in range(100000)], n_neighbors=k)
+    coords = pt.from_numpy(x)
+    out = {}
+    for t in batches:
+        data = pt.empty((len(x), 1, t), dtype=pt.float32).normal_()
+        ex._fit_data(coords, data, "f", 10 ** 9)             # first call builds the cache; warm the transport for this size
+        t0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            ex._fit_data(coords, data, "f", 10 ** 9)
+        pt.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        out[f"T{t}"] = dict(ms_per_batch=dt * 1e3, Gcells_snapshots_per_s=len(centers) * t / dt / 1e9)
+        del data
+    out["note"] = ("freshly allocated pageable host tensor [N,1,T] fp32 in, host f64 tensor out; only the source rows the grid "
+                   "references are uploaded")
+    return out
+
+
+def recorded_traffic(workload_key):
+    """HBM bytes per launch of the dominant kernel as RECORDED in the committed PMC passes (profiles/rNN/summary.json:
+    FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE from separate rocprofv3 --pmc runs of this
+    command); (None, None) when no pass was recorded for this workload"""
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "summary.json")), reverse=True):
         try:
             rec = json.load(open(f))
         except (OSError, ValueError):
             continue
-        if rec.get("workload") == workload and "traffic_bytes_per_launch" in rec:
-            return rec["traffic_bytes_per_launch"]
-    return None
+        if rec.get("workload_key") == workload_key and "traffic_bytes_per_launch" in rec:
+            return rec["traffic_bytes_per_launch"], os.path.relpath(f, ROOT)
+    return None, None
 
 
 def copy_bandwidth_gbs(n_bytes=2 << 30, reps=5):
@@ -123,13 +201,20 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cylinder3D_Re3900", choices=sorted(WORKLOADS))
     ap.add_argument("--t-batch", type=int, default=None)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--shard", choices=["snapshots", "cells"], default="snapshots",
-                    help="N>1: every rank interpolates all cells for its own snapshot batches (weak scaling, default) or "
-                         "its contiguous range of the generated cells for the same snapshots (strong scaling)")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baselines and the end-to-end leg (profiling runs)")
+    ap.add_argument("--shard", choices=["cells", "snapshots"], default="cells",
+                    help="N>1: every rank interpolates its contiguous range of the generated cells for the same snapshots "
+                         "(leaf-cell shards, default) or all cells for its own snapshot batches")
     ap.add_argument("--direct", action="store_true", help="time the direct gather kernel (s3_interp) instead of the "
                     "planned LDS-tiled kernel (s3_interp_planned)")
     args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        ap.error(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N ranks with `python -m torch.distributed.run --nnodes=1 "
+                 f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port P bench.py --gpus {args.gpus} ...`")
 
     # stdout carries exactly one JSON line: libraries that print there (the RCCL version banner at communicator
     # creation) are sent to stderr for the whole run, the result goes to the saved descriptor at the end
@@ -137,23 +222,15 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # S3_BENCH_SHARE_GPU=1 + S3_DIST_BACKEND=gloo: rehearsal of the N>1 code path on a box with a single GPU
     share = os.environ.get("S3_BENCH_SHARE_GPU") == "1"
     pt.cuda.set_device(0 if share else local_rank)
-    # S3_BENCH_FORCE_DIST=1: run the process-group code path (RCCL init, barriers, MAX all-reduce) with a single rank too
-    use_dist = world > 1 or os.environ.get("S3_BENCH_FORCE_DIST") == "1"
-    if use_dist:
-        backend = os.environ.get("S3_DIST_BACKEND", "nccl")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=pt.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
-
-    from sparsespatialsampling_amd import geometry, hipops
+    from sparsespatialsampling_amd import geometry, hipops, parallel
     from sparsespatialsampling_amd.s_cube import SamplingTree
+    if os.environ.get("S3_DIST_BACKEND") == "gloo" and world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+    comm = parallel.init()                 # RCCL communicator inside libs3hip.so when world > 1
     import logging
     logging.getLogger().setLevel(logging.WARNING)
 
@@ -161,83 +238,77 @@ def main():
     if args.t_batch:
         cfg["t_batch"] = args.t_batch
     k = 26
-    x, metric = synthetic_cylinder3d(cfg)
-    if os.environ.get("S3_BENCH_MESH_ORDER") == "1":
-        # experiment: points stored in a spatially coherent order (as a CFD mesh numbering would be) instead of random
-        q = ((x - x.min(0)) / (x.max(0) - x.min(0)).max() * 1023).astype(np.int64)
-
-        def spread(v):
-            v = (v | (v << 16)) & 0x030000FF
-            v = (v | (v << 8)) & 0x0300F00F
-            v = (v | (v << 4)) & 0x030C30C3
-            return (v | (v << 2)) & 0x09249249
-        order = np.argsort(spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2), kind="stable")
-        x, metric = np.ascontiguousarray(x[order]), np.ascontiguousarray(metric[order])
-    geos = [geometry.CubeGeometry("domain", True, cfg["lo"], [float(v) for v in cfg["hi"]]),
-            geometry.CylinderGeometry3D("cylinder", False, [(0.8, 1.0, -1.0), (0.8, 1.0, 1.0)], 0.05, refine=True)]
+    x, metric, geos, tree_kw = build_case(args.workload, cfg, geometry)
 
     # ---- refine (grid generation), timed separately -----------------------------------------------------------
-    # one tiny call first: context creation and the load of the library's code objects are one-off start-up cost
-    warm = hipops.KnnIndex(np.random.default_rng(0).random((64, 3)))
-    warm.query(np.zeros((1, 3)), 4)
+    # one tiny run first: context creation, the load of the library's code objects and the first launch of every kernel
+    # are one-off start-up cost of the process, not of a grid generation
+    rng0 = np.random.default_rng(0)
+    xs = rng0.random((20000, 3))
+    warm = SamplingTree(pt.from_numpy(xs), pt.from_numpy(0.1 + np.exp(-4 * np.linalg.norm(xs - 0.5, axis=1))),
+                        [geometry.CubeGeometry("domain", True, [0.0, 0.0, 0.0], [1.0, 1.0, 1.0]),
+                         geometry.CylinderGeometry3D("c", False, [(0.5, 0.5, -1.0), (0.5, 0.5, 2.0)], 0.1, refine=True)],
+                        uniform_level=3, min_metric=0.3)
+    warm.refine()
     warm.close()
+    del warm, xs
     pt.cuda.synchronize()
+    comm.barrier()
     t0 = time.perf_counter()
-    tree = SamplingTree(pt.from_numpy(x), pt.from_numpy(metric), geos, uniform_level=cfg["uniform_levels"],
-                        min_metric=cfg["min_metric"])
+    tree = SamplingTree(pt.from_numpy(x), pt.from_numpy(metric), geos, **tree_kw)
+    t_init = time.perf_counter() - t0
     tree.refine()
     pt.cuda.synchronize()
-    refine_s = time.perf_counter() - t0
+    refine_s = comm.allreduce_max(time.perf_counter() - t0)
     centers = tree.all_centers.numpy()
     info = dict(tree.data_final_mesh)
-    n_cells_total = tree._topo.n_cells
-    tree._backend.close()
-    del tree
+    n_cells_total = tree._topo_engine.n_created
+    tree.close()
+    del tree, metric
 
     # ---- KNN cache (once) -------------------------------------------------------------------------------------
     t0 = time.perf_counter()
-    knn = hipops.KnnIndex(x, hipops.knn_occupancy(k, 3))
-    idx, dist_ = knn.query(centers, k)
-    w = hipops.idw_weights(dist_)
-    pt.cuda.synchronize()
-    knn_cache_s = time.perf_counter() - t0
     nc_total = len(centers)
+    c0, c1 = (0, nc_total)
     if world > 1 and args.shard == "cells":
-        # leaf cells shard across ranks: contiguous ranges of the generated grid, no data-path collective
-        from sparsespatialsampling_amd.parallel import shard_range
-        c0, c1 = shard_range(nc_total, rank, world)
-        centers, idx, w = centers[c0:c1], idx[c0:c1].contiguous(), w[c0:c1].contiguous()
+        c0, c1 = parallel.shard_range(nc_total, rank, world)          # contiguous range of the generated leaf cells
+    my_centers = np.ascontiguousarray(centers[c0:c1])
+    knn = hipops.KnnIndex(x, hipops.knn_occupancy(k, 3))
+    idx, dist_ = knn.query(my_centers, k)
+    w = hipops.idw_weights(dist_)
     knn.close()
     del dist_
+    # only the source rows this rank's cells reference are resident (ExportData uploads exactly those per batch)
+    used, remap = hipops.referenced_rows([idx], len(x))
+    n_rows = int(used.numel())
+    hipops.remap_indices(idx, remap)
+    del remap
     plan = None
-    if not args.direct and cfg["t_batch"] % 4 == 0:      # the tiled kernel needs 16-byte aligned fp32 rows
-        plan = hipops.InterpPlan(idx, len(x), centers, tile_cells=int(os.environ.get("S3_TILE_CELLS", "0")))
-        pt.cuda.synchronize()
+    if not args.direct:
+        plan = hipops.InterpPlan(idx, n_rows, my_centers, tile_cells=int(os.environ.get("S3_TILE_CELLS", "0")))
+        plan.set_weights(w)
+    pt.cuda.synchronize()
     knn_cache_s = time.perf_counter() - t0
-    nc, n_src, t_b = len(centers), len(x), cfg["t_batch"]
-    n_unique = int(pt.unique(idx).numel())          # plumbing: only used for the algorithmic byte count
+    nc, t_b = len(my_centers), cfg["t_batch"]
 
     # ---- synthetic snapshot batch resident in HBM ---------------------------------------------------------------
     gen = pt.Generator(device="cuda").manual_seed(1234 + (rank if args.shard == "snapshots" else 0))
-    if plan is not None:
-        # same layout the export path uploads into: [N, n_comp*T] with the row pitch padded to a multiple of 128 bytes
-        data = hipops.padded_rows(n_src, t_b, pt.float32, "cuda", int(os.environ.get("S3_BENCH_PITCH_EXTRA", "0")))
-        data.normal_(generator=gen)
-    else:
-        data = pt.randn((n_src, 1, t_b), dtype=pt.float32, device="cuda", generator=gen)
-    out = pt.empty((nc, t_b) if plan is not None else (nc, 1, t_b), dtype=pt.float64, device="cuda")
+    # the layout the export path uploads into: [rows, T] with the pitch of hipops.padded_rows
+    data = hipops.padded_rows(n_rows, t_b, pt.float32, "cuda", int(os.environ.get("S3_BENCH_PITCH_EXTRA", "0")))
+    data.normal_(generator=gen)
+    dense = data.contiguous() if args.direct else None
+    out = pt.empty((nc, t_b), dtype=pt.float64, device="cuda")
 
     def step():
         if plan is not None:
             plan.interp(w, data, out=out)
         else:
-            hipops.interp(w, idx, data, out=out)
+            hipops.interp(w, idx, dense, out=out)
 
     for _ in range(args.warmup):
         step()
     pt.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
+    comm.barrier()
     ev = [(pt.cuda.Event(enable_timing=True), pt.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for a, b in ev:
@@ -245,46 +316,54 @@ def main():
         step()
         b.record()
     pt.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        tmax = pt.tensor([elapsed], dtype=pt.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    comm.barrier()
+    elapsed = comm.allreduce_max(time.perf_counter() - t0)
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))       # HIP events on the launch stream
 
     copy_bw = copy_bandwidth_gbs() if rank == 0 else None
     if rank == 0:
         units = (nc * world if args.shard == "snapshots" else nc_total) * t_b * args.steps
         value = units / elapsed / 1e6
-        # algorithmic HBM bytes of one launch: every referenced source row once + every output once +
-        # idx (int32) / weights (f64) once
-        b_alg = n_unique * t_b * 4 + nc * t_b * 8 + nc * k * (4 + 8)
+        # algorithmic HBM bytes of one launch on this rank: every referenced source row once + every output
+        # once + idx (int32) / weights (f64) once
+        b_alg = n_rows * t_b * 4 + nc * t_b * 8 + nc * k * (4 + 8)
         achieved = b_alg / (kernel_ms * 1e-3) / 1e9
-        workload = (f"{args.workload} (synthetic, SURVEY 8(d) C3): {n_src} points x {t_b} snapshots "
-                    f"per step, {nc_total} generated cells, k={k}, fp32 in / f64 out")
+        workload = (f"{args.workload} (synthetic, SURVEY 8(d)): {len(x)} points x {t_b} snapshots per step, "
+                    f"{nc_total} generated cells, k={k}, fp32 in / f64 out")
+        traffic, traffic_src = recorded_traffic(f"{args.workload}/T{t_b}") if plan is not None and world == 1 else (None, None)
+        short = plan is not None and t_b * 4 <= 64
         res = {
             "metric": "Mcells*snapshots/s interpolated", "value": value, "unit": "Mcells*snapshots/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak" if args.shard == "snapshots" else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": workload, "n_points": n_src, "n_cells": nc_total, "t_batch": t_b, "k": k, "n_comp": 1,
-                       "parallelism": f"{'snapshot-axis' if args.shard == 'snapshots' else 'leaf-cell'} shards x{world}"},
-            "refine_wall_s": refine_s, "refine_iterations": info["iterations"], "refine_cells_created": n_cells_total,
-            "refine_leaves_per_s": nc / refine_s, "knn_cache_s": knn_cache_s,
+            "higher_is_better": True, "scaling": "weak" if args.shard == "snapshots" else "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": workload, "n_points": len(x), "n_cells": nc_total, "t_batch": t_b, "k": k, "n_comp": 1,
+                       "parallelism": f"{'snapshot-axis' if args.shard == 'snapshots' else 'leaf-cell'} shards x{world}",
+                       "collectives": comm.name},
+            "refine_wall_s": refine_s, "refine_init_s": t_init, "refine_iterations": info["iterations"],
+            "refine_cells_created": n_cells_total, "refine_leaves_per_s": nc_total / refine_s, "knn_cache_s": knn_cache_s,
             "captured_metric": info["metric_per_iter"][-1],
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "copy_kernel_GBs": copy_bw, "frac_of_copy_kernel": achieved / copy_bw,
-                         "traffic": recorded_traffic(workload) if plan is not None else None, "kernel": "interp_kernel<float,4>" if plan is None else "interp_planned_kernel<float>",
+                         "traffic": traffic, "traffic_source": None if traffic is None else f"recorded, not measured in this run: {traffic_src}",
+                         "kernel": "interp_kernel<float,4>" if plan is None else
+                                   ("interp_planned_short_kernel<float,64>" if short else "interp_planned_kernel<float,64>"),
                          "staged_rows_per_launch": None if plan is None else plan.total_rows, "kernel_ms": kernel_ms,
-                         "algorithmic_bytes": b_alg, "unique_source_rows": n_unique,
+                         "algorithmic_bytes": b_alg, "resident_source_rows": n_rows, "cells_on_this_rank": nc,
                          "gather_upper_bound_bytes": nc * k * t_b * 4 + nc * t_b * 8},
         }
         if not args.no_cpu_baseline and world == 1:       # reported at N=1 only
-            res["cpu_baseline"] = cpu_baseline(x, centers, k, min(t_b, 64))
+            res["cpu_baseline"] = cpu_baseline(w, idx, data, k)
+            del data, out
+            pt.cuda.empty_cache()
+            if not cfg.get("kind") == "box":
+                res["end_to_end"] = end_to_end(x, centers, k)
+            res["refine_cpu_baseline"] = refine_cpu_baseline()
         os.write(json_fd, (json.dumps(res) + "\n").encode())
-    if use_dist:
-        dist.barrier()
+    comm.barrier()
+    parallel.shutdown()
+    if os.environ.get("S3_DIST_BACKEND") == "gloo" and world > 1:
+        import torch.distributed as dist
         dist.destroy_process_group()
 
 

@@ -216,6 +216,32 @@ int s3_remap_indices(int32_t *d_idx, int64_t n, const int32_t *d_remap, int64_t 
 int s3_gather_rows(const void *d_src, int64_t n_src_rows, int64_t row_bytes, int64_t src_pitch_bytes,
                    const int32_t *d_ids /*[n] or NULL*/, int64_t n, void *d_dst, int64_t dst_pitch_bytes, s3_stream stream);
 
+
+/* ---- multi-GPU (one process per GPU, RCCL over xGMI) -----------------------------------------------------
+ * The interpolation shards over the generated cells with no collective.  The refine loop has one exchange per batch:
+ * every rank evaluates s3_child_gain for its 1/W slice of the new cells (the reference farms the same work out to a
+ * process pool, s_cube.py:207-241) and ONE grouped in-place all-gather returns metric and gain to everybody
+ * (s3_comm_allgather_inplace); the captured metric (s_cube.py:317-336) is reduced as per-block partial sums
+ * (s3_sumsq_blocks, every rank a share of the blocks), gathered the same way and added in block order on every rank
+ * (s3_sum_ordered), so that the result is bit-identical for any number of ranks.
+ * Bootstrap: rank 0 calls s3_comm_unique_id and hands the 128 bytes to the other ranks by any host channel. */
+typedef struct s3_comm s3_comm;
+#define S3_COMM_ID_BYTES 128
+int s3_comm_unique_id(void *h_id_out, size_t bytes /* >= S3_COMM_ID_BYTES */);
+int s3_comm_init(const void *h_id, size_t bytes, int rank, int world, s3_comm **out);   /* the current device is used */
+void s3_comm_destroy(s3_comm *comm);
+int s3_comm_rank(const s3_comm *comm, int *rank, int *world);
+int s3_comm_allgather_inplace(s3_comm *comm, void *const *d_arrays, const size_t *bytes_per_rank, int n_arrays,
+                              s3_stream stream);
+int s3_comm_allreduce_f64(s3_comm *comm, double *d_buf, int64_t n, int op /*0 sum, 1 max*/, s3_stream stream);
+/* captured-metric numerator in a form that does not depend on how the work is split: partial[b] = sum of metric^2 over the
+ * leaf cells of the 1024-cell block b (fixed reduction tree inside a block), for blocks [block_begin, block_end);
+ * s3_sum_ordered adds n values in index order (fixed tree) into d_out[0] */
+#define S3_SUMSQ_BLOCK 1024
+int s3_sumsq_blocks(const double *d_metric, const uint8_t *d_leaf, int64_t n_cells, int64_t block_begin, int64_t block_end,
+                    double *d_partial /*[n_blocks total], entries [block_begin, block_end) written*/, s3_stream stream);
+int s3_sum_ordered(const double *d_values, int64_t n, double *d_out, s3_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

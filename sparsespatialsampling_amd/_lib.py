@@ -72,6 +72,14 @@ HIP_SIGNATURES = {
     "s3_interp_plan_info": (c_int, [c_vp, C.POINTER(c_i64), C.POINTER(c_i64)]),
     "s3_interp_plan_set_weights": (c_int, [c_vp, c_vp, c_vp]),
     "s3_interp_planned": (c_int, [c_vp, c_vp, c_vp, c_int, c_i64, c_i64, c_vp, c_vp]),
+    "s3_comm_unique_id": (c_int, [c_vp, C.c_size_t]),
+    "s3_comm_init": (c_int, [c_vp, C.c_size_t, c_int, c_int, C.POINTER(c_vp)]),
+    "s3_comm_destroy": (None, [c_vp]),
+    "s3_comm_rank": (c_int, [c_vp, C.POINTER(c_int), C.POINTER(c_int)]),
+    "s3_comm_allgather_inplace": (c_int, [c_vp, c_vp, c_vp, c_int, c_vp]),
+    "s3_comm_allreduce_f64": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp]),
+    "s3_sumsq_blocks": (c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp]),
+    "s3_sum_ordered": (c_int, [c_vp, c_i64, c_vp, c_vp]),
     "s3_mark_rows": (c_int, [c_vp, c_i64, c_i64, c_vp, c_vp]),
     "s3_compact_rows": (c_int, [c_vp, c_i64, c_vp, C.POINTER(c_i64), c_vp]),
     "s3_remap_indices": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp]),

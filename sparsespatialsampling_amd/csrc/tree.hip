@@ -235,6 +235,35 @@ __global__ void __launch_bounds__(256) sumsq_final_kernel(const double *__restri
     if (threadIdx.x == 0) *out = r;
 }
 
+// captured metric in a form that does not depend on how the cells are split over ranks: one workgroup per 1024-cell block
+// (4 cells per lane, fixed tree), then the block sums are added in index order by a single workgroup (fixed tree)
+__global__ void __launch_bounds__(256)
+sumsq_blocks_kernel(const double *__restrict__ metric, const uint8_t *__restrict__ leaf, int64_t n_cells, int64_t block_begin,
+                    double *__restrict__ partial) {
+    __shared__ double sh[4];
+    const int64_t blk = block_begin + blockIdx.x;
+    const int64_t base = blk * S3_SUMSQ_BLOCK;
+    double s = 0.0;
+#pragma unroll
+    for (int u = 0; u < S3_SUMSQ_BLOCK / 256; ++u) {
+        const int64_t i = base + u * 256 + threadIdx.x;
+        if (i < n_cells && leaf[i]) {
+            const double m = metric[i];
+            s += m * m;
+        }
+    }
+    const double r = block_sum_256(s, sh);
+    if (threadIdx.x == 0) partial[blk] = r;
+}
+
+__global__ void __launch_bounds__(256) sum_ordered_kernel(const double *__restrict__ v, int64_t n, double *__restrict__ out) {
+    __shared__ double sh[4];
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 256) s += v[i];        // lane l adds l, l + 256, ... in that order
+    const double r = block_sum_256(s, sh);
+    if (threadIdx.x == 0) *out = r;
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // a8: top-N by (gain desc, id asc) via a radix select over the 96-bit composite key (orderable gain bits, ~id)
 // ------------------------------------------------------------------------------------------------------------------
@@ -473,6 +502,27 @@ int s3_sumsq_leaf(const double *d_metric, const uint8_t *d_leaf, int64_t begin, 
     int nb = (int)std::min<int64_t>(1024, std::max<int64_t>(1, (end - begin + 1023) / 1024));
     sumsq_partial_kernel<<<nb, 256, 0, as_stream(stream)>>>(d_metric, d_leaf, begin, end, d_scratch);
     sumsq_final_kernel<<<1, 256, 0, as_stream(stream)>>>(d_scratch, nb, d_out);
+    S3_LAUNCH_CHECK();
+    return S3_OK;
+}
+
+int s3_sumsq_blocks(const double *d_metric, const uint8_t *d_leaf, int64_t n_cells, int64_t block_begin, int64_t block_end,
+                    double *d_partial, s3_stream stream) {
+    S3_REQUIRE(d_metric && d_leaf && d_partial, "s3_sumsq_blocks: null array");
+    const int64_t n_blocks = (n_cells + S3_SUMSQ_BLOCK - 1) / S3_SUMSQ_BLOCK;
+    S3_REQUIRE(n_cells >= 0 && block_begin >= 0 && block_end >= block_begin && block_end <= n_blocks,
+               "s3_sumsq_blocks: bad block range [%lld, %lld) of %lld", (long long)block_begin, (long long)block_end, (long long)n_blocks);
+    if (block_end == block_begin) return S3_OK;
+    S3_REQUIRE(block_end - block_begin < ((int64_t)1 << 31), "s3_sumsq_blocks: too many blocks");
+    sumsq_blocks_kernel<<<(unsigned)(block_end - block_begin), 256, 0, as_stream(stream)>>>(d_metric, d_leaf, n_cells, block_begin,
+                                                                                          d_partial);
+    S3_LAUNCH_CHECK();
+    return S3_OK;
+}
+
+int s3_sum_ordered(const double *d_values, int64_t n, double *d_out, s3_stream stream) {
+    S3_REQUIRE(d_values && d_out && n >= 0, "s3_sum_ordered: bad arguments");
+    sum_ordered_kernel<<<1, 256, 0, as_stream(stream)>>>(d_values, n, d_out);
     S3_LAUNCH_CHECK();
     return S3_OK;
 }

@@ -431,6 +431,15 @@ def sumsq_leaf(metric, leaf, begin, end, out, scratch):
                                        _stream()), "s3_sumsq_leaf")
 
 
+def sumsq_blocks(metric, leaf, n_cells, block_begin, block_end, partial):
+    check(_lib.hip_lib().s3_sumsq_blocks(_ptr(metric), _ptr(leaf), int(n_cells), int(block_begin), int(block_end),
+                                         _ptr(partial), _stream()), "s3_sumsq_blocks")
+
+
+def sum_ordered(values, n, out):
+    check(_lib.hip_lib().s3_sum_ordered(_ptr(values), int(n), _ptr(out), _stream()), "s3_sum_ordered")
+
+
 def topn_leaf(gain, leaf, n_cells, n_top, scratch):
     """-> numpy int32 ids ordered like heapq.nlargest(n_top, leaves, key=(gain, -id))  (s_cube.py:601-602)."""
     out = np.empty(max(int(n_top), 1), dtype=np.int32)

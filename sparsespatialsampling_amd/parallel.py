@@ -1,26 +1,29 @@
 """
-Multi-GPU glue (one process per GPU, ``torch.distributed`` with the ``nccl`` backend = RCCL over xGMI).
+Multi-GPU layer of the S^3 path: one process per GPU, the collectives run inside libs3hip.so on RCCL over xGMI
+(``s3_comm_*``, csrc/comm.hip).  SURVEY.md 8(e):
 
-The S^3 hot path shards without a data-path collective:
+* **interpolation** -- the generated cells are split into contiguous per-rank ranges (``shard_range``); every rank builds
+  the KNN cache / plan of its range, uploads only the source rows that range references and writes its own output rows.
+  No collective.
+* **refine** -- point cloud, KNN index and cell arrays are replicated; per batch every rank evaluates the KNN metric /
+  gain of its 1/W slice of the new cells (``batch_slice``; the reference spreads the same work over a process pool,
+  s_cube.py:207-241) and ONE grouped all-gather returns the slices to everybody.  The captured metric
+  (s_cube.py:317-336) is reduced as partial sums over fixed 1024-cell blocks, every rank a share of the blocks, gathered
+  and then added in block order on every rank: bit-identical for any number of ranks, so stopping decisions and therefore
+  the grid cannot depend on the world size.
 
-* **interpolation** -- the generated cells (or the snapshot axis) are split into contiguous per-rank ranges, each rank
-  interpolates its range with the KNN index/weights of that range; outputs land in disjoint row ranges
-  (``shard_range``).  No communication.
-* **refine** -- every rank holds the replicated point cloud + cell arrays; the only reduction that spans all cells per
-  iteration is the captured-metric numerator (sum of metric^2 over the leaves).  Each rank reduces a 1/W slice of the
-  cell id range on its GPU and one 8-byte all-reduce combines them (``allreduce_sumsq``) -- the "one RCCL all-reduce
-  per refinement iteration" of the north star.
-
-With a single process both helpers degenerate to the local computation.
+``get_comm()`` returns the process-wide communicator: ``RcclComm`` on GPUs (bootstrap: rank 0 creates the RCCL id and
+publishes it through a ``torch.distributed.TCPStore`` on MASTER_ADDR:MASTER_PORT -- plumbing, no process group is
+created), ``GlooComm`` for CPU tests / single-GPU rehearsals (``S3_DIST_BACKEND=gloo``, uses an initialised
+``torch.distributed`` gloo group), ``SoloComm`` when there is one process.
 """
+import ctypes as C
+import os
+
+import numpy as np
 import torch as pt
-import torch.distributed as dist
 
-
-def world():
-    if dist.is_available() and dist.is_initialized():
-        return dist.get_rank(), dist.get_world_size()
-    return 0, 1
+SUMSQ_BLOCK = 1024           # cells per partial sum of the captured metric (include/s3hip.h S3_SUMSQ_BLOCK)
 
 
 def shard_range(n, rank=None, world_size=None):
@@ -32,14 +35,169 @@ def shard_range(n, rank=None, world_size=None):
     return begin, begin + base + (1 if rank < rem else 0)
 
 
-def allreduce_sumsq(backend, n_cells):
-    """sum over leaf cells of metric^2; ranks reduce disjoint id ranges and all-reduce the partial sums"""
-    rank, size = world()
-    if size == 1:
-        return backend.sumsq(n_cells)
-    begin, end = shard_range(n_cells, rank, size)
-    part = backend.sumsq_range(begin, end)          # 1-element device tensor (RCCL) or CPU tensor (gloo tests)
-    if part.is_cuda and dist.get_backend() == "gloo":
-        part = part.cpu()                           # single-GPU rehearsal of the multi-rank path
-    dist.all_reduce(part, op=dist.ReduceOp.SUM)
-    return float(part.item())
+def batch_slice(n, rank, world_size):
+    """equal-sized chunks for an in-place all-gather: (chunk, begin, end) -- rank r owns [r * chunk, (r + 1) * chunk)
+    clipped to n; the gathered array spans world_size * chunk entries"""
+    chunk = -(-int(n) // int(world_size))
+    begin = min(rank * chunk, n)
+    return chunk, begin, min(begin + chunk, n)
+
+
+class SoloComm:
+    rank, world, name = 0, 1, "solo"
+
+    def allgather_inplace(self, arrays, counts):
+        pass
+
+    def allreduce_max(self, value):
+        return float(value)
+
+    def barrier(self):
+        pass
+
+    def close(self):
+        pass
+
+
+class GlooComm(SoloComm):
+    """``torch.distributed`` gloo group (CPU): the N > 1 protocol without GPUs, or several ranks sharing one GPU"""
+    name = "gloo"
+
+    def __init__(self):
+        import torch.distributed as dist
+        self._dist = dist
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+
+    def allgather_inplace(self, arrays, counts):
+        for a, cnt in zip(arrays, counts):
+            if cnt == 0:
+                continue
+            t = pt.from_numpy(a) if isinstance(a, np.ndarray) else a
+            flat = t.reshape(-1)[:self.world * cnt]
+            host = flat.cpu() if flat.is_cuda else flat
+            mine = host[self.rank * cnt:(self.rank + 1) * cnt].clone()
+            out = pt.empty_like(host)
+            self._dist.all_gather_into_tensor(out, mine)
+            flat.copy_(out)
+
+    def allreduce_max(self, value):
+        t = pt.tensor([float(value)], dtype=pt.float64)
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def barrier(self):
+        self._dist.barrier()
+
+
+class RcclComm(SoloComm):
+    """communicator inside libs3hip.so (RCCL); device tensors only"""
+    name = "rccl"
+
+    def __init__(self, rank, world_size, store):
+        from . import _lib, hipops
+        self._lib, self._ops = _lib, hipops
+        self.rank, self.world = int(rank), int(world_size)
+        lib = _lib.hip_lib()
+        ident = (C.c_char * 128)()
+        if self.rank == 0:
+            hipops.check(lib.s3_comm_unique_id(ident, 128), "s3_comm_unique_id")
+            store.set("s3_comm_id", bytes(ident.raw))
+        else:
+            ident.raw = store.get("s3_comm_id")
+        self._h = C.c_void_p(0)
+        hipops.device()
+        hipops.check(lib.s3_comm_init(ident, 128, self.rank, self.world, C.byref(self._h)), "s3_comm_init")
+        self._scalar = pt.zeros(1, dtype=pt.float64, device=hipops.device())
+
+    def allgather_inplace(self, arrays, counts):
+        """``arrays[i]`` is a contiguous device tensor whose first ``world * counts[i]`` elements are gathered in place:
+        rank r contributes elements [r * counts[i], (r + 1) * counts[i]).  One RCCL group for all arrays."""
+        n = len(arrays)
+        ptrs = (C.c_void_p * n)(*[a.data_ptr() for a in arrays])
+        sizes = (C.c_size_t * n)(*[int(c) * a.element_size() for a, c in zip(arrays, counts)])
+        for a, c in zip(arrays, counts):
+            if not (a.is_cuda and a.is_contiguous() and a.numel() >= self.world * c):
+                raise ValueError("allgather_inplace: contiguous device tensors with room for world * count elements required")
+        self._ops.check(self._lib.hip_lib().s3_comm_allgather_inplace(self._h, ptrs, sizes, n, self._ops._stream()),
+                        "s3_comm_allgather_inplace")
+
+    def _allreduce(self, value, op):
+        self._scalar[0] = float(value)
+        self._ops.check(self._lib.hip_lib().s3_comm_allreduce_f64(self._h, C.c_void_p(self._scalar.data_ptr()), 1, op,
+                                                                  self._ops._stream()), "s3_comm_allreduce_f64")
+        return float(self._scalar.item())
+
+    def allreduce_max(self, value):
+        return self._allreduce(value, 1)
+
+    def barrier(self):
+        self._allreduce(0.0, 0)
+
+    def close(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            self._lib.hip_lib().s3_comm_destroy(h)
+            self._h = C.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # interpreter shutdown
+            pass
+
+
+_comm = None
+
+
+def init(backend=None):
+    """create the process-wide communicator from the launcher's environment (RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT);
+    idempotent.  ``backend``: "rccl" (default with more than one rank), "gloo" (needs an initialised torch.distributed
+    group), None = S3_DIST_BACKEND or "rccl"."""
+    global _comm
+    if _comm is not None:
+        return _comm
+    rank, world_size = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    backend = backend or os.environ.get("S3_DIST_BACKEND", "rccl")
+    if backend == "gloo":
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            _comm = GlooComm() if dist.get_world_size() > 1 else SoloComm()
+        else:
+            _comm = SoloComm()
+    elif world_size > 1 or os.environ.get("S3_COMM_FORCE") == "1":
+        from torch.distributed import TCPStore
+        store = TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29500")), world_size,
+                         is_master=(rank == 0))
+        _comm = RcclComm(rank, world_size, store)
+        _comm._store = store            # keep the rendezvous alive as long as the communicator
+    else:
+        _comm = SoloComm()
+    return _comm
+
+
+def get_comm():
+    """the communicator of this process: what ``init`` created, else a gloo group that torch.distributed already has,
+    else a single-process stand-in"""
+    global _comm
+    if _comm is not None:
+        return _comm
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if "gloo" in str(dist.get_backend()):
+            return init("gloo")
+        # an RCCL process group of the caller: bootstrap over its store
+        _comm = RcclComm(dist.get_rank(), dist.get_world_size(), dist.distributed_c10d._get_default_store())
+        return _comm
+    return SoloComm()
+
+
+def shutdown():
+    global _comm
+    if _comm is not None:
+        _comm.close()
+        _comm = None
+
+
+def world():
+    c = get_comm()
+    return c.rank, c.world

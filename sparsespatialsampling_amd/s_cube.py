@@ -441,9 +441,9 @@ class SamplingTree(object):
     def _compute_captured_metric(self) -> bool:
         """||metric at the leaf centres||_2 / ||target||_2 (s_cube.py:317-336).  Each leaf's prediction was stored
         when the cell was created (the reference recomputes the identical values); the sum of squares is one device
-        reduction.  Multi-GPU runs split the reduction range across ranks and all-reduce (parallel.py)."""
-        from . import parallel
-        sumsq = parallel.allreduce_sumsq(self._backend, self._topo_engine.n_created)
+        reduction over fixed 1024-cell blocks (multi-GPU: every rank a share of the blocks, one small all-gather; the result
+        does not depend on the number of ranks, parallel.py)."""
+        sumsq = self._backend.sumsq(self._topo_engine.n_created)
         _ratio = float(np.sqrt(sumsq)) / self._target_norm
         self._metric.append(_ratio)
         return _ratio < self._min_metric

@@ -12,7 +12,7 @@ Per refine batch the host sends the ordered parent ids (4 B each) and receives t
 import numpy as np
 import torch as pt
 
-from . import hipops
+from . import hipops, parallel
 
 
 def _level_factor_table(width, n_dims, n_levels=64):
@@ -35,6 +35,7 @@ class HipTreeBackend:
         self.center = self.level = self.metric = self.gain = self.leaf = None
         self._parents = None
         self._poly_cache = {}
+        self.comm = parallel.get_comm()          # more than one rank: the KNN work of a batch is split, see refine_batch
 
     # -- plain KNN regression at arbitrary points (root cell, s_cube.py:372) ------------------------------------
     def predict(self, q):
@@ -58,7 +59,8 @@ class HipTreeBackend:
         for name, t in new.items():
             setattr(self, name, t)
         self.cap = cap
-        self._sumsq_scratch = pt.empty(1024, dtype=pt.float64, device=self.dev)
+        n_blocks = -(-cap // parallel.SUMSQ_BLOCK)
+        self._sumsq_partial = pt.zeros(n_blocks + self.comm.world, dtype=pt.float64, device=self.dev)
         self._sumsq_out = pt.empty(1, dtype=pt.float64, device=self.dev)
 
     def start(self, root_center, width, gain0, root_metric, root_gain):
@@ -77,12 +79,18 @@ class HipTreeBackend:
         evaluated (s_cube.py:875-900 -> a3 + a4)."""
         n_par = len(parents)
         n_new = n_par * self.nch
-        self._grow(first + n_new)
+        chunk, b, e = parallel.batch_slice(n_new, self.comm.rank, self.comm.world)
+        self._grow(first + chunk * self.comm.world)              # room for the gathered slices (equal-sized chunks)
         self._parents = hipops.to_device(np.ascontiguousarray(parents, dtype=np.int32))
         hipops.make_children(self.center, self.level, self._parents, first, float(self.width))
-        scratch = pt.empty(n_new * (self.nch + 1), dtype=pt.float64, device=self.dev)
-        hipops.child_gain(self.knn, self.k, self.center, self.level, first, n_new, float(self.width),
-                          self.level_factor, self.gain0, self.metric, self.gain, scratch)
+        # the KNN metric / gain of this rank's slice of the new cells (all of them with one rank) ...
+        if e > b:
+            scratch = pt.empty((e - b) * (self.nch + 1), dtype=pt.float64, device=self.dev)
+            hipops.child_gain(self.knn, self.k, self.center, self.level, first + b, e - b, float(self.width),
+                              self.level_factor, self.gain0, self.metric, self.gain, scratch)
+        # ... and one grouped all-gather hands every rank the others' slices
+        if self.comm.world > 1:
+            self.comm.allgather_inplace([self.metric[first:], self.gain[first:]], [chunk, chunk])
         return n_new
 
     def mask(self, geometries, refine_mode, cells=None, first=0, n=None):
@@ -128,14 +136,15 @@ class HipTreeBackend:
                             self._last_invalid if use_invalid else None)
 
     def sumsq(self, n_cells):
-        hipops.sumsq_leaf(self.metric, self.leaf, 0, n_cells, self._sumsq_out, self._sumsq_scratch)
+        """sum of metric^2 over the leaves: partial sums of fixed 1024-cell blocks (every rank a share of the blocks,
+        gathered), added in block order -- the same bits for any number of ranks"""
+        n_blocks = -(-n_cells // parallel.SUMSQ_BLOCK)
+        chunk, b, e = parallel.batch_slice(n_blocks, self.comm.rank, self.comm.world)
+        hipops.sumsq_blocks(self.metric, self.leaf, n_cells, b, e, self._sumsq_partial)
+        if self.comm.world > 1:
+            self.comm.allgather_inplace([self._sumsq_partial], [chunk])
+        hipops.sum_ordered(self._sumsq_partial, n_blocks, self._sumsq_out)
         return float(self._sumsq_out.item())
-
-    def sumsq_range(self, begin, end):
-        """partial captured-metric numerator over cell ids [begin, end) as a 1-element device tensor (multi-GPU)"""
-        out = pt.empty(1, dtype=pt.float64, device=self.dev)
-        hipops.sumsq_leaf(self.metric, self.leaf, begin, end, out, self._sumsq_scratch)
-        return out
 
     def topn(self, n_cells, n_top):
         scratch = hipops.topn_scratch(n_cells, n_top, self.dev)
@@ -151,5 +160,5 @@ class HipTreeBackend:
         self.knn.close()
         self.center = self.level = self.metric = self.gain = self.leaf = None
         self._parents = self._last_invalid = None
-        self._sumsq_out = self._sumsq_scratch = self.level_factor = None
+        self._sumsq_out = self._sumsq_partial = self.level_factor = None
         self._poly_cache = {}

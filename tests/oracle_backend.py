@@ -7,6 +7,7 @@ the checker the GPU tests compare the HIP backend against.  The product never im
 import numpy as np
 
 from oracle import s3_oracle as orc
+from sparsespatialsampling_amd import parallel
 
 
 class OracleTreeBackend:
@@ -23,6 +24,7 @@ class OracleTreeBackend:
         self.metric = np.zeros(0)
         self.gain = np.zeros(0)
         self.leaf = np.zeros(0, dtype=bool)
+        self.comm = parallel.get_comm()      # N > 1 (gloo on CPU): same split / gather protocol as the HIP backend
 
     def predict(self, q):
         return orc.idw_predict(self.pts, self.y, q, self.k)
@@ -45,15 +47,19 @@ class OracleTreeBackend:
     def refine_batch(self, parents, first):
         parents = np.asarray(parents, dtype=np.int64)
         n_new = len(parents) * self.nch
-        self._grow(first + n_new)
+        chunk, b, e = parallel.batch_slice(n_new, self.comm.rank, self.comm.world)
+        self._grow(first + chunk * self.comm.world)
         off = (0.25 * self.width) / (2.0 ** self.level[parents])
         ch = self.center[parents][:, None, :] + orc.DIRS[self.dim][None] * off[:, None, None]
         self.center[first:first + n_new] = ch.reshape(n_new, self.dim)
         self.level[first:first + n_new] = np.repeat(self.level[parents] + 1, self.nch)
-        m, g = orc.child_gain(self.pts, self.y, self.k, self.center[first:first + n_new],
-                              self.level[first:first + n_new], self.width, self.gain0)
-        self.metric[first:first + n_new] = m[:, 0]
-        self.gain[first:first + n_new] = g
+        if e > b:
+            m, g = orc.child_gain(self.pts, self.y, self.k, self.center[first + b:first + e],
+                                  self.level[first + b:first + e], self.width, self.gain0)
+            self.metric[first + b:first + e] = m[:, 0]
+            self.gain[first + b:first + e] = g
+        if self.comm.world > 1:
+            self.comm.allgather_inplace([self.metric[first:], self.gain[first:]], [chunk, chunk])
         self._parents = parents
         return n_new
 
@@ -89,11 +95,20 @@ class OracleTreeBackend:
         self.gain[first:first + n_new][bad] = 0.0
 
     def sumsq(self, n_cells):
-        return orc.sumsq(self.metric[:n_cells][self.leaf[:n_cells]])
-
-    def sumsq_range(self, begin, end):
-        import torch
-        return torch.tensor([orc.sumsq(self.metric[begin:end][self.leaf[begin:end]])], dtype=torch.float64)
+        """partial sums of fixed 1024-cell blocks (this rank's share), gathered, added in block order"""
+        blk = parallel.SUMSQ_BLOCK
+        n_blocks = -(-n_cells // blk)
+        chunk, b, e = parallel.batch_slice(n_blocks, self.comm.rank, self.comm.world)
+        partial = np.zeros(chunk * self.comm.world)
+        for j in range(b, e):
+            sl = slice(j * blk, min((j + 1) * blk, n_cells))
+            partial[j] = orc.sumsq(self.metric[sl][self.leaf[sl]])
+        if self.comm.world > 1:
+            self.comm.allgather_inplace([partial], [chunk])
+        total = 0.0
+        for v in partial[:n_blocks].tolist():
+            total += v
+        return total
 
     def topn(self, n_cells, n_top):
         ids = np.flatnonzero(self.leaf[:n_cells])

@@ -34,10 +34,34 @@ def test_bench_contract_small_workload():
     assert len(lines) == 1, run.stdout[-2000:]
     res = json.loads(lines[0])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "end_to_end", "refine_cpu_baseline",
+                "refine_wall_s"):
         assert key in res, key
     assert res["n_gpus"] == 1 and res["steps"] == 3 and res["warmup"] == 1 and res["higher_is_better"] is True
-    assert res["scaling"] == "weak" and res["vs_baseline"] is None and res["data"] == "synthetic" and "workload" in res["config"]
+    assert res["scaling"] == "strong" and res["vs_baseline"] is None and res["data"] == "synthetic" and "workload" in res["config"]
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(res["roofline"])
     assert res["roofline"]["bound"] == "hbm" and 0 < res["roofline"]["frac"] < 1 and res["value"] > 0
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(res["cpu_baseline"]) and res["cpu_baseline"]["kind"] == "port"
+    assert res["config"]["parallelism"] == "leaf-cell shards x1"
+    assert res["refine_cpu_baseline"]["same_grid_size"] and res["refine_cpu_baseline"]["speedup"] > 1
+    assert res["end_to_end"]["T25"]["Gcells_snapshots_per_s"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_share_one_gpu():
+    """rehearsal of the N = 2 path on one GPU (two processes, gloo for the exchange steps): the grid and the captured
+    metric must be the ones of the single-rank run (rank-count independent reduction), the bench line says leaf-cell
+    shards x2"""
+    import json
+    env = dict(os.environ, S3_BENCH_SHARE_GPU="1", S3_DIST_BACKEND="gloo")
+    base = [os.path.join(ROOT, "bench.py"), "--workload", "cylinder3D_small", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    one = subprocess.run([sys.executable] + base, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", "29611"] + base + ["--gpus", "2"], cwd=ROOT, env=env,
+                         capture_output=True, text=True, timeout=900)
+    assert two.returncode == 0, two.stderr[-3000:]
+    r1, r2 = json.loads(one.stdout.strip().splitlines()[-1]), json.loads(two.stdout.strip().splitlines()[-1])
+    assert r2["n_gpus"] == 2 and r2["config"]["parallelism"] == "leaf-cell shards x2" and r2["config"]["collectives"] == "gloo"
+    assert r1["config"]["n_cells"] == r2["config"]["n_cells"] and r1["refine_cells_created"] == r2["refine_cells_created"]
+    assert r1["captured_metric"] == r2["captured_metric"] and r1["refine_iterations"] == r2["refine_iterations"]

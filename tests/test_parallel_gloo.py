@@ -35,7 +35,8 @@ def _worker(rank, world, port, out):
     assert parallel.world() == (rank, world)
     x, y, geos, kw = refine_inputs("refine_2d_delta", geometry)
     tree = s_cube.SamplingTree(pt.from_numpy(x), pt.from_numpy(y), geometry_obj=geos, **kw)
-    tree.refine()                                    # every captured-metric evaluation went through all_reduce
+    tree.refine()            # every batch: split KNN work + all-gather; every captured metric: gathered block sums
+    assert tree._backend.comm.world == world and tree._backend.comm.name == "gloo"
     res = dict(metric=np.array(tree._metric), centers=tree.all_centers.numpy(), levels=tree.all_levels.numpy(),
                shard=parallel.shard_range(1001))
     gathered = [None] * world
@@ -53,8 +54,36 @@ def test_refine_two_ranks_gloo(tmp_path):
     for r in (r0, r1):                                # both ranks reproduce the reference grid
         assert np.array_equal(r["centers"], z["all_centers"]) and np.array_equal(r["levels"], z["all_levels"])
         np.testing.assert_allclose(r["metric"], z["metric_hist"], rtol=1e-12)
-    assert np.array_equal(r0["metric"], r1["metric"])  # identical on all ranks (all_reduce)
+    assert np.array_equal(r0["metric"], r1["metric"])  # identical on all ranks
     assert r0["shard"] == (0, 501) and r1["shard"] == (501, 1001)
+    # ... and identical to a single-process run, bit for bit: the reduction order does not depend on the world size
+    for p in (ROOT, os.path.join(ROOT, "tests", "golden")):
+        sys.path.insert(0, p) if p not in sys.path else None
+    import sparsespatialsampling_amd.s_cube as s_cube
+    from sparsespatialsampling_amd import geometry
+    from inputs import refine_inputs
+    from tests.oracle_backend import OracleTreeBackend
+    old = s_cube._make_backend
+    s_cube._make_backend = lambda v, t, k: OracleTreeBackend(v, t, k)
+    try:
+        x, y, geos, kw = refine_inputs("refine_2d_delta", geometry)
+        tree = s_cube.SamplingTree(pt.from_numpy(x), pt.from_numpy(y), geometry_obj=geos, **kw)
+        tree.refine()
+    finally:
+        s_cube._make_backend = old
+    assert np.array_equal(np.array(tree._metric), r0["metric"])
+
+
+def test_batch_slice_and_block_shares():
+    from sparsespatialsampling_amd.parallel import batch_slice
+    for n in (0, 1, 7, 8, 9, 1000, 40001):
+        for w in (1, 2, 3, 8):
+            parts = [batch_slice(n, r, w) for r in range(w)]
+            chunk = parts[0][0]
+            assert all(p[0] == chunk for p in parts) and chunk * w >= n
+            covered = [i for _, b, e in parts for i in range(b, e)]
+            assert covered == list(range(n))
+            assert all(b == min(r * chunk, n) for r, (_, b, _e) in enumerate(parts))
 
 
 def test_shard_range_covers_everything():

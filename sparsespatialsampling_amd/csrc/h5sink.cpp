@@ -1,0 +1,372 @@
+// libs3h5.so -- HDF5 sink / source of the S^3 export path on the HDF5 C library (include/s3h5.h).  Host code, no GPU.
+//
+// Reference behaviour covered: Datawriter.write_data (data.py:361-430: one dataset per call in grid/, constant/ or
+// data/<time>/), the per-write-time loop of ExportData._write_data_to_hdf5 (export.py:283-299) and the reads of Dataloader /
+// XDMFWriter (data.py:22-300, 504-777).  The on-disk layout is the reference's; what differs is how it gets there: a whole
+// snapshot batch is queued with one call and written by a background thread from the snapshot-major host buffer while
+// the GPU works on the next batch.
+#include "s3h5.h"
+
+#include <hdf5.h>
+
+#include <condition_variable>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+thread_local char g_err[512] = "";
+std::mutex g_hdf5;                       // the HDF5 library is not assumed to be thread safe: one call at a time
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+hid_t mem_type(int dtype) {
+    switch (dtype) {
+        case S3H5_F32: return H5T_NATIVE_FLOAT;
+        case S3H5_F64: return H5T_NATIVE_DOUBLE;
+        case S3H5_I32: return H5T_NATIVE_INT32;
+        case S3H5_I64: return H5T_NATIVE_INT64;
+        case S3H5_U8: return H5T_NATIVE_UINT8;
+        default: return -1;
+    }
+}
+
+struct Job {
+    std::string path;
+    int dtype, ndim;
+    hsize_t dims[S3H5_MAX_DIMS];
+    const void *data;
+    size_t bytes;
+};
+
+}  // namespace
+
+struct s3h5_file {
+    hid_t fid = -1;
+    bool writable = false;
+    std::deque<Job> queue;
+    std::mutex m;
+    std::condition_variable cv_work, cv_idle;
+    std::thread worker;
+    bool stop = false;
+    const void *busy_data = nullptr;     // buffer of the job being written
+    size_t busy_bytes = 0;
+    int async_error = 0;
+    std::string async_message;
+    int64_t skipped = 0;
+
+    // creates missing intermediate groups (the caller has checked that the dataset does not exist and holds g_hdf5)
+    int write_locked(const std::string &path, int dtype, int ndim, const hsize_t *dims, const void *data) {
+        const hid_t mt = mem_type(dtype);
+        if (mt < 0) { set_error("unknown element type %d", dtype); return S3H5_EINVAL; }
+        hid_t lcpl = H5Pcreate(H5P_LINK_CREATE);
+        H5Pset_create_intermediate_group(lcpl, 1);
+        hid_t space = ndim == 0 ? H5Screate(H5S_SCALAR) : H5Screate_simple(ndim, dims, nullptr);
+        hid_t ds = H5Dcreate2(fid, path.c_str(), mt, space, lcpl, H5P_DEFAULT, H5P_DEFAULT);
+        int rc = S3H5_OK;
+        if (ds < 0) {
+            set_error("could not create dataset '%s'", path.c_str());
+            rc = S3H5_EIO;
+        } else {
+            hsize_t n = 1;
+            for (int i = 0; i < ndim; ++i) n *= dims[i];
+            if (n > 0 && H5Dwrite(ds, mt, H5S_ALL, H5S_ALL, H5P_DEFAULT, data) < 0) {
+                set_error("could not write dataset '%s'", path.c_str());
+                rc = S3H5_EIO;
+            }
+            H5Dclose(ds);
+        }
+        H5Sclose(space);
+        H5Pclose(lcpl);
+        return rc;
+    }
+
+    // an intermediate path component that exists as a link makes H5Lexists on the full path safe only step by step
+    bool exists_locked(const std::string &path) {
+        size_t pos = 0;
+        while (true) {
+            pos = path.find('/', pos + 1);
+            const std::string part = path.substr(0, pos);
+            if (!part.empty() && H5Lexists(fid, part.c_str(), H5P_DEFAULT) <= 0) return false;
+            if (pos == std::string::npos) return true;
+        }
+    }
+
+    void loop() {
+        {
+            std::lock_guard<std::mutex> h(g_hdf5);
+            H5Eset_auto2(H5E_DEFAULT, nullptr, nullptr);      // the error stack (and its printing) is per thread
+        }
+        while (true) {
+            Job j;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv_work.wait(lk, [this] { return stop || !queue.empty(); });
+                if (queue.empty()) return;
+                j = std::move(queue.front());
+                queue.pop_front();
+                busy_data = j.data;
+                busy_bytes = j.bytes;
+            }
+            int rc;
+            std::string msg;
+            {
+                std::lock_guard<std::mutex> h(g_hdf5);
+                rc = exists_locked(j.path) ? S3H5_EEXIST : write_locked(j.path, j.dtype, j.ndim, j.dims, j.data);
+                if (rc != S3H5_OK) msg = g_err;
+            }
+            {
+                std::lock_guard<std::mutex> lk(m);
+                if (rc == S3H5_EEXIST) ++skipped;
+                else if (rc != S3H5_OK && async_error == 0) { async_error = rc; async_message = msg; }
+                busy_data = nullptr;
+                busy_bytes = 0;
+            }
+            cv_idle.notify_all();
+        }
+    }
+};
+
+extern "C" {
+
+const char *s3h5_last_error(void) { return g_err; }
+
+int s3h5_version(unsigned *major, unsigned *minor, unsigned *release) {
+    std::lock_guard<std::mutex> h(g_hdf5);
+    return H5get_libversion(major, minor, release) < 0 ? S3H5_EIO : S3H5_OK;
+}
+
+int s3h5_open(const char *path, const char *mode, s3h5_file **out) {
+    if (!path || !mode || !out) { set_error("s3h5_open: null argument"); return S3H5_EINVAL; }
+    *out = nullptr;
+    std::lock_guard<std::mutex> h(g_hdf5);
+    H5open();
+    H5Eset_auto2(H5E_DEFAULT, nullptr, nullptr);          // errors are reported through return codes, not stderr
+    hid_t fid = -1;
+    bool writable = true;
+    if (!strcmp(mode, "w")) {
+        fid = H5Fcreate(path, H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT);
+    } else if (!strcmp(mode, "a") || !strcmp(mode, "r+")) {
+        fid = H5Fopen(path, H5F_ACC_RDWR, H5P_DEFAULT);
+        if (fid < 0 && !strcmp(mode, "a")) fid = H5Fcreate(path, H5F_ACC_EXCL, H5P_DEFAULT, H5P_DEFAULT);
+    } else if (!strcmp(mode, "r")) {
+        fid = H5Fopen(path, H5F_ACC_RDONLY, H5P_DEFAULT);
+        writable = false;
+    } else {
+        set_error("s3h5_open: unknown mode '%s'", mode);
+        return S3H5_EINVAL;
+    }
+    if (fid < 0) { set_error("could not open '%s' (mode %s)", path, mode); return S3H5_ENOENT; }
+    s3h5_file *f = new s3h5_file();
+    f->fid = fid;
+    f->writable = writable;
+    *out = f;
+    return S3H5_OK;
+}
+
+int s3h5_flush(s3h5_file *f, int64_t *n_skipped) {
+    if (!f) { set_error("s3h5_flush: null file"); return S3H5_EINVAL; }
+    std::unique_lock<std::mutex> lk(f->m);
+    f->cv_idle.wait(lk, [f] { return f->queue.empty() && f->busy_data == nullptr; });
+    if (n_skipped) *n_skipped = f->skipped;
+    f->skipped = 0;
+    if (f->async_error) {
+        const int rc = f->async_error;
+        set_error("%s", f->async_message.c_str());
+        f->async_error = 0;
+        return rc;
+    }
+    return S3H5_OK;
+}
+
+int s3h5_wait_buffer(s3h5_file *f, const void *h_base, size_t bytes) {
+    if (!f) { set_error("s3h5_wait_buffer: null file"); return S3H5_EINVAL; }
+    const char *lo = static_cast<const char *>(h_base), *hi = lo + bytes;
+    auto overlaps = [&](const void *p, size_t n) {
+        const char *a = static_cast<const char *>(p);
+        return p != nullptr && a < hi && a + n > lo;
+    };
+    std::unique_lock<std::mutex> lk(f->m);
+    f->cv_idle.wait(lk, [&] {
+        if (overlaps(f->busy_data, f->busy_bytes)) return false;
+        for (const Job &j : f->queue)
+            if (overlaps(j.data, j.bytes)) return false;
+        return true;
+    });
+    return S3H5_OK;
+}
+
+int s3h5_close(s3h5_file *f) {
+    if (!f) return S3H5_OK;
+    int rc = s3h5_flush(f, nullptr);
+    {
+        std::lock_guard<std::mutex> lk(f->m);
+        f->stop = true;
+    }
+    f->cv_work.notify_all();
+    if (f->worker.joinable()) f->worker.join();
+    {
+        std::lock_guard<std::mutex> h(g_hdf5);
+        if (f->fid >= 0 && H5Fclose(f->fid) < 0 && rc == S3H5_OK) { set_error("H5Fclose failed"); rc = S3H5_EIO; }
+    }
+    delete f;
+    return rc;
+}
+
+int s3h5_write(s3h5_file *f, const char *path, int dtype, int ndim, const int64_t *dims, const void *data) {
+    if (!f || !path || ndim < 0 || ndim > S3H5_MAX_DIMS || (ndim > 0 && !dims)) { set_error("s3h5_write: bad arguments"); return S3H5_EINVAL; }
+    if (!f->writable) { set_error("s3h5_write: file opened read-only"); return S3H5_EINVAL; }
+    int rc = s3h5_flush(f, nullptr);                      // keep the order of writes
+    if (rc != S3H5_OK) return rc;
+    hsize_t hd[S3H5_MAX_DIMS] = {0};
+    for (int i = 0; i < ndim; ++i) {
+        if (dims[i] < 0) { set_error("s3h5_write: negative dimension"); return S3H5_EINVAL; }
+        hd[i] = (hsize_t)dims[i];
+    }
+    std::lock_guard<std::mutex> h(g_hdf5);
+    if (f->exists_locked(path)) { set_error("dataset '%s' exists already", path); return S3H5_EEXIST; }
+    return f->write_locked(path, dtype, ndim, hd, data);
+}
+
+int s3h5_write_snapshots_async(s3h5_file *f, const char *group, const char *const *times, int64_t n_snapshots, const char *name,
+                               int dtype, int ndim, const int64_t *dims, const void *h_base, int64_t stride_bytes) {
+    if (!f || !group || !times || !name || n_snapshots < 0 || ndim < 0 || ndim > S3H5_MAX_DIMS || (ndim > 0 && !dims) || !h_base ||
+        mem_type(dtype) < 0) {
+        set_error("s3h5_write_snapshots_async: bad arguments");
+        return S3H5_EINVAL;
+    }
+    if (!f->writable) { set_error("s3h5_write_snapshots_async: file opened read-only"); return S3H5_EINVAL; }
+    static const size_t item[] = {4, 8, 4, 8, 1};
+    size_t bytes = item[dtype];
+    Job proto{};
+    proto.dtype = dtype;
+    proto.ndim = ndim;
+    for (int i = 0; i < ndim; ++i) {
+        if (dims[i] < 0) { set_error("s3h5_write_snapshots_async: negative dimension"); return S3H5_EINVAL; }
+        proto.dims[i] = (hsize_t)dims[i];
+        bytes *= (size_t)dims[i];
+    }
+    proto.bytes = bytes;
+    if (stride_bytes < (int64_t)bytes) { set_error("s3h5_write_snapshots_async: snapshots overlap"); return S3H5_EINVAL; }
+    {
+        std::lock_guard<std::mutex> lk(f->m);
+        for (int64_t i = 0; i < n_snapshots; ++i) {
+            Job j = proto;
+            j.path = std::string(group) + "/" + times[i] + "/" + name;
+            j.data = static_cast<const char *>(h_base) + i * stride_bytes;
+            f->queue.push_back(std::move(j));
+        }
+        if (!f->worker.joinable()) f->worker = std::thread([f] { f->loop(); });
+    }
+    f->cv_work.notify_one();
+    return S3H5_OK;
+}
+
+int s3h5_exists(s3h5_file *f, const char *path) {
+    if (!f || !path) { set_error("s3h5_exists: null argument"); return S3H5_EINVAL; }
+    int rc = s3h5_flush(f, nullptr);
+    if (rc != S3H5_OK) return rc;
+    std::lock_guard<std::mutex> h(g_hdf5);
+    return f->exists_locked(path) ? 1 : 0;
+}
+
+int s3h5_shape(s3h5_file *f, const char *path, int *dtype, int *ndim, int64_t *dims) {
+    if (!f || !path || !ndim || !dims) { set_error("s3h5_shape: null argument"); return S3H5_EINVAL; }
+    int rc = s3h5_flush(f, nullptr);
+    if (rc != S3H5_OK) return rc;
+    std::lock_guard<std::mutex> h(g_hdf5);
+    if (!f->exists_locked(path)) { set_error("no dataset '%s'", path); return S3H5_ENOENT; }
+    hid_t ds = H5Dopen2(f->fid, path, H5P_DEFAULT);
+    if (ds < 0) { set_error("'%s' is not a dataset", path); return S3H5_ENOENT; }
+    hid_t space = H5Dget_space(ds);
+    const int nd = H5Sget_simple_extent_ndims(space);
+    hsize_t hd[S3H5_MAX_DIMS] = {0};
+    if (nd < 0 || nd > S3H5_MAX_DIMS) { H5Sclose(space); H5Dclose(ds); set_error("'%s': unsupported rank", path); return S3H5_EIO; }
+    if (nd > 0) H5Sget_simple_extent_dims(space, hd, nullptr);
+    *ndim = nd;
+    for (int i = 0; i < nd; ++i) dims[i] = (int64_t)hd[i];
+    if (dtype) {
+        hid_t t = H5Dget_type(ds);
+        const H5T_class_t cls = H5Tget_class(t);
+        const size_t sz = H5Tget_size(t);
+        *dtype = -1;
+        if (cls == H5T_FLOAT) *dtype = sz == 4 ? S3H5_F32 : S3H5_F64;
+        else if (cls == H5T_INTEGER) *dtype = sz == 1 ? S3H5_U8 : (sz <= 4 ? S3H5_I32 : S3H5_I64);
+        H5Tclose(t);
+    }
+    H5Sclose(space);
+    H5Dclose(ds);
+    return S3H5_OK;
+}
+
+int s3h5_read(s3h5_file *f, const char *path, int dtype, void *out, int64_t n_elements) {
+    if (!f || !path || (!out && n_elements > 0)) { set_error("s3h5_read: null argument"); return S3H5_EINVAL; }
+    const hid_t mt = mem_type(dtype);
+    if (mt < 0) { set_error("s3h5_read: unknown element type %d", dtype); return S3H5_EINVAL; }
+    int rc = s3h5_flush(f, nullptr);
+    if (rc != S3H5_OK) return rc;
+    std::lock_guard<std::mutex> h(g_hdf5);
+    if (!f->exists_locked(path)) { set_error("no dataset '%s'", path); return S3H5_ENOENT; }
+    hid_t ds = H5Dopen2(f->fid, path, H5P_DEFAULT);
+    if (ds < 0) { set_error("'%s' is not a dataset", path); return S3H5_ENOENT; }
+    hid_t space = H5Dget_space(ds);
+    const hssize_t n = H5Sget_simple_extent_npoints(space);
+    H5Sclose(space);
+    if (n != n_elements) {
+        H5Dclose(ds);
+        set_error("'%s' holds %lld elements, the buffer %lld", path, (long long)n, (long long)n_elements);
+        return S3H5_EINVAL;
+    }
+    rc = S3H5_OK;
+    if (n > 0 && H5Dread(ds, mt, H5S_ALL, H5S_ALL, H5P_DEFAULT, out) < 0) { set_error("could not read '%s'", path); rc = S3H5_EIO; }
+    H5Dclose(ds);
+    return rc;
+}
+
+static herr_t collect_names(hid_t, const char *name, const H5L_info_t *, void *op) {
+    static_cast<std::vector<std::string> *>(op)->push_back(name);
+    return 0;
+}
+
+int s3h5_list(s3h5_file *f, const char *group, char *buf, size_t buf_bytes, size_t *needed, int64_t *n_members) {
+    if (!f || !group) { set_error("s3h5_list: null argument"); return S3H5_EINVAL; }
+    int rc = s3h5_flush(f, nullptr);
+    if (rc != S3H5_OK) return rc;
+    std::lock_guard<std::mutex> h(g_hdf5);
+    const bool root = !strcmp(group, "/") || !strcmp(group, "");
+    if (!root && !f->exists_locked(group)) { set_error("no group '%s'", group); return S3H5_ENOENT; }
+    hid_t g = H5Gopen2(f->fid, root ? "/" : group, H5P_DEFAULT);
+    if (g < 0) { set_error("'%s' is not a group", group); return S3H5_ENOENT; }
+    std::vector<std::string> names;
+    hsize_t idx = 0;
+    const herr_t e = H5Literate(g, H5_INDEX_NAME, H5_ITER_INC, &idx, collect_names, &names);
+    H5Gclose(g);
+    if (e < 0) { set_error("could not list '%s'", group); return S3H5_EIO; }
+    size_t need = 1;
+    for (const std::string &s : names) need += s.size() + 1;
+    if (needed) *needed = need;
+    if (n_members) *n_members = (int64_t)names.size();
+    if (buf && buf_bytes >= need) {
+        char *p = buf;
+        for (const std::string &s : names) {
+            memcpy(p, s.data(), s.size());
+            p += s.size();
+            *p++ = '\n';
+        }
+        *p = 0;
+    }
+    return S3H5_OK;
+}
+
+}  // extern "C"

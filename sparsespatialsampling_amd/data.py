@@ -1,127 +1,98 @@
 """
-HDF5 / XDMF sink and loader of the S^3 results -- API mirror of the reference's ``sparseSpatialSampling/data.py``
-(``Dataloader`` :22-300, ``Datawriter`` :303-501, ``XDMFWriter`` :504-777) with the same on-disk layout:
+HDF5 / XDMF sink and loader of the S^3 results -- the classes and signatures of the reference's
+``sparseSpatialSampling/data.py`` (``Dataloader`` :22-300, ``Datawriter`` :303-501, ``XDMFWriter`` :504-777) on the
+package's own HDF5 layer (``h5io``: libs3h5.so on the HDF5 C library, h5py as a fallback).  On-disk layout and XDMF2
+text are the reference's, so files written by either implementation load in the other and in ParaView:
 
     grid/{faces, vertices, centers}
     constant/{levels, metric, size_initial_cell, ...}
     data/<write time>/<field>_{center, vertices}
 
-and the same XDMF2 text (temporal collection, or a single uniform grid when there is no ``data`` group), so files written
-by either implementation load in the other and in ParaView.  This is disk I/O: it stays on the
-host and needs ``h5py``, which is imported lazily so that the rest of the package works without it.
+Organisation (this file's own): one ``_Placement`` rule table says where a ``write_data`` call lands; the XDMF writer
+works from a shape inventory of the file (no array is loaded to describe it).  Where the reference ends the process
+(``exit()``: unknown group, missing file, missing grid) this module raises ``ValueError`` / ``FileNotFoundError`` /
+``KeyError`` instead -- a caller's process is not ours to end.
 """
 import logging
 from os.path import isfile, join
 from typing import List, Union
 
+import numpy as np
 import torch as pt
 
 from .const import CENTERS, CONST, DATA, FACES, GRID, VERTICES
+from .h5io import open_h5
 
 logger = logging.getLogger(__name__)
 
 
-def _h5file(*args, **kwargs):
-    try:
-        from h5py import File
-    except ModuleNotFoundError as e:        # pragma: no cover - depends on the environment
-        raise ModuleNotFoundError("h5py is required for reading / writing S^3 HDF5 files (pip install h5py)") from e
-    return File(*args, **kwargs)
-
-
-def _np(data):
-    return data.detach().cpu().numpy() if isinstance(data, pt.Tensor) else data
-
-
+# ======================================================================================================================
+# loader
+# ======================================================================================================================
 class Dataloader:
+    """lazy reader of an S^3 HDF5 file.  Names follow the reference: ``vertices`` are the cell CENTRES, ``nodes`` the cell
+    corners, ``weights`` the cell areas / volumes."""
+
+    # attribute -> (dataset, squeeze)
+    _ARRAYS = {"vertices": (f"{GRID}/{CENTERS}", False), "nodes": (f"{GRID}/{VERTICES}", False),
+               "faces": (f"{GRID}/{FACES}", False), "levels": (f"{CONST}/levels", True), "metric": (f"{CONST}/metric", True)}
+
     def __init__(self, load_path: str, file_name: str, dtype: pt.dtype = pt.float32):
-        self._load_path = load_path
-        self._file_name = file_name
-        self._dtype = dtype
-        self._read_header(strict=False)
-        self._clear_cache()
+        self._load_path, self._file_name, self._dtype = load_path, file_name, dtype
+        self._cache = {}
+        self._scan(tolerant=True)
 
-    # -- helpers -------------------------------------------------------------------------------------------------
-    def _path(self) -> str:
-        return join(self._load_path, self._file_name)
+    def _open(self):
+        return open_h5(join(self._load_path, self._file_name), "r")
 
-    def _read(self, key: str):
-        with _h5file(self._path(), "r") as f:
-            return f.get(key)[()]
-
-    def _read_header(self, strict: bool) -> None:
-        with _h5file(self._path(), "r") as f:
-            shape = f.get(f"{GRID}/{CENTERS}")[()].shape
-            self._n_cells, self._n_dimensions = shape[0], shape[1]
-            try:
-                self._size_initial_cell = f.get(f"{CONST}/size_initial_cell")[()]
-            except TypeError:
-                if strict:
-                    raise
+    def _scan(self, tolerant: bool) -> None:
+        """grid size and initial cell width (a file without the width only fails later, as in the reference)"""
+        self._cache = {}
+        with self._open() as f:
+            self._n_cells, self._n_dimensions = f.shape(f"{GRID}/{CENTERS}")
+            if f.exists(f"{CONST}/size_initial_cell"):
+                self._size_initial_cell = f.read(f"{CONST}/size_initial_cell")[()]
+            elif tolerant:
                 logger.warning("Could not load initial cell size.")
+            else:
+                raise KeyError(f"{CONST}/size_initial_cell")
 
-    def _clear_cache(self) -> None:
-        self._write_times = None
-        self._weights = None            # cell areas (2-D) / volumes (3-D)
-        self._levels = None
-        self._metric = None
-        self._field_names = None
-        self._vertices = None
-        self._faces = None
-        self._nodes = None
+    def _array(self, name: str) -> pt.Tensor:
+        if name not in self._cache:
+            key, squeeze = self._ARRAYS[name]
+            with self._open() as f:
+                t = pt.from_numpy(f.read(key))
+            self._cache[name] = t.squeeze() if squeeze else t
+        return self._cache[name]
 
-    # -- lazily loaded properties (names as in the reference: ``vertices`` are the cell CENTRES, ``nodes`` the corners)
+    vertices = property(lambda self: self._array("vertices"))
+    nodes = property(lambda self: self._array("nodes"))
+    faces = property(lambda self: self._array("faces"))
+    levels = property(lambda self: self._array("levels"))
+    metric = property(lambda self: self._array("metric"))
+
     @property
     def write_times(self) -> List[str]:
-        if self._write_times is None:
-            with _h5file(self._path(), "r") as f:
-                if DATA in f.keys():
-                    self._write_times = list(f.get(DATA).keys())
-        return self._write_times
-
-    @property
-    def weights(self) -> pt.Tensor:
-        if self._weights is None:
-            self._weights = (pow(self._size_initial_cell / pow(2, self.levels), self._n_dimensions)).squeeze()
-        return self._weights
-
-    @property
-    def vertices(self) -> pt.Tensor:
-        if self._vertices is None:
-            self._vertices = pt.from_numpy(self._read(f"{GRID}/{CENTERS}"))
-        return self._vertices
-
-    @property
-    def nodes(self) -> pt.Tensor:
-        if self._nodes is None:
-            self._nodes = pt.from_numpy(self._read(f"{GRID}/{VERTICES}"))
-        return self._nodes
-
-    @property
-    def faces(self) -> pt.Tensor:
-        if self._faces is None:
-            self._faces = pt.from_numpy(self._read(f"{GRID}/{FACES}"))
-        return self._faces
+        if "write_times" not in self._cache:
+            with self._open() as f:
+                self._cache["write_times"] = f.keys(DATA) if DATA in f.keys() else None
+        return self._cache["write_times"]
 
     @property
     def field_names(self) -> dict:
-        if self._field_names is None:
-            with _h5file(self._path(), "r") as f:
-                self._field_names = {t: [n.split("_")[0] for n in f[f"{DATA}/{t}"].keys() if n.endswith("center")]
-                                     for t in f[DATA].keys()}
-        return self._field_names
+        """{write time: [fields with a ``_center`` dataset]}"""
+        if "field_names" not in self._cache:
+            with self._open() as f:
+                self._cache["field_names"] = {t: [n.split("_")[0] for n in f.keys(f"{DATA}/{t}") if n.endswith("center")]
+                                              for t in f.keys(DATA)}
+        return self._cache["field_names"]
 
     @property
-    def levels(self) -> pt.Tensor:
-        if self._levels is None:
-            self._levels = pt.from_numpy(self._read(f"{CONST}/levels")).squeeze()
-        return self._levels
-
-    @property
-    def metric(self) -> pt.Tensor:
-        if self._metric is None:
-            self._metric = pt.from_numpy(self._read(f"{CONST}/metric")).squeeze()
-        return self._metric
+    def weights(self) -> pt.Tensor:
+        """cell areas (2-D) / volumes (3-D): (size_initial_cell / 2^level)^d  (reference data.py:240-247)"""
+        if "weights" not in self._cache:
+            self._cache["weights"] = (pow(self._size_initial_cell / pow(2, self.levels), self._n_dimensions)).squeeze()
+        return self._cache["weights"]
 
     @property
     def load_path(self) -> str:
@@ -130,8 +101,7 @@ class Dataloader:
     @load_path.setter
     def load_path(self, value: str) -> None:
         self._load_path = value
-        self._read_header(strict=True)
-        self._clear_cache()
+        self._scan(tolerant=False)
 
     @property
     def file_name(self) -> str:
@@ -140,89 +110,100 @@ class Dataloader:
     @file_name.setter
     def file_name(self, value: str) -> None:
         self._file_name = value
-        self._read_header(strict=True)
-        self._clear_cache()
+        self._scan(tolerant=False)
 
     def load_snapshot(self, field_name: Union[List[str], str],
                       write_times: Union[str, List[str]] = None) -> Union[List[pt.Tensor], pt.Tensor]:
-        """data matrix ``[N_cells, (N_dims,) N_times]`` of one field, or a list of them for several fields"""
+        """data matrix ``[N_cells, (N_dims,) N_times]`` of one field (cell-centred values), or a list of them"""
         times = self.write_times if write_times is None else write_times
-        times = [times] if isinstance(times, str) else times
-        names = [field_name] if isinstance(field_name, str) else field_name
-        matrices = []
-        with _h5file(self._path(), "r") as f:
-            for name in names:
-                first = f.get(f"{DATA}/{times[0]}/{name}_center")[()]
-                dm = pt.zeros(tuple(first.shape) + (len(times),), dtype=self._dtype)
-                for i, t in enumerate(times):
-                    dm[..., i] = pt.from_numpy(f.get(f"{DATA}/{t}/{name}_center")[()])
-                matrices.append(dm)
-        return matrices[0] if len(matrices) == 1 else matrices
+        times = [times] if isinstance(times, str) else list(times)
+        fields = [field_name] if isinstance(field_name, str) else list(field_name)
+        out = []
+        with self._open() as f:
+            for name in fields:
+                per_time = [pt.from_numpy(f.read(f"{DATA}/{t}/{name}_center")) for t in times]
+                out.append(pt.stack(per_time, dim=-1).to(self._dtype))
+        return out[0] if len(out) == 1 else out
+
+
+# ======================================================================================================================
+# writer
+# ======================================================================================================================
+class _Placement:
+    """where a ``write_data`` call lands: HDF5 prefix and whether the dataset name gets a location suffix"""
+
+    def __init__(self, prefix_of, suffixed, duplicate_message):
+        self.prefix_of, self.suffixed, self.duplicate_message = prefix_of, suffixed, duplicate_message
+
+
+_PLACEMENTS = {
+    GRID: _Placement(lambda t: GRID, False, None),                       # the grid is written once; a duplicate is an error
+    CONST: _Placement(lambda t: CONST, False, "Field {name} already exists in time step {t}. Skipping field {name}."),
+    DATA: _Placement(lambda t: f"{DATA}/{t}", True, "Field {name} already exists in the HDF file. Skipping field {name}."),
+}
 
 
 class Datawriter:
     def __init__(self, file_path: str, file_name: str, mode: str = "w", mixed: bool = False):
-        self._file_name = file_name
-        self._mode = mode
-        self._mixed = mixed
-        self._file_path = file_path
-        self._file = _h5file(join(self._file_path, self._file_name), self._mode)
-        keys = self._file.keys()
-        self._data = self._file[DATA] if DATA in keys else None
-        self._const = self._file[CONST] if CONST in keys else None
-        self._grid = self._file[GRID] if GRID in keys else None
+        self._file_path, self._file_name, self._mode, self._mixed = file_path, file_name, mode, mixed
+        self._file = open_h5(join(file_path, file_name), mode)
         self._n_cells = None
 
     def close(self) -> None:
-        self._file.close()
+        if self._file is not None:
+            skipped = self._file.flush()
+            if skipped:
+                logger.warning(f"{skipped} dataset(s) of the last batches existed already in {self._file_name} and were skipped.")
+            self._file.close()
+            self._file = None
 
     def write_grid(self, loader: Dataloader) -> None:
+        """copy the grid of an existing S^3 file (centres, corner nodes, faces)"""
         self._n_cells = loader.vertices.shape[0]
-        self.write_data("centers", group="grid", data=loader.vertices)
-        self.write_data("vertices", group="grid", data=loader.nodes)
-        self.write_data("faces", group="grid", data=loader.faces)
+        for key, values in ((CENTERS, loader.vertices), (VERTICES, loader.nodes), (FACES, loader.faces)):
+            self.write_data(key, group=GRID, data=values)
 
-    def write_data(self, name: str, data: any, group: str = "constant",
-                   time_step: Union[int, float, str] = None) -> None:
-        """one dataset in ``grid/``, ``constant/`` or ``data/<time_step>/`` (reference data.py:361-430)"""
-        data = _np(data)
+    def _resolve(self, name: str, data, group: str, time_step):
+        """(HDF5 path, placement) of one ``write_data`` call -- reference data.py:361-430"""
+        if time_step is not None and group != DATA:
+            group = DATA                                      # a time step always means temporal data
+        if group not in _PLACEMENTS:
+            raise ValueError(f"Unknown group type {group!r}, available types are '{DATA}', '{CONST}' and '{GRID}'.")
+        place = _PLACEMENTS[group]
         if group == DATA and time_step is None:
             logger.warning(f"No time step for group 'data' provided. Writing data to the zeroth time step '{DATA}/0'.")
             time_step = "0"
+        if place.suffixed and self._n_cells is not None and not name.endswith(("center", "vertices")):
+            # with a known grid (write_grid was used) plain names get the location suffix the loader expects
+            name = f"{name}_center" if np.shape(data)[0] == self._n_cells else f"{name}_vertices"
+        return f"{place.prefix_of(time_step)}/{name}", place, name, time_step
 
-        if time_step is not None or group == DATA:
-            # with a known grid (write_grid was used) un-suffixed names get the location suffix the loader expects
-            if self._n_cells is not None and not (name.endswith("center") or name.endswith("vertices")):
-                name = f"{name}_center" if data.shape[0] == self._n_cells else f"{name}_vertices"
-            if self._data is None or str(time_step) not in self._file[DATA].keys():
-                self._data = self._file.create_group(f"{DATA}/{time_step}")
-            else:
-                self._data = self._file[f"{DATA}/{time_step}"]
-            try:
-                self._data.create_dataset(name, data=data)
-            except ValueError:
-                logger.warning(f"Field {name} already exists in the HDF file. Skipping field {name}.")
-        elif group == CONST:
-            self._const = self._file.create_group(CONST) if self._const is None else self._file[CONST]
-            try:
-                self._const.create_dataset(name, data=data)
-            except ValueError:
-                logger.warning(f"Field {name} already exists in time step {time_step}. Skipping field {name}.")
-        elif group == GRID:
-            self._grid = self._file.create_group(GRID) if self._grid is None else self._file[GRID]
-            self._grid.create_dataset(name, data=data)
-        else:
-            logger.critical(f"Unknown group type, available types are '{DATA}', '{CONST}' and '{GRID}'.")
-            exit()
+    def write_data(self, name: str, data: any, group: str = "constant", time_step: Union[int, float, str] = None) -> None:
+        """one dataset in ``grid/``, ``constant/`` or ``data/<time_step>/``"""
+        path, place, name, time_step = self._resolve(name, data, group, time_step)
+        if not self._file.write(path, data):
+            if place.duplicate_message is None:
+                raise ValueError(f"Unable to create dataset {path!r}: it exists already.")
+            logger.warning(place.duplicate_message.format(name=name, t=time_step))
+
+    def write_snapshots(self, name: str, times: list, host_snapshot_major) -> None:
+        """``data/<times[i]>/<name>`` = ``host_snapshot_major[i]`` for a whole batch, queued and written in the background
+        (this build's addition: ExportData hands over its snapshot-major download buffer)"""
+        self._file.write_snapshots([str(t) for t in times], name, host_snapshot_major, group=DATA)
+
+    def wait_buffer(self, host) -> None:
+        """returns once no queued write reads from ``host`` any more (a closed file has nothing queued)"""
+        if self._file is not None:
+            self._file.wait_buffer(host)
 
     def write_xdmf_file(self) -> None:
-        if not isfile(join(self._file_path, self._file_name)):
-            logger.error(f"Could not find {join(self._file_path, self._file_name)}. Make sure the file exists and the "
-                         f"provided path is correct.")
-            exit(0)
+        if self._file is not None:
+            self.close()
+        full = join(self._file_path, self._file_name)
+        if not isfile(full):
+            raise FileNotFoundError(f"Could not find {full}. Make sure the file exists and the provided path is correct.")
         logger.info(f"Writing XDMF file for file {self._file_name}")
         XDMFWriter(self._file_path, self._file_name, mixed=self._mixed).write_xdmf()
-        self.close()
 
     @property
     def mode(self) -> str:
@@ -230,12 +211,19 @@ class Datawriter:
 
     @mode.setter
     def mode(self, value) -> None:
+        """re-open the file in another mode (the export path switches a finished file to "a" for the next field)"""
+        if self._file is not None:
+            self.close()
         self._mode = value
-        self._file = _h5file(join(self._file_path, self._file_name), self._mode)
+        self._file = open_h5(join(self._file_path, self._file_name), value)
 
     @property
     def file_name(self) -> str:
         return self._file_name
+
+    @property
+    def is_open(self) -> bool:
+        return self._file is not None
 
     @property
     def n_cells(self) -> Union[int, None]:
@@ -246,109 +234,93 @@ class Datawriter:
         self._n_cells = value
 
 
+# ======================================================================================================================
+# XDMF
+# ======================================================================================================================
 class XDMFWriter:
-    """XDMF2 description of an S^3 HDF5 file (text identical to the reference's writer, data.py:504-777)"""
+    """XDMF2 description of an S^3 HDF5 file: a temporal collection, or one uniform grid when there is no ``data`` group.
+    The text is the reference writer's (data.py:566-777); it is assembled here from a shape inventory of the file."""
 
-    _HEADER = '<?xml version="1.0"?>\n<!DOCTYPE Xdmf SYSTEM "Xdmf.dtd" []>\n<Xdmf Version="2.0">\n'
+    _OPEN = '<?xml version="1.0"?>\n<!DOCTYPE Xdmf SYSTEM "Xdmf.dtd" []>\n<Xdmf Version="2.0">\n'
 
     def __init__(self, file_path: str, file_name: str, grid_name: str = "grid_s_cube", mixed: bool = False):
-        self._file_path = file_path
-        self._grid_name = grid_name
-        self._mixed = mixed
-        self._hdf_file_name = file_name
-        self._file = _h5file(join(self._file_path, self._hdf_file_name), "r")
-        self._xdmf_file_name = f"{self._hdf_file_name.split('.h5')[0]}.xdmf"
-        self._check_grid()
-        centers = self._file.get(f"{GRID}/{CENTERS}")[()]
-        self._n_dimensions, self._n_cells = centers.shape[-1], centers.shape[0]
-        self._n_faces = self._file.get(f"{GRID}/{FACES}")[()].shape[0]
-        self._n_vertices = self._file.get(f"{GRID}/{VERTICES}")[()].shape[0]
+        self._file_path, self._hdf_file_name, self._grid_name, self._mixed = file_path, file_name, grid_name, mixed
+        self._xdmf_file_name = f"{file_name.split('.h5')[0]}.xdmf"
+        self._inventory = self._take_inventory()
+        grid = self._inventory[GRID]
+        self._n_cells, self._n_dimensions = grid[CENTERS][0], grid[CENTERS][-1]
+        self._n_faces, self._n_vertices = grid[FACES][0], grid[VERTICES][0]
         self._grid_type = "Mixed" if mixed else ("Quadrilateral" if self._n_dimensions == 2 else "Hexahedron")
         self._dims = "XY" if self._n_dimensions == 2 else "XYZ"
-        self._keys_const_attributes = []
 
-    # -- building blocks -------------------------------------------------------------------------------------------
-    def _topology_and_geometry(self) -> str:
+    def _take_inventory(self) -> dict:
+        """{group: {dataset: shape}} with ``data`` as {time: {dataset: shape}}; raises when the grid is incomplete"""
+        inv = {}
+        with open_h5(join(self._file_path, self._hdf_file_name), "r") as f:
+            top = f.keys()
+            if GRID not in top:
+                raise KeyError("Found no grid in the provided HDF5 file. Unable to create XDMF file without a grid.")
+            have = f.keys(GRID)
+            for key, what in ((FACES, "faces"), (CENTERS, "centers"), (VERTICES, "vertices")):
+                if key not in have:
+                    raise KeyError(f"Unable to find cell {what} in group {GRID}. Make sure the key to the cell {what} is present "
+                                   f"and named {key}.")
+            inv[GRID] = {k: f.shape(f"{GRID}/{k}") for k in have}
+            inv[CONST] = {k: f.shape(f"{CONST}/{k}") for k in f.keys(CONST)} if CONST in top else None
+            inv[DATA] = ({t: {k: f.shape(f"{DATA}/{t}/{k}") for k in f.keys(f"{DATA}/{t}")} for t in f.keys(DATA)}
+                         if DATA in top else None)
+        return inv
+
+    # -- text fragments --------------------------------------------------------------------------------------------
+    def _mesh(self) -> str:
         face_dims = f"{self._n_faces}" if self._mixed else f"{self._n_faces} {pow(2, self._n_dimensions)}"
+        h5 = self._hdf_file_name
         return (f'<Topology TopologyType="{self._grid_type}" NumberOfElements="{self._n_faces}">\n'
-                f'<DataItem Format="HDF" DataType="Int" Dimensions="{face_dims}">\n'
-                f"{self._hdf_file_name}:/{GRID}/{FACES}\n"
-                f'</DataItem>\n</Topology>\n<Geometry GeometryType="{self._dims}">\n'
-                f'<DataItem Rank="2" Dimensions="{self._n_vertices} {self._n_dimensions}" '
-                f'NumberType="Float" Precision="8" Format="HDF">\n'
-                f"{self._hdf_file_name}:/{GRID}/{VERTICES}\n</DataItem>\n</Geometry>\n")
+                f'<DataItem Format="HDF" DataType="Int" Dimensions="{face_dims}">\n{h5}:/{GRID}/{FACES}\n</DataItem>\n'
+                f'</Topology>\n<Geometry GeometryType="{self._dims}">\n'
+                f'<DataItem Rank="2" Dimensions="{self._n_vertices} {self._n_dimensions}" NumberType="Float" Precision="8" '
+                f'Format="HDF">\n{h5}:/{GRID}/{VERTICES}\n</DataItem>\n</Geometry>\n')
 
-    def _attribute(self, name: str, h5_key: str) -> str:
-        """cell- or node-centred attribute, or '' (with a warning) when the size matches neither"""
-        shape = self._file.get(h5_key)[()].shape
-        second = 1 if len(shape) == 1 else shape[1]
-        if shape[0] == self._n_cells:
-            center, n = "Cell", self._n_cells
-        elif shape[0] == self._n_vertices:
-            center, n = "Node", self._n_vertices
-        else:
-            logger.warning(f"Field in '{h5_key}' with a size of {shape} doesn't match the number of cells with "
-                           f"N_cells = {self._n_cells} or the number of vertices with N_vertices = "
-                           f"{self._n_vertices}. Skipping this field.")
+    def _field(self, label: str, h5_key: str, shape: tuple) -> str:
+        """cell- or node-centred attribute; '' (with a warning) when the leading size matches neither"""
+        location = {self._n_cells: "Cell", self._n_vertices: "Node"}.get(shape[0] if shape else None)
+        if location is None:
+            logger.warning(f"Field in '{h5_key}' with a size of {shape} doesn't match the number of cells with N_cells = "
+                           f"{self._n_cells} or the number of vertices with N_vertices = {self._n_vertices}. Skipping this field.")
             return ""
-        return (f'<Attribute Name="{name}" AttributeType="Vector" Center="{center}">\n<DataItem '
-                f'NumberType="Float" Precision="8" Format="HDF" Dimensions="{n} {second}">\n'
-                f"{self._hdf_file_name}:/{h5_key}\n</DataItem>\n</Attribute>\n")
+        width = 1 if len(shape) == 1 else shape[1]
+        return (f'<Attribute Name="{label}" AttributeType="Vector" Center="{location}">\n<DataItem NumberType="Float" '
+                f'Precision="8" Format="HDF" Dimensions="{shape[0]} {width}">\n{self._hdf_file_name}:/{h5_key}\n</DataItem>\n'
+                f'</Attribute>\n')
 
-    def _write_attributes(self) -> str:
-        return "".join(self._attribute(k, f"{CONST}/{k}") for k in self._keys_const_attributes)
-
-    # -- writers -------------------------------------------------------------------------------------------------
-    def write_xdmf(self) -> None:
-        self._keys_const_attributes = self._get_const_keys()
-        if self._check_data():
-            self._write_temporal_grid()
-        else:
-            self._write_const_grid()
-
-    def _write_temporal_grid(self) -> None:
-        with open(join(self._file_path, self._xdmf_file_name), "w") as f_out:
-            f_out.write(self._HEADER)
-            f_out.write(f'<Domain>\n<Grid Name="{self._grid_name}" GridType="Collection" CollectionType="temporal">\n')
-            for i, t in enumerate(sorted(self._file.get(DATA).keys(), key=lambda x: float(x))):
-                f_out.write(f'<Grid Name="{self._grid_name} {t}" GridType="Uniform">\n<Time Value="{t}"/>\n')
-                f_out.write(self._topology_and_geometry())
-                if i == 0:                          # constant fields go into the first time step
-                    f_out.write(self._write_attributes())
-                for k in self._file[f"{DATA}/{t}"].keys():
-                    parts = k.split("_")           # <field name>_<center|vertices>
-                    f_out.write(self._attribute("_".join(parts[:-1]) if len(parts) > 1 else k, f"{DATA}/{t}/{k}"))
-                f_out.write('</Grid>\n')
-            f_out.write('</Grid>\n</Domain>\n</Xdmf>')
-
-    def _write_const_grid(self) -> None:
-        with open(join(self._file_path, self._xdmf_file_name), "w") as f_out:
-            f_out.write(self._HEADER)
-            f_out.write(f'<Domain>\n<Grid Name="{self._grid_name}" GridType="Uniform">\n')
-            f_out.write(self._topology_and_geometry())
-            f_out.write(self._write_attributes())
-            f_out.write("</Grid>\n</Domain>\n</Xdmf>")
-
-    def _get_const_keys(self) -> list:
-        if CONST not in self._file.keys():
+    def _constant_fields(self) -> str:
+        const = self._inventory[CONST]
+        if const is None:
             logger.info("Couldn't find any constant fields to write.")
-            return []
-        keys = []
-        for k in self._file[CONST].keys():
-            shape = self._file.get(f"{CONST}/{k}")[()].shape
-            if shape and shape[0] in (self._n_cells, self._n_vertices):
-                keys.append(k)
-        return keys
+            return ""
+        return "".join(self._field(k, f"{CONST}/{k}", shape) for k, shape in const.items()
+                       if shape and shape[0] in (self._n_cells, self._n_vertices))
 
-    def _check_data(self) -> bool:
-        return DATA in self._file.keys()
+    # -- documents -------------------------------------------------------------------------------------------------
+    def write_xdmf(self) -> None:
+        body = self._temporal_collection() if self._inventory[DATA] is not None else self._single_grid()
+        with open(join(self._file_path, self._xdmf_file_name), "w") as out:
+            out.write(self._OPEN + body)
 
-    def _check_grid(self) -> None:
-        if GRID not in self._file.keys():
-            logger.error("Found no grid in the provided HDF5 file. Unable to create XDMF file without a grid.")
-            exit(0)
-        for key, what in ((FACES, "faces"), (CENTERS, "centers"), (VERTICES, "vertices")):
-            if key not in self._file[GRID].keys():
-                logger.error(f"Unable to find cell {what} in group {GRID}. Make sure the key to the cell {what} is "
-                             f"present and named {key}.")
-                exit(0)
+    def _single_grid(self) -> str:
+        return (f'<Domain>\n<Grid Name="{self._grid_name}" GridType="Uniform">\n' + self._mesh() + self._constant_fields()
+                + "</Grid>\n</Domain>\n</Xdmf>")
+
+    def _temporal_collection(self) -> str:
+        parts = [f'<Domain>\n<Grid Name="{self._grid_name}" GridType="Collection" CollectionType="temporal">\n']
+        data = self._inventory[DATA]
+        for i, t in enumerate(sorted(data, key=float)):
+            parts.append(f'<Grid Name="{self._grid_name} {t}" GridType="Uniform">\n<Time Value="{t}"/>\n' + self._mesh())
+            if i == 0:                                        # constant fields go with the first time step
+                parts.append(self._constant_fields())
+            for k, shape in data[t].items():
+                stem = k.split("_")                           # <field>_<center|vertices>
+                parts.append(self._field("_".join(stem[:-1]) if len(stem) > 1 else k, f"{DATA}/{t}/{k}", shape))
+            parts.append("</Grid>\n")
+        parts.append("</Grid>\n</Domain>\n</Xdmf>")
+        return "".join(parts)

@@ -26,8 +26,23 @@ def test_header_symbols_exported_and_bound():
     assert lib.s3_abi_version() == 1
 
 
+def test_h5_sink_symbols_exported_and_bound():
+    """libs3h5.so (HDF5 sink) exports what include/s3h5.h declares and h5io binds all of it"""
+    from sparsespatialsampling_amd import h5io
+    lib = h5io.native_lib()
+    if lib is None:
+        pytest.skip("HDF5 C library not available on this machine: libs3h5.so not built")
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "s3h5.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(s3h5_[a-z0-9_]+)\s*\(", text)))
+    assert len(names) >= 12 and set(names) == set(h5io.H5_SIGNATURES)
+    for n in names:
+        assert hasattr(lib, n), f"libs3h5.so does not export {n}"
+    major = ctypes.c_uint(0)
+    assert lib.s3h5_version(ctypes.byref(major), ctypes.byref(ctypes.c_uint(0)), ctypes.byref(ctypes.c_uint(0))) == 0 and major.value == 1
+
+
 def test_no_torch_types_in_abi():
-    text = open(os.path.join(ROOT, "include", "s3hip.h")).read()
+    text = open(os.path.join(ROOT, "include", "s3hip.h")).read() + open(os.path.join(ROOT, "include", "s3h5.h")).read()
     code = re.sub(r"/\*.*?\*/", "", text, flags=re.S)                # declarations only, comments stripped
     assert "torch" not in code.lower() and "at::" not in code and "std::" not in code and "Tensor" not in code
 

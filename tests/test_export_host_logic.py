@@ -1,7 +1,10 @@
 """
-Host logic of ExportData (batching state machine, HDF5 layout, XDMF text) on CPU.  The GPU entry points are replaced by
-oracle-backed stand-ins (test-only monkeypatch) and h5py by tests/fake_h5py.py; tests/test_gpu_refine.py runs the same
-class with the real kernels.
+Host logic of ExportData (batching state machine, HDF5 layout, XDMF text) on CPU, writing REAL HDF5 files through the
+package's native sink (libs3h5.so on the HDF5 C library; h5py if that is what is installed).  The GPU entry points are
+replaced by oracle-backed stand-ins (test-only monkeypatch); tests/test_gpu_refine.py runs the same class with the real
+kernels.  ``test_reference_fixture_file`` reads the reference's own test file (tests/golden/s_cube_test_dataset.h5, a data
+file of the reference's tests) with this package's loader and checks what the reference's
+tests/test_s_cube_dataloader.py:40-57 checks.
 """
 import os
 import types
@@ -11,7 +14,25 @@ import pytest
 import torch as pt
 
 from oracle import s3_oracle as orc
-from tests import fake_h5py
+from sparsespatialsampling_amd import h5io
+
+pytestmark = pytest.mark.skipif(h5io.native_lib() is None and __import__("importlib").util.find_spec("h5py") is None,
+                                reason="neither libs3h5.so nor h5py available")
+
+
+def dump(path):
+    """{dataset path: array} of a whole HDF5 file"""
+    out = {}
+    with h5io.open_h5(path, "r") as f:
+        def walk(group):
+            for k in f.keys(group):
+                p = k if group == "/" else f"{group}/{k}"
+                try:
+                    out[p] = f.read(p)
+                except (FileNotFoundError, h5io.H5Error):
+                    walk(p)
+        walk("/")
+    return out
 
 
 class _CpuKnn:
@@ -65,12 +86,9 @@ def _cpu_ops():
 
 @pytest.fixture
 def export_mod(monkeypatch):
-    fake_h5py.install()
     import sparsespatialsampling_amd.export as export
     monkeypatch.setattr(export, "hipops", _cpu_ops())
     yield export
-    import sys
-    sys.modules.pop("h5py", None)
 
 
 def _scube(tmp_path, d=2, nc=40):
@@ -99,7 +117,8 @@ def test_export_batches_layout_and_xdmf(export_mod, tmp_path):
     assert ex._snapshot_counter == 0                       # finished -> state reset (reference export.py:302-319)
     ex.export(pt.from_numpy(coords), pt.from_numpy(u), "U")
 
-    h5 = fake_h5py.dump(os.path.join(str(tmp_path), "case.h5"))
+    h5 = dump(os.path.join(str(tmp_path), "case.h5"))
+    assert h5["grid/faces"].dtype == np.int32 and h5["constant/levels"].shape == (40, 1) and h5["constant/size_initial_cell"].shape == ()
     idx, dist = orc.knn(coords, s.centers.numpy(), 8)
     w = orc.idw_weights(dist)
     assert set(k for k in h5 if k.startswith("grid/")) == {"grid/faces", "grid/vertices", "grid/centers"}
@@ -153,7 +172,72 @@ def test_dataloader_roundtrip(export_mod, tmp_path):
     wr.write_data("p", group="data", time_step="0.1", data=rng.random(7))          # duplicate -> warning, no crash
     wr.write_xdmf_file()
     ld = Dataloader(str(tmp_path), "g.h5")
-    assert ld.write_times == ["0.1", "0.2"] and ld.field_names["0.1"] == ["p", "U"]
+    assert ld.write_times == ["0.1", "0.2"] and ld.field_names["0.1"] == ["U", "p"]      # HDF5 lists members in name order
     assert ld.load_snapshot("p").shape == (7, 2) and ld.load_snapshot("U").shape == (7, 3, 2)
     assert pt.allclose(ld.weights, (2.0 / 2.0 ** ld.levels.double()) ** 3)
     assert 'TopologyType="Hexahedron"' in open(os.path.join(str(tmp_path), "g.xdmf")).read()
+
+
+def test_reference_fixture_file():
+    """the reference's own test file through this package's loader: the expectations of the reference's
+    tests/test_s_cube_dataloader.py:40-57 (209 cells, 247 nodes, 2-D, one write time with the field p)"""
+    from sparsespatialsampling_amd.data import Dataloader, XDMFWriter
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    ld = Dataloader(here, "s_cube_test_dataset.h5")
+    assert len(ld.write_times) == 1 and ld.write_times == ["0.4"] and ld.field_names == {"0.4": ["p"]}
+    assert ld.vertices.shape == (209, 2) and ld.weights.shape == ld.levels.shape and ld.faces.shape == (209, 4)
+    assert ld.nodes.shape == (247, 2) and ld.load_snapshot("p", "0.4").shape == (209, 1)
+    assert ld.load_snapshot("p", "0.4").dtype == pt.float32 and ld.metric.shape == (209,)
+    # cells tile their nodes: centre = mean of the four corner nodes of its face
+    corners = ld.nodes[ld.faces.long()]
+    assert pt.allclose(corners.mean(1), ld.vertices, atol=1e-12)
+    # the areas follow from the levels and the initial cell size
+    edge = corners.max(1).values - corners.min(1).values
+    assert pt.allclose(edge.prod(1), ld.weights.to(edge.dtype), rtol=1e-6)
+
+
+def test_reference_fixture_roundtrip(tmp_path):
+    """copy the reference's fixture through Dataloader -> Datawriter (write_grid + constants + data) and read it back:
+    same arrays, and an XDMF file that names every dataset"""
+    from sparsespatialsampling_amd.data import Dataloader, Datawriter
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    src = Dataloader(here, "s_cube_test_dataset.h5", dtype=pt.float64)
+    wr = Datawriter(str(tmp_path), "copy.h5")
+    wr.write_grid(src)
+    wr.write_data("levels", group="constant", data=src.levels.unsqueeze(-1))
+    wr.write_data("metric", group="constant", data=src.metric)
+    wr.write_data("size_initial_cell", group="constant", data=float(src._size_initial_cell))
+    wr.write_data("p", group="data", time_step="0.4", data=src.load_snapshot("p", "0.4").squeeze(-1))   # -> p_center
+    with pytest.raises(ValueError):
+        wr.write_data("x", group="nonsense", data=np.zeros(3))
+    wr.write_xdmf_file()
+    a, b = dump(os.path.join(here, "s_cube_test_dataset.h5")), dump(os.path.join(str(tmp_path), "copy.h5"))
+    for key in ("grid/centers", "grid/vertices", "grid/faces", "constant/levels", "constant/metric", "data/0.4/p_center"):
+        assert np.array_equal(np.squeeze(a[key]), np.squeeze(b[key])), key
+    xdmf = open(os.path.join(str(tmp_path), "copy.xdmf")).read()
+    assert "copy.h5:/data/0.4/p_center" in xdmf and 'NumberOfElements="209"' in xdmf and 'Dimensions="247 2"' in xdmf
+
+
+def test_async_batches_and_duplicates(tmp_path):
+    """the background writer: batches queued from snapshot-major buffers, a buffer reused only after wait_buffer, datasets
+    that exist already skipped and counted"""
+    from sparsespatialsampling_amd.data import Datawriter
+    rng = np.random.default_rng(0)
+    wr = Datawriter(str(tmp_path), "b.h5")
+    bufs = [pt.empty((6, 50, 3), dtype=pt.float64), pt.empty((6, 50, 3), dtype=pt.float64)]
+    want = {}
+    for batch in range(5):
+        buf = bufs[batch % 2]
+        wr.wait_buffer(buf)                                        # the writer may still be storing batch - 2 from it
+        buf.copy_(pt.from_numpy(rng.random((6, 50, 3))))
+        times = [f"{batch}.{i}" for i in range(6)]
+        wr.write_snapshots("U_center", times, buf)
+        for i, t in enumerate(times):
+            want[t] = buf[i].clone().numpy()
+    wr.write_snapshots("U_center", ["0.0", "9.9"], bufs[0][:2].contiguous())     # the first exists already
+    assert wr._file.flush() == 1
+    wr.close()
+    got = dump(os.path.join(str(tmp_path), "b.h5"))
+    assert len(got) == 31
+    for t, v in want.items():
+        assert np.array_equal(got[f"data/{t}/U_center"], v)

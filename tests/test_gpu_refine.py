@@ -103,6 +103,57 @@ def test_export_pipeline_gpu(tmp_path):
     assert np.abs(ex._metric.numpy() - ref_metric).max() <= 1e-13 * np.abs(ref_metric).max()
 
 
+def test_export_to_real_hdf5_and_back_gpu(tmp_path):
+    """``ExportData.export()`` end to end on the GPU into a REAL HDF5 file (native sink, background writer, two download
+    buffers): a scalar field in batches of 7 + 7 + 3 snapshots and a vector field at once, interpolation at the vertices
+    too; read back with ``Dataloader`` and compared with the oracle; layout as the reference's loader expects
+    (tests/test_s_cube_dataloader.py:40-57: write times, field names, shapes) and as export.py:283-299 writes it (one
+    dataset ``data/<t>/<field>_center`` per write time; scalars squeezed)."""
+    from sparsespatialsampling_amd import geometry, h5io
+    from sparsespatialsampling_amd.data import Dataloader
+    from sparsespatialsampling_amd.export import ExportData
+    from sparsespatialsampling_amd.sparse_spatial_sampling import SparseSpatialSampling
+    from oracle import s3_oracle as orc
+    if h5io.native_lib() is None:
+        pytest.importorskip("h5py")
+    x, y, geos, kw = refine_inputs("refine_2d_metric", geometry)
+    s3 = SparseSpatialSampling(pt.from_numpy(x), pt.from_numpy(y), geos, str(tmp_path), "case", uniform_levels=4, min_metric=0.6)
+    s3.execute_grid_generation()
+    n_t = 17
+    times = [f"{0.05 * i:.2f}" for i in range(n_t)]
+    rng = np.random.default_rng(9)
+    p = rng.standard_normal((len(x), 1, n_t)).astype(np.float32)
+    u = rng.standard_normal((len(x), 2, n_t)).astype(np.float32)
+    ex = ExportData(s3, write_times=times, interpolate_at_vertices=True)
+    for a, b in ((0, 7), (7, 14), (14, 17)):
+        ex.export(pt.from_numpy(x), pt.from_numpy(p[:, :, a:b]), "p", n_snapshots_total=n_t)
+    ex.export(pt.from_numpy(x), pt.from_numpy(u), "U")
+
+    ld = Dataloader(str(tmp_path), "case.h5", dtype=pt.float64)
+    nc, nv = len(s3.centers), len(s3.vertices)
+    assert ld.write_times == sorted(times) and ld.field_names[times[3]] == ["U", "p"]
+    assert ld.vertices.shape == (nc, 2) and ld.nodes.shape == (nv, 2) and ld.faces.shape == (nc, 4) and ld.faces.dtype == pt.int32
+    assert pt.equal(ld.vertices, s3.centers) and pt.equal(ld.nodes, s3.vertices) and pt.equal(ld.faces, s3.faces)
+    assert pt.equal(ld.levels, s3.levels.squeeze()) and ld.weights.shape == ld.levels.shape
+    idx_c, dist_c = orc.knn(x, s3.centers.numpy(), 8)
+    idx_v, dist_v = orc.knn(x, s3.vertices.numpy(), 8)
+    w_c, w_v = orc.idw_weights(dist_c), orc.idw_weights(dist_v)
+    got_p, got_u = ld.load_snapshot("p", times), ld.load_snapshot("U", times)
+    assert got_p.shape == (nc, n_t) and got_u.shape == (nc, 2, n_t)
+    ref_p, ref_u = orc.interp(w_c, idx_c, p), orc.interp(w_c, idx_c, u)
+    assert np.abs(got_p.numpy() - ref_p[:, 0, :]).max() <= 1e-13 * np.abs(ref_p).max()
+    assert np.abs(got_u.numpy() - ref_u).max() <= 1e-13 * np.abs(ref_u).max()
+    np.testing.assert_allclose(ld.metric.numpy(), orc.interp(w_c, idx_c, y), rtol=1e-13)
+    with h5io.open_h5(os.path.join(str(tmp_path), "case.h5"), "r") as f:       # vertex values and the raw layout
+        assert f.keys() == ["constant", "data", "grid"] and f.keys("data/0.10") == ["U_center", "U_vertices", "p_center", "p_vertices"]
+        assert f.shape("data/0.10/p_center") == (nc,) and f.shape("data/0.10/U_vertices") == (nv, 2)
+        ref_pv = orc.interp(w_v, idx_v, p)
+        for i in (0, 6, 7, 16):
+            assert np.abs(f.read(f"data/{times[i]}/p_vertices") - ref_pv[:, 0, i]).max() <= 1e-13 * np.abs(ref_pv).max()
+    xdmf = open(os.path.join(str(tmp_path), "case.xdmf")).read()
+    assert xdmf.count("<Time Value=") == n_t and f'case.h5:/data/{times[-1]}/U_vertices' in xdmf
+
+
 def _naca_polygon(n=120, chord=1.0, t=0.12):
     """closed NACA-00xx outline (the OAT15-like body of BASELINE config C2)"""
     xs = 0.5 * (1 - np.cos(np.linspace(0, np.pi, n // 2)))

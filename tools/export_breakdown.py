@@ -2,8 +2,6 @@
 import sys, time, types, logging
 import numpy as np, torch as pt
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
-from tests import fake_h5py
-fake_h5py.install()
 from sparsespatialsampling_amd import hipops
 from sparsespatialsampling_amd.export import ExportData, _as_float
 logging.getLogger().setLevel(logging.WARNING)

@@ -2,8 +2,6 @@
 import sys, time, logging, types
 import numpy as np, torch as pt
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
-from tests import fake_h5py
-fake_h5py.install()
 import bench
 from sparsespatialsampling_amd.export import ExportData
 logging.getLogger().setLevel(logging.WARNING)

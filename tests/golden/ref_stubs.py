@@ -131,6 +131,13 @@ def install():
 
     if REFERENCE_ROOT not in sys.path:
         sys.path.insert(0, REFERENCE_ROOT)
+    # the name ``sparseSpatialSampling`` must resolve to the REAL reference here, never to the import-name alias of this
+    # repository (compat/sparseSpatialSampling): a generator or fuzzer that compared the package with itself would pin nothing
+    import importlib.util
+    spec = importlib.util.find_spec("sparseSpatialSampling")
+    if spec is None or not str(spec.origin).startswith(REFERENCE_ROOT + "/"):
+        raise ImportError(f"'sparseSpatialSampling' resolves to {getattr(spec, 'origin', None)}, not to the reference under "
+                          f"{REFERENCE_ROOT}")
 
 
 install()

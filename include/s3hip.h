@@ -242,6 +242,16 @@ int s3_sumsq_blocks(const double *d_metric, const uint8_t *d_leaf, int64_t n_cel
                     double *d_partial /*[n_blocks total], entries [block_begin, block_end) written*/, s3_stream stream);
 int s3_sum_ordered(const double *d_values, int64_t n, double *d_out, s3_stream stream);
 
+
+/* ---- weighted SVD downstream of S^3 (utils.py:302-346, data.py:240-247) -------------------------
+ * G[t,t] = sum_n w[n] (x[n,:] - mean[n]) (x[n,:] - mean[n])^T over the rows of the interpolated snapshot matrix x
+ * [n_rows, t] (f64, row pitch in_stride), accumulated with v_mfma_f64_16x16x4_f64; centring and weighting are fused into
+ * the operand staging.  d_mean: temporal mean per row (s3_row_moments), d_weight: cell area / volume per row.  The
+ * eigen-decomposition of G (small) and the mode GEMM are host / library work (sparsespatialsampling_amd/svd.py). */
+size_t s3_weighted_gram_scratch_bytes(int64_t n_rows, int64_t t);
+int s3_weighted_gram(const double *d_x, int64_t n_rows, int64_t t, int64_t in_stride, const double *d_mean,
+                     const double *d_weight, double *d_gram /*[t,t]*/, void *d_scratch, s3_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,175 @@
+// Weighted Gram matrix of the interpolated snapshot matrix on the f64 matrix cores -- the dense step of the weighted SVD
+// downstream of S^3.  gfx950 only.
+//
+// Reference behaviour: utils.compute_svd (sparseSpatialSampling/utils.py:302-346): subtract the temporal mean of every row,
+// scale every row by sqrt(cell area / volume) (data.py:240-247), SVD of the [N_cells * n_comp, T] matrix.  T (snapshots) is
+// a few thousand at most while N is 10^5..10^7, so the SVD is taken through the T x T Gram matrix
+//     G = sum_n a_n (x_n - mean_n)(x_n - mean_n)^T         (x_n = row n of the data matrix, a_n its cell area)
+// (method of snapshots): G is accumulated here with v_mfma_f64_16x16x4_f64, the small eigenproblem is solved on the host,
+// the modes follow from one plain library GEMM (svd.py).  Centring and weighting are fused into the operand staging: the
+// matrix is read as it left the interpolation kernel, nothing is materialised.
+//
+// Kernel: one 256-thread workgroup per (128 x 128 block of the upper triangle of G, slice of the rows).  Per step 16 rows
+// of the two column panels are loaded (coalesced 16-byte pieces), centred, weighted and stored to LDS; each wavefront
+// owns a 64 x 64 quarter = 4 x 4 MFMA tiles (128 accumulator VGPRs) and issues 16 MFMAs per 4 rows.  The row slices'
+// partial blocks are added in slice order by a second kernel (deterministic), which also mirrors the lower triangle.
+#include "common.h"
+
+#include <vector>
+
+namespace s3 {
+
+constexpr int GB = 128;            // block edge of G
+constexpr int GK = 16;             // rows of the data matrix per step
+constexpr int GLD = GB + 16;       // LDS row pitch in doubles: consecutive rows start 128 B apart modulo 256 B (no bank conflicts
+                                   // between the four 16-lane groups of a ds_read_b64)
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(256)
+gram_block_kernel(const double *__restrict__ x, int64_t n_rows, int t, int64_t in_stride, const double *__restrict__ mean,
+                  const double *__restrict__ weight, const int2 *__restrict__ pairs, int64_t rows_per_slice,
+                  double *__restrict__ partial /*[slice][pair][GB][GB]*/) {
+    __shared__ double sA[2][GK][GLD];
+    __shared__ double sB[2][GK][GLD];
+    const int pair = blockIdx.x, slice = blockIdx.y;
+    const int bi = pairs[pair].x, bj = pairs[pair].y;
+    const bool diagonal = bi == bj;
+    const int64_t r0 = (int64_t)slice * rows_per_slice, r1 = min(n_rows, r0 + rows_per_slice);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+
+    double4_t acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = double4_t{0.0, 0.0, 0.0, 0.0};
+
+    // staging role: 16 threads per row, each 4 pieces of 2 doubles per panel (columns c2, c2 + 32, c2 + 64, c2 + 96)
+    const int srow = threadIdx.x >> 4, c2 = (threadIdx.x & 15) * 2;
+    auto stage = [&](int buf, int64_t row_base) {
+        const int64_t row = row_base + srow;
+        const bool ok = row < r1;
+        const double mu = ok ? mean[row] : 0.0;
+        const double sw = ok ? sqrt(weight[row]) : 0.0;
+        const double *xr = x + (ok ? row : 0) * in_stride;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int c = c2 + 32 * p;
+            double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+            const int ca = bi * GB + c, cb = bj * GB + c;
+            if (ok && ca < t) a0 = (xr[ca] - mu) * sw;
+            if (ok && ca + 1 < t) a1 = (xr[ca + 1] - mu) * sw;
+            sA[buf][srow][c] = a0;
+            sA[buf][srow][c + 1] = a1;
+            if (!diagonal) {
+                if (ok && cb < t) b0 = (xr[cb] - mu) * sw;
+                if (ok && cb + 1 < t) b1 = (xr[cb + 1] - mu) * sw;
+                sB[buf][srow][c] = b0;
+                sB[buf][srow][c + 1] = b1;
+            }
+        }
+    };
+
+    int buf = 0;
+    if (r0 < r1) stage(0, r0);
+    __syncthreads();
+    for (int64_t row = r0; row < r1; row += GK) {
+        if (row + GK < r1) stage(buf ^ 1, row + GK);            // next step's panels go to the other buffer meanwhile
+        const double(*pa)[GLD] = sA[buf];
+        const double(*pb)[GLD] = diagonal ? sA[buf] : sB[buf];
+#pragma unroll
+        for (int k4 = 0; k4 < GK / 4; ++k4) {
+            const int kr = k4 * 4 + (lane >> 4), cl = lane & 15;
+            double a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a[i] = pa[kr][wi * 64 + i * 16 + cl];
+                b[i] = pb[kr][wj * 64 + i * 16 + cl];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    // C/D layout of v_mfma_f64_16x16x4_f64: column = lane & 15, row = (lane >> 4) + 4 * register
+    double *out = partial + ((int64_t)slice * gridDim.x + pair) * GB * GB;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gr = wi * 64 + i * 16 + (lane >> 4) + 4 * r, gc = wj * 64 + j * 16 + (lane & 15);
+                out[gr * GB + gc] = acc[i][j][r];
+            }
+}
+
+// G block = sum over the row slices in slice order; upper block written as is, lower block mirrored
+__global__ void __launch_bounds__(256)
+gram_reduce_kernel(const double *__restrict__ partial, const int2 *__restrict__ pairs, int n_pairs, int n_slices, int t,
+                   double *__restrict__ g) {
+    const int pair = blockIdx.x;
+    const int bi = pairs[pair].x, bj = pairs[pair].y;
+    for (int e = threadIdx.x; e < GB * GB; e += 256) {
+        double s = 0.0;
+        for (int sl = 0; sl < n_slices; ++sl) s += partial[((int64_t)sl * n_pairs + pair) * GB * GB + e];
+        const int r = bi * GB + e / GB, c = bj * GB + e % GB;
+        if (r < t && c < t) {
+            if (bi != bj || c >= r) g[(int64_t)r * t + c] = s;
+            if (bi != bj || c > r) g[(int64_t)c * t + r] = s;
+        }
+    }
+}
+
+}  // namespace s3
+
+using namespace s3;
+
+extern "C" {
+
+size_t s3_weighted_gram_scratch_bytes(int64_t n_rows, int64_t t) {
+    if (n_rows < 1 || t < 1) return 0;
+    const int64_t nb = (t + GB - 1) / GB, n_pairs = nb * (nb + 1) / 2;
+    int64_t slices = (1024 + n_pairs - 1) / n_pairs;
+    const int64_t max_slices = (n_rows + 16 * GK - 1) / (16 * GK);
+    if (slices > max_slices) slices = max_slices;
+    if (slices < 1) slices = 1;
+    return (size_t)(slices * n_pairs) * GB * GB * sizeof(double) + (size_t)n_pairs * sizeof(int2) + 64;
+}
+
+int s3_weighted_gram(const double *d_x, int64_t n_rows, int64_t t, int64_t in_stride, const double *d_mean,
+                     const double *d_weight, double *d_gram, void *d_scratch, s3_stream stream) {
+    S3_REQUIRE(d_x && d_mean && d_weight && d_gram && d_scratch, "s3_weighted_gram: null array");
+    S3_REQUIRE(n_rows >= 1 && t >= 1 && t < (1 << 20) && in_stride >= t, "s3_weighted_gram: bad sizes (rows %lld, t %lld, stride %lld)",
+               (long long)n_rows, (long long)t, (long long)in_stride);
+    hipStream_t st = as_stream(stream);
+    const int nb = (int)((t + GB - 1) / GB), n_pairs = nb * (nb + 1) / 2;
+    int64_t slices = (1024 + n_pairs - 1) / n_pairs;
+    const int64_t max_slices = (n_rows + 16 * GK - 1) / (16 * GK);
+    if (slices > max_slices) slices = max_slices;
+    if (slices < 1) slices = 1;
+    int64_t rows_per_slice = (n_rows + slices - 1) / slices;
+    rows_per_slice = (rows_per_slice + GK - 1) / GK * GK;
+    slices = (n_rows + rows_per_slice - 1) / rows_per_slice;
+    S3_REQUIRE(slices < 65536, "s3_weighted_gram: too many row slices");
+    double *d_partial = static_cast<double *>(d_scratch);
+    int2 *d_pairs = reinterpret_cast<int2 *>(d_partial + (size_t)slices * n_pairs * GB * GB);
+    std::vector<int2> pairs;
+    for (int i = 0; i < nb; ++i)
+        for (int j = i; j < nb; ++j) pairs.push_back(make_int2(i, j));
+    S3_HIP_CHECK(hipMemcpyAsync(d_pairs, pairs.data(), sizeof(int2) * pairs.size(), hipMemcpyHostToDevice, st));
+    S3_HIP_CHECK(hipStreamSynchronize(st));               // `pairs` is a local
+    gram_block_kernel<<<dim3((unsigned)n_pairs, (unsigned)slices), 256, 0, st>>>(d_x, n_rows, (int)t, in_stride, d_mean, d_weight,
+                                                                                d_pairs, rows_per_slice, d_partial);
+    S3_LAUNCH_CHECK();
+    gram_reduce_kernel<<<(unsigned)n_pairs, 256, 0, st>>>(d_partial, d_pairs, n_pairs, (int)slices, (int)t, d_gram);
+    S3_LAUNCH_CHECK();
+    return S3_OK;
+}
+
+}  // extern "C"

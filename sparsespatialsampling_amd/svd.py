@@ -1,0 +1,89 @@
+"""
+Weighted SVD of the fields on the S^3 grid -- the consumer downstream of the interpolation.
+Mirrors ``sparseSpatialSampling.utils.compute_svd`` (reference utils.py:302-346): temporal mean removed, every cell
+weighted by the square root of its area / volume (``Dataloader.weights``, data.py:240-247), returns ``(s, U, V)`` with the
+weighting divided out of the modes again.
+
+How it runs on the MI355X (method of snapshots; the snapshot count T is small against the number of cells N):
+
+1. temporal mean per row -- ``s3_row_moments`` (one streaming pass, csrc/metric.hip);
+2. ``G = sum_n a_n (x_n - mean_n)(x_n - mean_n)^T`` [T, T] -- ``s3_weighted_gram`` on the f64 matrix cores
+   (``v_mfma_f64_16x16x4_f64``, csrc/svd.hip); centring and weighting are fused into the operand staging, the data matrix
+   is read as the interpolation kernel left it (f64, HBM resident);
+3. ``G = V diag(s^2) V^T`` -- symmetric eigenproblem of a T x T matrix, on the host (LAPACK through torch);
+4. modes ``U = (X - mean) V diag(1/s)`` -- one plain library GEMM (rocBLAS through torch) plus a rank-one correction for
+   the mean; the weights cancel: ``(sqrt(a) (X - mean) V / s) / sqrt(a)``.
+
+The reference delegates to ``flowtorch.analysis.SVD`` (absent here): ``rank=None`` selects the optimal hard threshold of
+Gavish & Donoho as flowtorch documents it (``opt_rank``); that selection rule is restated from the documentation, not pinned
+against flowtorch.  Unlike the reference the caller's ``data_matrix`` is not modified.  Squaring the matrix halves the
+attainable relative accuracy of the small singular values (about sqrt(eps) * s_max); the leading modes -- what
+``write_svd_s_cube_to_file`` stores, utils.py:349-413 -- are unaffected.
+"""
+import ctypes as C
+from typing import Tuple
+
+import numpy as np
+import torch as pt
+
+from . import _lib, hipops, metrics
+
+
+def optimal_rank(s: pt.Tensor, n_rows: int, n_cols: int) -> int:
+    """singular values above the optimal hard threshold ``omega(beta) * median(s)`` (Gavish & Donoho 2014, unknown noise
+    level; ``beta`` = aspect ratio <= 1)"""
+    beta = min(n_rows, n_cols) / max(n_rows, n_cols)
+    omega = 0.56 * beta ** 3 - 0.95 * beta ** 2 + 1.82 * beta + 1.43
+    tau = omega * float(pt.median(s))
+    return max(1, int((s > tau).sum()))
+
+
+def weighted_gram(x: pt.Tensor, mean: pt.Tensor, weight: pt.Tensor) -> pt.Tensor:
+    """``sum_n weight[n] (x[n] - mean[n]) (x[n] - mean[n])^T`` for a device matrix ``x`` [N, T] float64 (rows may be pitched:
+    a column slice of a wider buffer) -> [T, T] float64 on the device"""
+    if not (x.is_cuda and x.dtype == pt.float64 and x.dim() == 2 and x.stride(1) == 1):
+        raise TypeError("weighted_gram: 2-D float64 device matrix with unit inner stride required")
+    n, t = int(x.shape[0]), int(x.shape[1])
+    mean, weight = hipops.to_device(mean, pt.float64).reshape(-1), hipops.to_device(weight, pt.float64).reshape(-1)
+    if mean.numel() != n or weight.numel() != n:
+        raise ValueError("weighted_gram: one mean and one weight per row required")
+    lib = _lib.hip_lib()
+    scratch = pt.empty(int(lib.s3_weighted_gram_scratch_bytes(n, t)), dtype=pt.uint8, device=x.device)
+    g = pt.empty((t, t), dtype=pt.float64, device=x.device)
+    hipops.check(lib.s3_weighted_gram(C.c_void_p(x.data_ptr()), n, t, int(x.stride(0)), hipops._ptr(mean), hipops._ptr(weight),
+                                      hipops._ptr(g), hipops._ptr(scratch), hipops._stream()), "s3_weighted_gram")
+    return g
+
+
+def compute_svd(data_matrix: pt.Tensor, cell_area: pt.Tensor, rank: int = None) -> Tuple[pt.Tensor, pt.Tensor, pt.Tensor]:
+    """weighted SVD of a field: ``data_matrix`` [N_cells, N_snapshots] (scalar) or [N_cells, N_dims, N_snapshots]
+    (vector; the components are stacked like the reference does, utils.py:333-336), ``cell_area`` [N_cells].  Returns
+    ``(s [r], U [N_cells, (N_dims,) r], V [N_snapshots, r])`` on the device the data came from."""
+    shape = tuple(data_matrix.shape)
+    if len(shape) not in (2, 3):
+        raise ValueError(f"expected [N_cells, N_snapshots] or [N_cells, N_dims, N_snapshots], got {shape}")
+    on_host = not data_matrix.is_cuda
+    x = hipops.to_device(data_matrix if data_matrix.dtype == pt.float64 else data_matrix.to(pt.float64))
+    area = hipops.to_device(cell_area, pt.float64).reshape(-1)
+    n_cells, t = shape[0], shape[-1]
+    if len(shape) == 3:
+        # the reference reshapes [N, C, T] -> [C * N, T] of the C-contiguous tensor, i.e. row (n, c) keeps the area of cell n
+        x2 = x.reshape(n_cells * shape[1], t)
+        w = area.repeat_interleave(shape[1])
+    else:
+        x2, w = x, area
+    mean = metrics.temporal_mean(x2)
+    g = weighted_gram(x2, mean, w)
+    lam, vec = pt.linalg.eigh(g.cpu())                        # ascending; T x T, on the host
+    lam, vec = lam.flip(0).clamp_min(0.0), vec.flip(1)
+    s_all = lam.sqrt()
+    r = optimal_rank(s_all, x2.shape[0], t) if rank is None else min(int(rank), t)
+    keep = s_all[:r] > s_all[0] * 1e-14 if r else s_all[:0] > 0
+    r = int(keep.sum()) if r else 0
+    s, v = s_all[:r], vec[:, :r].contiguous()
+    b = (v / s).to(x2.device)                                 # [T, r]
+    u = x2 @ b - mean.reshape(-1, 1) * b.sum(0, keepdim=True)     # (X - mean 1^T) B; the sqrt(area) factors cancel
+    if len(shape) == 3:
+        u = u.reshape(n_cells, shape[1], r)
+    s, v = s.to(x2.device), v.to(x2.device)
+    return (s.cpu(), u.cpu(), v.cpu()) if on_host else (s, u, v)

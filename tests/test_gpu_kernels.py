@@ -531,3 +531,54 @@ def test_temporal_std_is_a_valid_metric():
                         min_metric=0.6)
     tree.refine()
     assert len(tree.all_centers) > 64
+
+
+# ---- weighted SVD downstream -----------------------------------------------------------------
+@pytest.mark.parametrize("n,t,pitch", [(3000, 40, 0), (20011, 130, 6), (5000, 257, 0), (777, 5, 3), (40, 300, 0)])
+def test_weighted_gram_vs_torch(ops, n, t, pitch):
+    """G = sum_n a_n (x_n - mean_n)(x_n - mean_n)^T on the f64 matrix cores against torch float64 on the host"""
+    from sparsespatialsampling_amd import metrics, svd
+    rng = np.random.default_rng(n + t)
+    buf = pt.from_numpy(rng.standard_normal((n, t + pitch)) * (1 + np.arange(t + pitch)[None, :] * 0.01) + rng.standard_normal((n, 1))).cuda()
+    x = buf[:, :t]
+    area = pt.from_numpy(rng.random(n) + 0.1)
+    mean = metrics.temporal_mean(x)
+    g = svd.weighted_gram(x, mean, area).cpu()
+    xc = (x.cpu() - x.cpu().mean(-1, keepdim=True)) * area.sqrt()[:, None]
+    ref = xc.T @ xc
+    assert pt.equal(g, g.T)                                                       # mirrored, exactly symmetric
+    assert (g - ref).abs().max() <= 1e-12 * ref.abs().max()
+
+
+@pytest.mark.parametrize("shape,rank", [((6000, 60), 8), ((2500, 3, 48), 5), ((4000, 33), None)])
+def test_compute_svd_vs_torch(shape, rank):
+    """the weighted SVD (reference utils.py:302-346) against torch.linalg.svd of the weighted, centred matrix in float64:
+    singular values, modes and coefficients up to sign, and the reconstruction"""
+    from sparsespatialsampling_amd import svd
+    rng = np.random.default_rng(len(shape))
+    n, t = shape[0], shape[-1]
+    # a few coherent structures + noise
+    base = sum(np.outer(rng.standard_normal(int(np.prod(shape[:-1]))), np.sin((j + 1) * np.linspace(0, 3, t) + j)) * 2.0 ** (4 - j)
+               for j in range(6)).reshape(shape) + 0.01 * rng.standard_normal(shape) + 3.0
+    data = pt.from_numpy(base)
+    area = pt.from_numpy(rng.random(n) * 0.5 + 0.05)
+    keep = data.clone()
+    s, u, v = svd.compute_svd(data, area, rank)
+    assert pt.equal(data, keep)                                                    # the caller's matrix is left alone
+    xw = (data - data.mean(-1, keepdim=True)) * (area.sqrt()[:, None] if len(shape) == 2 else area.sqrt()[:, None, None])
+    u_ref, s_ref, vt_ref = pt.linalg.svd(xw.reshape(-1, t), full_matrices=False)
+    r = len(s)
+    if rank is not None:
+        assert r == rank
+    else:
+        assert r == svd.optimal_rank(s_ref, xw.reshape(-1, t).shape[0], t) and 1 <= r <= t
+    assert pt.allclose(s, s_ref[:r], rtol=1e-9)
+    uw = (u * (area.sqrt()[:, None] if len(shape) == 2 else area.sqrt()[:, None, None])).reshape(-1, r)   # weighted modes
+    lead = min(r, 5)
+    sign = pt.sign((uw[:, :lead] * u_ref[:, :lead]).sum(0))
+    assert (uw[:, :lead] * sign - u_ref[:, :lead]).abs().max() <= 1e-7
+    assert (v[:, :lead] * sign - vt_ref[:lead].T).abs().max() <= 1e-7
+    assert pt.allclose(uw.T @ uw, pt.eye(r, dtype=pt.float64), atol=1e-8)
+    recon = (uw * s) @ v.T
+    best = (u_ref[:, :r] * s_ref[:r]) @ vt_ref[:r]
+    assert (recon - best).abs().max() <= 1e-8 * s_ref[0]

@@ -45,37 +45,50 @@ gram_block_kernel(const double *__restrict__ x, int64_t n_rows, int t, int64_t i
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = double4_t{0.0, 0.0, 0.0, 0.0};
 
-    // staging role: 16 threads per row, each 4 pieces of 2 doubles per panel (columns c2, c2 + 32, c2 + 64, c2 + 96)
+    // staging role: 16 threads per row, each 4 pieces of 2 doubles per panel (columns c2, c2 + 32, c2 + 64, c2 + 96).  The
+    // raw loads of step s + 1 are issued before the MFMAs of step s and land in registers; they are centred, weighted
+    // and written to the other LDS buffer after the MFMAs (global latency hidden behind ~4000 cycles of matrix work)
     const int srow = threadIdx.x >> 4, c2 = (threadIdx.x & 15) * 2;
-    auto stage = [&](int buf, int64_t row_base) {
+    double ra[4][2], rb[4][2], mu = 0.0, sw = 0.0;
+    auto load = [&](int64_t row_base) {
         const int64_t row = row_base + srow;
         const bool ok = row < r1;
-        const double mu = ok ? mean[row] : 0.0;
-        const double sw = ok ? sqrt(weight[row]) : 0.0;
+        mu = ok ? mean[row] : 0.0;
+        sw = ok ? sqrt(weight[row]) : 0.0;                        // sw = 0 zeroes the padding rows
         const double *xr = x + (ok ? row : 0) * in_stride;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            const int c = c2 + 32 * p;
-            double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
-            const int ca = bi * GB + c, cb = bj * GB + c;
-            if (ok && ca < t) a0 = (xr[ca] - mu) * sw;
-            if (ok && ca + 1 < t) a1 = (xr[ca + 1] - mu) * sw;
-            sA[buf][srow][c] = a0;
-            sA[buf][srow][c + 1] = a1;
+            const int ca = bi * GB + c2 + 32 * p, cb = bj * GB + c2 + 32 * p;
+            ra[p][0] = ca < t ? xr[ca] : mu;                      // columns past t contribute (mu - mu) * sw = 0
+            ra[p][1] = ca + 1 < t ? xr[ca + 1] : mu;
             if (!diagonal) {
-                if (ok && cb < t) b0 = (xr[cb] - mu) * sw;
-                if (ok && cb + 1 < t) b1 = (xr[cb + 1] - mu) * sw;
-                sB[buf][srow][c] = b0;
-                sB[buf][srow][c + 1] = b1;
+                rb[p][0] = cb < t ? xr[cb] : mu;
+                rb[p][1] = cb + 1 < t ? xr[cb + 1] : mu;
+            }
+        }
+    };
+    auto store = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int c = c2 + 32 * p;
+            sA[buf][srow][c] = (ra[p][0] - mu) * sw;
+            sA[buf][srow][c + 1] = (ra[p][1] - mu) * sw;
+            if (!diagonal) {
+                sB[buf][srow][c] = (rb[p][0] - mu) * sw;
+                sB[buf][srow][c + 1] = (rb[p][1] - mu) * sw;
             }
         }
     };
 
     int buf = 0;
-    if (r0 < r1) stage(0, r0);
+    if (r0 < r1) {
+        load(r0);
+        store(0);
+    }
     __syncthreads();
     for (int64_t row = r0; row < r1; row += GK) {
-        if (row + GK < r1) stage(buf ^ 1, row + GK);            // next step's panels go to the other buffer meanwhile
+        const bool more = row + GK < r1;
+        if (more) load(row + GK);
         const double(*pa)[GLD] = sA[buf];
         const double(*pb)[GLD] = diagonal ? sA[buf] : sB[buf];
 #pragma unroll
@@ -92,6 +105,7 @@ gram_block_kernel(const double *__restrict__ x, int64_t n_rows, int t, int64_t i
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
         }
+        if (more) store(buf ^ 1);
         __syncthreads();
         buf ^= 1;
     }
@@ -115,7 +129,8 @@ gram_reduce_kernel(const double *__restrict__ partial, const int2 *__restrict__ 
                    double *__restrict__ g) {
     const int pair = blockIdx.x;
     const int bi = pairs[pair].x, bj = pairs[pair].y;
-    for (int e = threadIdx.x; e < GB * GB; e += 256) {
+    {
+        const int e = blockIdx.y * 256 + threadIdx.x;            // one entry of the block per lane
         double s = 0.0;
         for (int sl = 0; sl < n_slices; ++sl) s += partial[((int64_t)sl * n_pairs + pair) * GB * GB + e];
         const int r = bi * GB + e / GB, c = bj * GB + e % GB;
@@ -167,7 +182,7 @@ int s3_weighted_gram(const double *d_x, int64_t n_rows, int64_t t, int64_t in_st
     gram_block_kernel<<<dim3((unsigned)n_pairs, (unsigned)slices), 256, 0, st>>>(d_x, n_rows, (int)t, in_stride, d_mean, d_weight,
                                                                                 d_pairs, rows_per_slice, d_partial);
     S3_LAUNCH_CHECK();
-    gram_reduce_kernel<<<(unsigned)n_pairs, 256, 0, st>>>(d_partial, d_pairs, n_pairs, (int)slices, (int)t, d_gram);
+    gram_reduce_kernel<<<dim3((unsigned)n_pairs, GB * GB / 256), 256, 0, st>>>(d_partial, d_pairs, n_pairs, (int)slices, (int)t, d_gram);
     S3_LAUNCH_CHECK();
     return S3_OK;
 }

@@ -582,3 +582,41 @@ def test_compute_svd_vs_torch(shape, rank):
     recon = (uw * s) @ v.T
     best = (u_ref[:, :r] * s_ref[:r]) @ vt_ref[:r]
     assert (recon - best).abs().max() <= 1e-8 * s_ref[0]
+
+
+# ---- RCCL communicator inside the library -------------------------------------------------------------
+def test_rccl_comm_single_rank_roundtrip():
+    """the s3_comm_* entry points on hardware with a one-rank communicator (a one-GPU box cannot host more ranks on RCCL):
+    bootstrap through a TCPStore, grouped in-place all-gather, sum / max all-reduce, and a whole refine with the
+    communicator forced on (S3_COMM_FORCE=1) giving the grid of the plain run"""
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    code = r"""
+import os, sys
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests", "golden"))
+import numpy as np, torch as pt
+from sparsespatialsampling_amd import geometry, parallel
+import sparsespatialsampling_amd.s_cube as s_cube
+from inputs import refine_inputs
+comm = parallel.init()
+assert comm.name == "rccl" and (comm.rank, comm.world) == (0, 1)
+a = pt.arange(10, dtype=pt.float64, device="cuda"); b = pt.arange(7, dtype=pt.float64, device="cuda") * 2
+comm.allgather_inplace([a, b], [10, 7])
+assert pt.equal(a.cpu(), pt.arange(10, dtype=pt.float64)) and pt.equal(b.cpu(), pt.arange(7, dtype=pt.float64) * 2)
+assert comm.allreduce_max(3.5) == 3.5
+comm.barrier()
+x, y, geos, kw = refine_inputs("refine_3d_metric", geometry)
+tree = s_cube.SamplingTree(pt.from_numpy(x), pt.from_numpy(y), geometry_obj=geos, **kw)
+assert tree._backend.comm is comm
+tree.refine()
+z = np.load(os.path.join("tests", "golden", "refine_3d_metric.npz"))
+assert np.array_equal(tree.all_centers.numpy(), z["all_centers"]) and np.array_equal(tree.face_ids.numpy(), z["face_ids"])
+parallel.shutdown()
+print("rccl ok")
+"""
+    env = dict(os.environ, S3_COMM_FORCE="1", RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    run = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0 and "rccl ok" in run.stdout, (run.stdout + run.stderr)[-3000:]

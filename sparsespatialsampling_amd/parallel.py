@@ -165,9 +165,14 @@ def init(backend=None):
         else:
             _comm = SoloComm()
     elif world_size > 1 or os.environ.get("S3_COMM_FORCE") == "1":
-        from torch.distributed import TCPStore
-        store = TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29500")), world_size,
-                         is_master=(rank == 0))
+        # the launcher's rendezvous store (torch.distributed.run hosts it itself and tells the workers so through
+        # TORCHELASTIC_USE_AGENT_STORE; a bare environment gets a TCPStore served by rank 0): torch's own env:// handler
+        # knows both cases.  Only the store is used -- no process group is created.
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        store, _, _ = next(dist.rendezvous("env://", rank=rank, world_size=world_size))
+        store = dist.PrefixStore("s3_comm", store)
         _comm = RcclComm(rank, world_size, store)
         _comm._store = store            # keep the rendezvous alive as long as the communicator
     else:

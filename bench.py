@@ -279,7 +279,8 @@ def main():
     knn.close()
     del dist_
     # only the source rows this rank's cells reference are resident (ExportData uploads exactly those per batch)
-    used, remap = hipops.referenced_rows([idx], len(x))
+    # (in Hilbert order of their coordinates, as ExportData keeps them; S3_BENCH_ROW_ORDER=id: ascending point id)
+    used, remap = hipops.referenced_rows([idx], len(x), coords=None if os.environ.get("S3_BENCH_ROW_ORDER") == "id" else x)
     n_rows = int(used.numel())
     hipops.remap_indices(idx, remap)
     del remap

@@ -213,6 +213,12 @@ int s3_mark_rows(const int32_t *d_idx, int64_t n, int64_t n_src, int32_t *d_flag
 int s3_compact_rows(int32_t *d_flag_remap /*[n_src] in: 0/1, out: remap*/, int64_t n_src, int32_t *d_used /*[n_src]*/,
                     int64_t *h_n_used, s3_stream stream);
 int s3_remap_indices(int32_t *d_idx, int64_t n, const int32_t *d_remap, int64_t n_src, s3_stream stream);
+/* Hilbert-curve order of n points [n,dim] (dim 2 | 3): d_perm[position] = point.  The export path keeps the referenced
+ * source rows in this order in HBM, so that the rows a tile of neighbouring cells gathers lie close together (fewer
+ * DRAM pages / address translations per tile than with the CFD mesh's arbitrary numbering). */
+int s3_spatial_order(const double *d_points, int64_t n, int dim, int32_t *d_perm, s3_stream stream);
+/* d_remap[d_ids[i]] = i for the n distinct row ids, every other entry of d_remap[n_src] = -1 */
+int s3_positions_of(const int32_t *d_ids, int64_t n, int32_t *d_remap, int64_t n_src, s3_stream stream);
 int s3_gather_rows(const void *d_src, int64_t n_src_rows, int64_t row_bytes, int64_t src_pitch_bytes,
                    const int32_t *d_ids /*[n] or NULL*/, int64_t n, void *d_dst, int64_t dst_pitch_bytes, s3_stream stream);
 

@@ -241,6 +241,44 @@ struct Scratch {                           // frees whatever was allocated when 
         }                                                                                             \
     } while (0)
 
+// Hilbert-curve order of n points (dim 2 | 3): bounding box, 48-bit keys, stable radix sort -> perm[position] = point
+static int spatial_perm(const double *d_points, int64_t n, int dim, hipStream_t st, int32_t *d_perm, Scratch &tmp) {
+    const int nb = 256;
+    double *d_part = nullptr;
+    S3_PB_CHECK(tmp.alloc(&d_part, (size_t)nb * 6));
+    plan_bbox_kernel<<<nb, 256, 0, st>>>(d_points, n, dim, d_part);
+    S3_PB_CHECK(hipGetLastError());
+    std::vector<double> part((size_t)nb * 6);
+    S3_PB_CHECK(hipMemcpyAsync(part.data(), d_part, sizeof(double) * part.size(), hipMemcpyDeviceToHost, st));
+    S3_PB_CHECK(hipStreamSynchronize(st));
+    KeyParams kp{};
+    double hi[3] = {-1e300, -1e300, -1e300};
+    for (int j = 0; j < 3; ++j) kp.lo[j] = 1e300;
+    for (int b = 0; b < nb; ++b)
+        for (int j = 0; j < dim; ++j) {
+            kp.lo[j] = std::fmin(kp.lo[j], part[(size_t)b * 6 + j]);
+            hi[j] = std::fmax(hi[j], part[(size_t)b * 6 + 3 + j]);
+        }
+    double ext = 0;
+    for (int j = 0; j < dim; ++j) ext = std::fmax(ext, hi[j] - kp.lo[j]);
+    kp.dim = dim;
+    kp.bits = dim == 3 ? 16 : 24;                       // 48-bit keys
+    kp.scale = ext > 0 && std::isfinite(ext) ? ((double)((1u << kp.bits) - 1) / ext) : 0.0;
+    uint64_t *key_in = nullptr, *key_out = nullptr;
+    int32_t *val_in = nullptr;
+    S3_PB_CHECK(tmp.alloc(&key_in, (size_t)n));
+    S3_PB_CHECK(tmp.alloc(&key_out, (size_t)n));
+    S3_PB_CHECK(tmp.alloc(&val_in, (size_t)n));
+    key_kernel<<<grid_for(n, 256), 256, 0, st>>>(d_points, n, kp, key_in, val_in);
+    S3_PB_CHECK(hipGetLastError());
+    size_t bytes = 0;
+    S3_PB_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, key_in, key_out, val_in, d_perm, (int)n, 0, dim * kp.bits, st));
+    char *d_sort = nullptr;
+    S3_PB_CHECK(tmp.alloc(&d_sort, bytes));
+    S3_PB_CHECK(hipcub::DeviceRadixSort::SortPairs(d_sort, bytes, key_in, key_out, val_in, d_perm, (int)n, 0, dim * kp.bits, st));
+    return S3_OK;
+}
+
 int build_plan_tables(const int32_t *d_idx, int64_t nc, int k, int64_t n_src, const double *d_centers, int dim, int tc,
                       int ucap, hipStream_t st, PlanTables *out) {
     Scratch tmp;
@@ -253,41 +291,8 @@ int build_plan_tables(const int32_t *d_idx, int64_t nc, int k, int64_t n_src, co
 
     S3_PB_CHECK(hipMalloc(reinterpret_cast<void **>(&out->perm), sizeof(int32_t) * nc));
     if (d_centers) {
-        const int nb = 256;
-        double *d_part = nullptr;
-        S3_PB_CHECK(tmp.alloc(&d_part, (size_t)nb * 6));
-        plan_bbox_kernel<<<nb, 256, 0, st>>>(d_centers, nc, dim, d_part);
-        S3_PB_CHECK(hipGetLastError());
-        std::vector<double> part((size_t)nb * 6);
-        S3_PB_CHECK(hipMemcpyAsync(part.data(), d_part, sizeof(double) * part.size(), hipMemcpyDeviceToHost, st));
-        S3_PB_CHECK(hipStreamSynchronize(st));
-        KeyParams kp{};
-        double hi[3] = {-1e300, -1e300, -1e300};
-        for (int j = 0; j < 3; ++j) kp.lo[j] = 1e300;
-        for (int b = 0; b < nb; ++b)
-            for (int j = 0; j < dim; ++j) {
-                kp.lo[j] = std::fmin(kp.lo[j], part[(size_t)b * 6 + j]);
-                hi[j] = std::fmax(hi[j], part[(size_t)b * 6 + 3 + j]);
-            }
-        double ext = 0;
-        for (int j = 0; j < dim; ++j) ext = std::fmax(ext, hi[j] - kp.lo[j]);
-        kp.dim = dim;
-        kp.bits = dim == 3 ? 16 : 24;                       // 48-bit keys
-        kp.scale = ext > 0 && std::isfinite(ext) ? ((double)((1u << kp.bits) - 1) / ext) : 0.0;
-        uint64_t *key_in = nullptr, *key_out = nullptr;
-        int32_t *val_in = nullptr;
-        S3_PB_CHECK(tmp.alloc(&key_in, (size_t)nc));
-        S3_PB_CHECK(tmp.alloc(&key_out, (size_t)nc));
-        S3_PB_CHECK(tmp.alloc(&val_in, (size_t)nc));
-        key_kernel<<<grid_for(nc, 256), 256, 0, st>>>(d_centers, nc, kp, key_in, val_in);
-        S3_PB_CHECK(hipGetLastError());
-        size_t bytes = 0;
-        S3_PB_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, key_in, key_out, val_in, out->perm, (int)nc, 0,
-                                                       dim * kp.bits, st));
-        char *d_sort = nullptr;
-        S3_PB_CHECK(tmp.alloc(&d_sort, bytes));
-        S3_PB_CHECK(hipcub::DeviceRadixSort::SortPairs(d_sort, bytes, key_in, key_out, val_in, out->perm, (int)nc, 0,
-                                                       dim * kp.bits, st));
+        const int rc = spatial_perm(d_centers, nc, dim, st, out->perm, tmp);
+        if (rc != S3_OK) return rc;
     } else {
         iota_kernel<<<grid_for(nc, 256), 256, 0, st>>>(out->perm, nc);
         S3_PB_CHECK(hipGetLastError());
@@ -491,5 +496,44 @@ int s3_gather_rows(const void *d_src, int64_t n_src_rows, int64_t row_bytes, int
     return S3_OK;
 }
 
-}  // extern "C"
+__global__ void fill_i32_kernel(int32_t *__restrict__ v, int64_t n, int32_t value) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n) v[i] = value;
+}
 
+__global__ void scatter_positions_kernel(const int32_t *__restrict__ ids, int64_t n, int32_t n_src, int32_t *__restrict__ remap,
+                                         int32_t *__restrict__ bad) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t r = ids[i];
+    if (r < 0 || r >= n_src) { atomicExch(bad, 1); return; }
+    remap[r] = (int32_t)i;
+}
+
+// d_remap[d_ids[i]] = i, every other entry -1 (the inverse of a list of distinct row ids)
+int s3_positions_of(const int32_t *d_ids, int64_t n, int32_t *d_remap, int64_t n_src, s3_stream stream) {
+    S3_REQUIRE(d_remap && n >= 0 && n_src >= 1 && n_src < ((int64_t)1 << 31) && (n == 0 || d_ids), "s3_positions_of: bad arguments");
+    hipStream_t st = s3::as_stream(stream);
+    s3::Scratch tmp;
+    int32_t *d_bad = nullptr, bad = 0;
+    S3_HIP_CHECK(tmp.alloc(&d_bad, 1));
+    S3_HIP_CHECK(hipMemsetAsync(d_bad, 0, sizeof(int32_t), st));
+    fill_i32_kernel<<<s3::grid_for(n_src, 256), 256, 0, st>>>(d_remap, n_src, -1);
+    if (n > 0) scatter_positions_kernel<<<s3::grid_for(n, 256), 256, 0, st>>>(d_ids, n, (int32_t)n_src, d_remap, d_bad);
+    S3_LAUNCH_CHECK();
+    S3_HIP_CHECK(hipMemcpyAsync(&bad, d_bad, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    S3_HIP_CHECK(hipStreamSynchronize(st));
+    S3_REQUIRE(bad == 0, "s3_positions_of: row id outside [0, %lld)", (long long)n_src);
+    return S3_OK;
+}
+
+int s3_spatial_order(const double *d_points, int64_t n, int dim, int32_t *d_perm, s3_stream stream) {
+    S3_REQUIRE(d_points && d_perm && n >= 1 && n < ((int64_t)1 << 31) && (dim == 2 || dim == 3), "s3_spatial_order: bad arguments");
+    s3::Scratch tmp;
+    const int rc = s3::spatial_perm(d_points, n, dim, s3::as_stream(stream), d_perm, tmp);
+    if (rc != S3_OK) return rc;
+    S3_HIP_CHECK(hipStreamSynchronize(s3::as_stream(stream)));       // the scratch arrays go away with `tmp`
+    return S3_OK;
+}
+
+}  // extern "C"

@@ -303,9 +303,19 @@ def gather_rows(src, ids, dst):
     return dst
 
 
-def referenced_rows(tables, n_src):
-    """the source rows the neighbour tables (int32 device tensors) reference: (used ids ascending int32 [n_used] device,
-    remap int32 [n_src] device: position among the used rows or -1) -- mark / scan / compact on the device"""
+def spatial_order(points):
+    """Hilbert-curve order of device points [n, 2|3] float64 -> int32 permutation (position -> point) on the device"""
+    pts = to_device(points, pt.float64)
+    perm = pt.empty(int(pts.shape[0]), dtype=pt.int32, device=pts.device)
+    check(_lib.hip_lib().s3_spatial_order(_ptr(pts), int(pts.shape[0]), int(pts.shape[1]), _ptr(perm), _stream()),
+          "s3_spatial_order")
+    return perm
+
+
+def referenced_rows(tables, n_src, coords=None):
+    """the source rows the neighbour tables (int32 device tensors) reference: (used ids int32 [n_used] device, remap int32
+    [n_src] device: position among the used rows or -1) -- mark / scan / compact on the device.  Ascending ids, or, with
+    the points' coordinates ``coords`` [n_src, dim], the Hilbert-curve order of the referenced points."""
     dev = tables[0].device
     remap = pt.zeros(int(n_src), dtype=pt.int32, device=dev)
     for t in tables:
@@ -314,7 +324,16 @@ def referenced_rows(tables, n_src):
     n_used = C.c_int64(0)
     check(_lib.hip_lib().s3_compact_rows(_ptr(remap), int(n_src), _ptr(used), C.byref(n_used), _stream()),
           "s3_compact_rows")
-    return used[:n_used.value], remap
+    used = used[:n_used.value]
+    if coords is not None and n_used.value > 1:
+        # keep the referenced rows in Hilbert order of their coordinates instead of the CFD mesh's numbering
+        pts = pt.empty((n_used.value, int(coords.shape[1])), dtype=pt.float64, device=dev)
+        gather_rows(to_device(coords, pt.float64), used.contiguous(), pts)
+        ordered = pt.empty((n_used.value, 1), dtype=pt.int32, device=dev)
+        gather_rows(used.contiguous().reshape(-1, 1), spatial_order(pts), ordered)
+        used = ordered.reshape(-1)
+        check(_lib.hip_lib().s3_positions_of(_ptr(used), n_used.value, _ptr(remap), int(n_src), _stream()), "s3_positions_of")
+    return used, remap
 
 
 def remap_indices(idx, remap):

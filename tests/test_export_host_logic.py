@@ -63,7 +63,7 @@ def _cpu_ops():
                                             "supports": staticmethod(lambda k, d: False)})
     ops.padded_rows = lambda n_rows, row_len, dtype, dev, extra_lines=0: pt.empty((n_rows, row_len + 3), dtype=dtype)[:, :row_len]
 
-    def referenced_rows(tables, n_src):
+    def referenced_rows(tables, n_src, coords=None):
         used = np.unique(np.concatenate([t.numpy().ravel() for t in tables])).astype(np.int32)
         remap = np.full(n_src, -1, dtype=np.int32)
         remap[used] = np.arange(len(used), dtype=np.int32)

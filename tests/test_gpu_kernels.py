@@ -193,6 +193,14 @@ def test_referenced_rows_and_gather(ops):
         dst = ops.gather_rows(src, used, ops.padded_rows(len(want), row_len, dtype, "cuda"))
         assert pt.equal(dst, src[used.long()])
         assert pt.equal(ops.gather_rows(src, None, ops.padded_rows(n_src, row_len, dtype, "cuda")), src)
+    # with coordinates: the same rows, in Hilbert order of the points (a permutation; spatially consecutive)
+    pts = rng.random((n_src, 3))
+    tb2 = dev(b)
+    used_s, remap_s = ops.referenced_rows([dev(a), tb2], n_src, coords=pts)
+    us = used_s.cpu().numpy()
+    assert np.array_equal(np.sort(us), want) and np.array_equal(remap_s.cpu().numpy()[us], np.arange(len(want)))
+    step = np.linalg.norm(np.diff(pts[us], axis=0), axis=1).mean()
+    assert step < 0.25 * np.linalg.norm(np.diff(pts[want], axis=0), axis=1).mean()      # far shorter hops than in id order
     from sparsespatialsampling_amd._lib import S3HipError
     with pytest.raises(S3HipError):
         ops.referenced_rows([dev(np.array([[0, n_src]], dtype=np.int32))], n_src)

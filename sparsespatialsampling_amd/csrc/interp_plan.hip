@@ -169,6 +169,77 @@ interp_planned_short_kernel(const int32_t *__restrict__ perm, const int32_t *__r
     }
 }
 
+// Short rows, weights in registers (k <= KMAX): with at most four vectors per row every (cell, vector) pair of a tile has its
+// own lane, so the lane reads its cell's k weights / LDS positions straight from the plan-ordered streams into registers
+// (coalesced: consecutive cells are consecutive in the stream) while the row pieces are on their way -- no LDS round trip
+// for them, and LDS holds row data only (31 KiB: five workgroups per CU fit, registers allow four).
+template <typename T, int KMAX>
+__global__ void __launch_bounds__(256, KMAX <= 26 ? 4 : 3)      // 126 VGPRs at KMAX = 26; KMAX = 32 would spill at four waves
+interp_planned_short_reg_kernel(const int32_t *__restrict__ perm, const int32_t *__restrict__ tile_cell_begin,
+                                const int32_t *__restrict__ tile_row_begin, const int32_t *__restrict__ rows,
+                                const uint16_t *__restrict__ loc, const double *__restrict__ w /*plan order*/, int k,
+                                const T *__restrict__ data, int64_t row_len, int64_t in_stride, double *__restrict__ out,
+                                int64_t n_tiles, int64_t tiles_per_xcd, int vc) {
+    using V = typename Vec16<T>::type;
+    constexpr int EPV = Vec16<T>::N;
+    constexpr int BLOCK = 256;
+    constexpr int UN = 8;
+    extern __shared__ float4 lds_raw[];
+    V *s_data = reinterpret_cast<V *>(lds_raw);                  // [n_r][vc]
+
+    const int64_t b = blockIdx.x;
+    const int64_t tile = (b & 7) * tiles_per_xcd + (b >> 3);
+    if (tile >= n_tiles) return;
+    const int c_begin = tile_cell_begin[tile], n_c = tile_cell_begin[tile + 1] - c_begin;
+    const int r_begin = tile_row_begin[tile], n_r = tile_row_begin[tile + 1] - r_begin;
+    const bool even_rows = (row_len & 1) == 0;
+
+    // stage the rows: up to UN pieces per lane in flight (n_r * vc <= 496 * 4 < 256 * UN)
+    const int n_items = n_r * vc;
+    V reg[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+        const int item = min(u * BLOCK + (int)threadIdx.x, n_items - 1);
+        const int r = item / vc, v = item - r * vc;
+        reg[u] = *reinterpret_cast<const V *>(data + (int64_t)rows[r_begin + r] * in_stride + (int64_t)v * EPV);
+    }
+    // this lane's (cell, vector) pair and the cell's weights / positions
+    const int cl = min((int)threadIdx.x / vc, n_c - 1), v = (int)threadIdx.x - ((int)threadIdx.x / vc) * vc;
+    const bool has_item = (int)threadIdx.x < n_c * vc;
+    const double *wt = w + (int64_t)c_begin * k + cl;
+    const uint16_t *lt = loc + (int64_t)c_begin * k + cl;
+    double wr[KMAX];
+    int pr[KMAX];
+#pragma unroll
+    for (int m = 0; m < KMAX; ++m) {
+        const int mm = m < k ? m : 0;
+        wr[m] = wt[(int64_t)mm * n_c];
+        pr[m] = lt[(int64_t)mm * n_c];
+    }
+    const int64_t cell = perm[c_begin + cl];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+        const int item = u * BLOCK + (int)threadIdx.x;
+        if (item < n_items) s_data[item] = reg[u];               // [r][v] with pitch vc == item
+    }
+    __syncthreads();
+    if (!has_item) return;
+    double acc[EPV];
+#pragma unroll
+    for (int i = 0; i < EPV; ++i) acc[i] = 0.0;
+#pragma unroll
+    for (int m = 0; m < KMAX; ++m) {
+        if (m < k) {
+            const V a = s_data[pr[m] * vc + v];
+            const T *ae = reinterpret_cast<const T *>(&a);
+#pragma unroll
+            for (int i = 0; i < EPV; ++i) acc[i] = fma(wr[m], (double)ae[i], acc[i]);
+        }
+    }
+    const int64_t col = (int64_t)v * EPV;
+    store_piece<EPV>(out + cell * row_len + col, acc, row_len - col, even_rows);
+}
+
 template <typename T, int TC>
 __global__ void __launch_bounds__(TC * 4, 2)  // 226 VGPRs: two waves per SIMD
 interp_planned_kernel(const int32_t *__restrict__ perm, const int32_t *__restrict__ tile_cell_begin,
@@ -315,6 +386,23 @@ static int launch_planned(const s3_interp_plan *p, const void *data, int64_t row
     S3_REQUIRE(gx < ((int64_t)1 << 31), "s3_interp_planned: too many tiles");
     if ((row_len + EPV - 1) / EPV <= s3::short_row_vecs() && p->tc == 64) {
         const int vpr = (int)((row_len + EPV - 1) / EPV);
+        if (vpr <= 4 && p->ucap * vpr <= 256 * 8 && p->k <= 32 && !getenv("S3_SHORT_LDS_WEIGHTS")) {
+            // one lane per (cell, vector) pair, weights in registers
+            const size_t lds = (size_t)p->ucap * vpr * 16;
+#define S3_LAUNCH_SHORT_REG(KM)                                                                                                  \
+    do {                                                                                                                         \
+        auto kern = interp_planned_short_reg_kernel<T, KM>;                                                                      \
+        kern<<<dim3((unsigned)gx), 256, lds, st>>>(p->perm, p->tile_cell_begin, p->tile_row_begin, p->rows, p->loc, p->wp, p->k, \
+                                                   static_cast<const T *>(data), row_len, in_stride, out, p->n_tiles,            \
+                                                   tiles_per_xcd, vpr);                                                          \
+    } while (0)
+            if (p->k <= 8) S3_LAUNCH_SHORT_REG(8);
+            else if (p->k <= 26) S3_LAUNCH_SHORT_REG(26);
+            else S3_LAUNCH_SHORT_REG(32);
+#undef S3_LAUNCH_SHORT_REG
+            S3_LAUNCH_CHECK();
+            return S3_OK;
+        }
         const int pitch = vpr < 8 ? vpr : 8;
         const size_t lds = (size_t)p->ucap * pitch * 16 + (size_t)p->k * p->tc * (sizeof(double) + sizeof(uint16_t)) +
                            (size_t)p->tc * sizeof(int32_t);

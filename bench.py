@@ -168,7 +168,7 @@ def recorded_traffic(workload_key):
     """HBM bytes per launch of the dominant kernel as RECORDED in the committed PMC passes (profiles/rNN/summary.json:
     FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE from separate rocprofv3 --pmc runs of this
     command); (None, None) when no pass was recorded for this workload"""
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "summary.json")), reverse=True):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "*", "summary.json")), reverse=True):
         try:
             rec = json.load(open(f))
         except (OSError, ValueError):

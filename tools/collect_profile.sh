@@ -1,23 +1,24 @@
 #!/bin/bash
-# Runs ON THE GPU BOX (via gpurun) from the repo root: the rocprofv3 passes behind profiles/rNN/.
-#   gpurun --timeout 900 -- 'bash tools/collect_profile.sh r01'
+# Runs ON THE GPU BOX (via gpurun) from the repo root: the rocprofv3 passes behind profiles/<tag>/<name>/.
+#   gpurun --timeout 900 -- 'bash tools/collect_profile.sh r02 cylinder3D'                        (default bench command)
+#   gpurun --timeout 900 -- 'bash tools/collect_profile.sh r02 box5e7 --workload box5e7'          (any bench arguments)
 # 1) bench.py as the driver runs it (JSON line), 2) --kernel-trace --stats of the same command, 3) one --pmc pass per
-# counter (FETCH_SIZE, WRITE_SIZE; kernel-trace only, as gpurun requires).  Raw output -> gpurun_out/prof_<tag>/;
-# tools/summarize_profile.py turns it into profiles/<tag>/ afterwards (in the dev container).
+# counter (FETCH_SIZE, WRITE_SIZE; kernel-trace only, as gpurun requires).  Raw output -> gpurun_out/prof_<tag>/<name>/;
+# tools/summarize_profile.py turns it into profiles/<tag>/<name>/ afterwards (in the dev container).
 set -o pipefail
-tag=${1:-r01}
+tag=${1:-r02}; name=${2:-cylinder3D}; shift 2
 root=$(pwd)
-out=$root/gpurun_out/prof_$tag
+out=$root/gpurun_out/prof_$tag/$name
 mkdir -p "$out"
 export TMPDIR=/tmp
-python bench.py --steps 20 --warmup 3 > "$out/bench.json" 2> "$out/bench.err" || exit 1
+python bench.py --steps 20 --warmup 3 "$@" > "$out/bench.json" 2> "$out/bench.err" || exit 1
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python "$root/bench.py" --steps 20 --warmup 3 --no-cpu-baseline > "$out/stats.log" 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python "$root/bench.py" --steps 20 --warmup 3 --no-cpu-baseline "$@" > "$out/stats.log" 2>&1 || exit 1
 for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$out/pmc_$c" -- python "$root/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > "$out/pmc_$c.log" 2>&1 || exit 1
+    rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$out/pmc_$c" -- python "$root/bench.py" --steps 3 --warmup 1 --no-cpu-baseline "$@" > "$out/pmc_$c.log" 2>&1 || exit 1
 done
 cd "$root"
-# keep what travels back small: per-kernel stats + the counter rows of the dominant kernel
+# keep what travels back small: per-kernel stats + the counter rows of the interpolation kernels
 find "$out" -name "*kernel_stats.csv" -exec cp {} "$out/kernel_stats.csv" \;
 for c in FETCH_SIZE WRITE_SIZE; do
     f=$(find "$out/pmc_$c" -name "*counter_collection.csv" | head -n 1)
@@ -27,7 +28,8 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 with open(sys.argv[2], "w") as f:
     f.write("Kernel_Name,Counter_Name,Counter_Value\n")
     for r in rows:
-        f.write('"%s",%s,%f\n' % (r["Kernel_Name"][:80], r["Counter_Name"], float(r["Counter_Value"])))
+        if "interp" in r["Kernel_Name"]:
+            f.write('"%s",%s,%f\n' % (r["Kernel_Name"][:80], r["Counter_Name"], float(r["Counter_Value"])))
 PY
 done
 rm -rf "$out/stats" "$out/pmc_FETCH_SIZE" "$out/pmc_WRITE_SIZE"

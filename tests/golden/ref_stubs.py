@@ -134,7 +134,10 @@ def install():
     # the name ``sparseSpatialSampling`` must resolve to the REAL reference here, never to the import-name alias of this
     # repository (compat/sparseSpatialSampling): a generator or fuzzer that compared the package with itself would pin nothing
     import importlib.util
+    import os
     spec = importlib.util.find_spec("sparseSpatialSampling")
+    if not os.path.isdir(REFERENCE_ROOT):
+        return                       # no reference on this machine (GPU box): nothing to import, nothing to confuse
     if spec is None or not str(spec.origin).startswith(REFERENCE_ROOT + "/"):
         raise ImportError(f"'sparseSpatialSampling' resolves to {getattr(spec, 'origin', None)}, not to the reference under "
                           f"{REFERENCE_ROOT}")

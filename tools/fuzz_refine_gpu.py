@@ -6,13 +6,15 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tools"))
 import logging
+import types
 import numpy as np
 import torch as pt
 
-import fuzz_refine_vs_reference as gen
+import inputs                                               # tests/golden/inputs.py: the generators the reference fuzz uses
+gen = types.SimpleNamespace(bodies=inputs.random_bodies, build=inputs.build_geometries)
 from sparsespatialsampling_amd import geometry, s_cube
 from oracle_backend import OracleTreeBackend
 

@@ -69,8 +69,10 @@ struct PySet {
         while (newsize <= minused) newsize <<= 1;
         int64_t *nt = alloc(newsize);
         const int64_t nm = newsize - 1;
-        for (int64_t i = 0; i <= mask; ++i)
+        for (int64_t i = 0; i <= mask; ++i) {
+            if (i + 16 <= mask && table[i + 16] >= 0) __builtin_prefetch(&nt[(uint64_t)table[i + 16] & (uint64_t)nm]);
             if (table[i] >= 0) insert_clean(nt, nm, table[i]);
+        }
         std::free(table);
         table = nt;
         mask = nm;
@@ -129,6 +131,8 @@ struct PySet {
         --used;
     }
 
+    void prefetch(int64_t key) const { __builtin_prefetch(&table[(uint64_t)key & (uint64_t)mask]); }
+
     void merge(const PySet &o) {
         if (&o == this || o.used == 0) return;
         if ((fill + o.used) * 5 >= mask * 3) resize((used + o.used) * 2);
@@ -138,14 +142,21 @@ struct PySet {
             used = o.used;
             return;
         }
+        // (the first probe of an element some slots ahead is prefetched: a 10^7-entry table does not fit any cache, and a
+        // rebuild in the middle of the loop only makes the prefetches useless, not wrong)
+        constexpr int64_t AHEAD = 16;
         if (fill == 0) {
             fill = used = o.used;
-            for (int64_t i = 0; i <= o.mask; ++i)
+            for (int64_t i = 0; i <= o.mask; ++i) {
+                if (i + AHEAD <= o.mask && o.table[i + AHEAD] >= 0) prefetch(o.table[i + AHEAD]);
                 if (o.table[i] >= 0) insert_clean(table, mask, o.table[i]);
+            }
             return;
         }
-        for (int64_t i = 0; i <= o.mask; ++i)
+        for (int64_t i = 0; i <= o.mask; ++i) {
+            if (i + AHEAD <= o.mask && o.table[i + AHEAD] >= 0) prefetch(o.table[i + AHEAD]);
             if (o.table[i] >= 0) add(o.table[i]);
+        }
     }
 
     void difference_update(const PySet &o) {
@@ -156,8 +167,10 @@ struct PySet {
             fill = used = 0;
             return;
         }
-        for (int64_t i = 0; i <= o.mask; ++i)
+        for (int64_t i = 0; i <= o.mask; ++i) {
+            if (i + 16 <= o.mask && o.table[i + 16] >= 0) prefetch(o.table[i + 16]);
             if (o.table[i] >= 0) discard(o.table[i]);
+        }
         if (fill - used <= mask / 4) return;
         resize(used > 50000 ? used * 2 : used * 4);
     }
@@ -189,6 +202,7 @@ int s3set_update_ids(void *h, const int64_t *ids, int64_t n) try {
     PySet *s = static_cast<PySet *>(h);
     for (int64_t i = 0; i < n; ++i) {
         if (ids[i] < 0) return -2;
+        if (i + 16 < n && ids[i + 16] >= 0) s->prefetch(ids[i + 16]);
         s->add(ids[i]);
     }
     return 0;

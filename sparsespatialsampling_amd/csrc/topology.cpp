@@ -221,6 +221,7 @@ struct Topo {
     // finalize() results
     std::vector<int64_t> face_ids;    // after finalize(): old node id -> new node id (-1 = dropped)
     int64_t n_leaf = 0, n_unique = 0;
+    std::vector<int64_t> chunk_first_row;   // after finalize(): output row of the first leaf of every 2^16-cell chunk
 
     int64_t n_used = 0;               // cells created so far; the cell tables are sized to their capacity
     double half_width[64], quarter_width[64];   // (0.5 * width) / 2^level, (0.25 * width) / 2^level
@@ -730,6 +731,49 @@ int64_t s3t_refine(void *h, const int64_t *parents, int64_t n, int relink) try {
 
 // cell.parent.children = _assign_neighbors(cell.parent, children=cell.parent.children)   (s_cube.py:609, 834, 494)
 static void relink_parents(Topo *t, const int64_t *cells, int64_t n) {
+    if (t->pool && n >= 4 * t->par_min) {
+        // The refresh of a parent p reads p's own neighbour row and rewrites the rows of p's children.  Two listed parents
+        // interact only when one is the parent of the other (the refresh of g rewrites the row that the refresh of its
+        // child p reads): those few are replayed sequentially in list order, occurrence by occurrence; all the others
+        // are independent of everything in the list and are refreshed once each, in parallel.
+        std::vector<int32_t> par((size_t)n);
+        std::vector<uint8_t> dep((size_t)n, 0);
+        int32_t *stamp = t->batch_pos.data();                      // -1 outside batches; holds the winning occurrence here
+        t->pool->run(n, 2048, [&](int64_t b, int64_t e) {
+            for (int64_t i = b; i < e; ++i) {
+                if (i + 8 < e) __builtin_prefetch(&t->parent[cells[i + 8]]);
+                const int32_t p = t->parent[cells[i]];
+                par[i] = p;
+                if (p < 0) continue;
+                int32_t expected = -1;
+                __atomic_compare_exchange_n(&stamp[p], &expected, (int32_t)i, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED);
+            }
+        });
+        t->pool->run(n, 2048, [&](int64_t b, int64_t e) {
+            for (int64_t i = b; i < e; ++i) {
+                const int32_t p = par[i];
+                if (p < 0) continue;
+                const int32_t g = t->parent[p];
+                if (g >= 0 && stamp[g] >= 0) {
+                    __atomic_store_n(&dep[stamp[p]], (uint8_t)1, __ATOMIC_RELAXED);
+                    __atomic_store_n(&dep[stamp[g]], (uint8_t)1, __ATOMIC_RELAXED);
+                }
+            }
+        });
+        for (int64_t i = 0; i < n; ++i)                            // the interacting ones, exactly as the list says
+            if (par[i] >= 0 && dep[stamp[par[i]]]) t->assign_neighbors(par[i]);
+        t->pool->run(n, 256, [&](int64_t b, int64_t e) {
+            for (int64_t i = b; i < e; ++i) {
+                if (i + 2 < e && par[i + 2] >= 0) __builtin_prefetch(&t->nb[(size_t)par[i + 2] * t->nnb]);
+                if (par[i] >= 0 && stamp[par[i]] == i && !dep[i]) t->assign_neighbors(par[i]);
+            }
+        });
+        t->pool->run(n, 2048, [&](int64_t b, int64_t e) {
+            for (int64_t i = b; i < e; ++i)
+                if (par[i] >= 0) __atomic_store_n(&stamp[par[i]], (int32_t)-1, __ATOMIC_RELAXED);
+        });
+        return;
+    }
     // stays sequential: a listed cell's parent may itself be a child of another listed cell's parent, whose refresh
     // rewrites the row this one reads -- the result depends on the order of the list.  Software prefetch runs ahead:
     // the parent id eight positions ahead, its neighbour row four ahead, the neighbours' first-child entries two ahead
@@ -876,25 +920,48 @@ int s3t_check_nb(void *h, int64_t cell, int64_t *out) {
 
 // _resort_nodes_and_indices_of_grid, s_cube.py:734-772 (+ 1695-1736).  Returns the number of leaf cells; results
 // are read through s3t_face_ids / s3t_unique_nodes.
+// run fn(begin, end) over [0, n) on the engine's pool (or inline without one)
+static void for_chunks(Topo *t, int64_t n, int64_t grain, const std::function<void(int64_t, int64_t)> &fn) {
+    if (t->pool) t->pool->run(n, grain, fn);
+    else if (n > 0) fn(0, n);
+}
+
 int64_t s3t_finalize(void *h, int64_t *n_unique_nodes) try {
     Topo *t = static_cast<Topo *>(h);
     if (t->wait_idle() != 0) return -1;
     const int nch = t->nch;
     const int64_t nc = t->n_cells(), nn = t->n_nodes();
+    constexpr int64_t CH = 1 << 16;                                 // cells per chunk
+    const int64_t n_chunks = (nc + CH - 1) / CH;
     std::vector<uint8_t> used(nn, 0);
-    int64_t lo = INT64_MAX, hi = -1, n_leaf = 0;
-    for (int64_t c = 0; c < nc; ++c) {
-        if (t->first_child[c] != LEAF) continue;
-        ++n_leaf;
-        const int64_t *ni = &t->node_idx[(size_t)c * nch];
-        for (int s = 0; s < nch; ++s) {
-            const int64_t v = ni[s];
-            used[v] = 1;
-            if (v < lo) lo = v;
-            if (v > hi) hi = v;
+    std::vector<int64_t> chunk_leaf((size_t)n_chunks + 1, 0), chunk_lo((size_t)n_chunks, INT64_MAX), chunk_hi((size_t)n_chunks, -1);
+    for_chunks(t, n_chunks, 1, [&](int64_t cb, int64_t ce) {
+        for (int64_t k = cb; k < ce; ++k) {
+            int64_t lo = INT64_MAX, hi = -1, leaves = 0;
+            for (int64_t c = k * CH; c < std::min(nc, (k + 1) * CH); ++c) {
+                if (t->first_child[c] != LEAF) continue;
+                ++leaves;
+                const int64_t *ni = &t->node_idx[(size_t)c * nch];
+                for (int s = 0; s < nch; ++s) {
+                    const int64_t v = ni[s];
+                    __atomic_store_n(&used[v], (uint8_t)1, __ATOMIC_RELAXED);    // several chunks may mark the same node
+                    if (v < lo) lo = v;
+                    if (v > hi) hi = v;
+                }
+            }
+            chunk_leaf[k + 1] = leaves;
+            chunk_lo[k] = lo;
+            chunk_hi[k] = hi;
         }
+    });
+    int64_t lo = INT64_MAX, hi = -1;
+    for (int64_t k = 0; k < n_chunks; ++k) {
+        chunk_leaf[k + 1] += chunk_leaf[k];                            // first output row of every chunk
+        lo = std::min(lo, chunk_lo[k]);
+        hi = std::max(hi, chunk_hi[k]);
     }
-    t->n_leaf = n_leaf;
+    t->n_leaf = chunk_leaf[n_chunks];
+    t->chunk_first_row = chunk_leaf;
     // unused = ids in {0..2^d-1} U [min, max] that no leaf references; everything else keeps a slot (reference quirk)
     t->face_ids.assign((size_t)nn, -1);                 // old node id -> new node id
     int64_t counter = 0;
@@ -904,7 +971,7 @@ int64_t s3t_finalize(void *h, int64_t *n_unique_nodes) try {
     }
     t->n_unique = counter;
     *n_unique_nodes = counter;
-    return n_leaf;
+    return t->n_leaf;
 } catch (...) {
     return -1;
 }
@@ -916,32 +983,46 @@ void s3t_export_grid(void *h, void *faces_out, int as32, double *nodes_out) {
     const int nch = t->nch, dim = t->dim;
     const int64_t nc = t->n_cells(), nn = t->n_nodes();
     const int64_t *map = t->face_ids.data();
-    int64_t row = 0;
-    for (int64_t c = 0; c < nc; ++c) {
-        if (t->first_child[c] != LEAF) continue;
-        const int64_t *ni = &t->node_idx[(size_t)c * nch];
-        if (as32) {
-            int32_t *o = static_cast<int32_t *>(faces_out) + row * nch;
-            for (int s = 0; s < nch; ++s) o[s] = (int32_t)map[ni[s]];
-        } else {
-            int64_t *o = static_cast<int64_t *>(faces_out) + row * nch;
-            for (int s = 0; s < nch; ++s) o[s] = map[ni[s]];
+    constexpr int64_t CH = 1 << 16;
+    const int64_t n_chunks = (nc + CH - 1) / CH;
+    for_chunks(t, n_chunks, 1, [&](int64_t cb, int64_t ce) {
+        for (int64_t k = cb; k < ce; ++k) {
+            int64_t row = t->chunk_first_row[k];
+            for (int64_t c = k * CH; c < std::min(nc, (k + 1) * CH); ++c) {
+                if (t->first_child[c] != LEAF) continue;
+                const int64_t *ni = &t->node_idx[(size_t)c * nch];
+                if (as32) {
+                    int32_t *o = static_cast<int32_t *>(faces_out) + row * nch;
+                    for (int s = 0; s < nch; ++s) o[s] = (int32_t)map[ni[s]];
+                } else {
+                    int64_t *o = static_cast<int64_t *>(faces_out) + row * nch;
+                    for (int s = 0; s < nch; ++s) o[s] = map[ni[s]];
+                }
+                ++row;
+            }
         }
-        ++row;
-    }
-    for (int64_t i = 0; i < nn; ++i)
-        if (map[i] >= 0)
-            for (int j = 0; j < dim; ++j) nodes_out[(size_t)map[i] * dim + j] = t->nodes[(size_t)i * dim + j];
+    });
+    for_chunks(t, nn, 1 << 16, [&](int64_t b, int64_t e) {
+        for (int64_t i = b; i < e; ++i)
+            if (map[i] >= 0)
+                for (int j = 0; j < dim; ++j) nodes_out[(size_t)map[i] * dim + j] = t->nodes[(size_t)i * dim + j];
+    });
 }
 
 // centres / levels of the listed cells (the leaves in the host's set order), gathered natively
 void s3t_gather_cells(void *h, const int64_t *ids, int64_t n, double *centers_out, int64_t *levels_out) {
     Topo *t = static_cast<Topo *>(h);
     t->wait_idle();
-    for (int64_t i = 0; i < n; ++i) {
-        for (int j = 0; j < t->dim; ++j) centers_out[i * t->dim + j] = t->center[(size_t)ids[i] * t->dim + j];
-        levels_out[i] = t->level[ids[i]];
-    }
+    for_chunks(t, n, 1 << 15, [&](int64_t b, int64_t e) {
+        for (int64_t i = b; i < e; ++i) {
+            if (i + 8 < e) {
+                __builtin_prefetch(&t->center[(size_t)ids[i + 8] * t->dim]);
+                __builtin_prefetch(&t->level[ids[i + 8]]);
+            }
+            for (int j = 0; j < t->dim; ++j) centers_out[i * t->dim + j] = t->center[(size_t)ids[i] * t->dim + j];
+            levels_out[i] = t->level[ids[i]];
+        }
+    });
 }
 
 // geometric self-check of the node rule tables: every (slot, nb_node) candidate and every sibling copy must name the

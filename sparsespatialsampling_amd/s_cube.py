@@ -482,7 +482,9 @@ class SamplingTree(object):
             self._update_leaf_cells(all_parents, all_children)
             self._current_min_level += 1
             self._current_max_level += 1
-            self._remove_invalid_cells(self._new_set(range(first, first + n_new)), _batch=(first, n_new))
+            # set(range(first, first + n_new)) of the reference == all_children (same insertions into an empty set, and
+            # merging it into the leaf set did not touch it): its iteration order is reused instead of rebuilt
+            self._remove_invalid_cells(all_children, _batch=(first, n_new))
         logger.info("Finished uniform refinement.")
         self._times["t_end_uniform"] = time()
 
@@ -496,6 +498,7 @@ class SamplingTree(object):
         all_parents.update(order.tolist() if self._new_set is set else order)
         all_children.update(range(first, first + n_new))
         self._update_leaf_cells(all_parents, all_children)
+        self._new_children = all_children          # == set(range(first, first + n_new)), reused by the callers
         return first, n_new
 
     def _remove_invalid_cells(self, _refined_cells: set, _refine_geometry: bool = False,
@@ -571,7 +574,7 @@ class SamplingTree(object):
                 self._topo_engine.submit_relink_parent_of(_leaf_cells_sorted)
 
             first, n_new = self._refine_cells(to_refine)
-            self._remove_invalid_cells(self._new_set(range(first, first + n_new)), _batch=(first, n_new))
+            self._remove_invalid_cells(self._new_children, _batch=(first, n_new))
 
             if self._n_cells_max is None:
                 self._compute_captured_metric()
@@ -660,7 +663,7 @@ class SamplingTree(object):
                     self._topo_engine.submit_relink_parent_of(cells)
 
                 first, n_new = self._refine_cells(to_refine)
-                _idx_new = self._new_set(range(first, first + n_new))
+                _idx_new = self._new_children
                 self._remove_invalid_cells(_idx_new, _geometry_no=g, _batch=(first, n_new))
 
                 # among the new *valid* cells, which ones still touch the geometry?  ({i for i in _idx_new if ...}: a

@@ -34,18 +34,16 @@ for n in ("mask", "refine_batch", "topn", "sumsq", "commit"):
 for n in ("_remove_invalid_cells", "_refine_cells", "_compute_captured_metric", "_refine_uniform", "_refine_geometries", "_resort_nodes_and_indices_of_grid"):
     wrap(s_cube.SamplingTree, n, "tree." + n)
 
-cfg = dict(bench.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "cylinder3D_Re3900"])
-x, metric = bench.synthetic_cylinder3d(cfg)
-geos = [geometry.CubeGeometry("domain", True, cfg["lo"], [float(v) for v in cfg["hi"]]),
-        geometry.CylinderGeometry3D("cylinder", False, [(0.8, 1.0, -1.0), (0.8, 1.0, 1.0)], 0.05, refine=True)]
+name = sys.argv[1] if len(sys.argv) > 1 else "cylinder3D_Re3900"
+x, metric, geos, tree_kw = bench.build_case(name, dict(bench.WORKLOADS[name]), geometry)
 for rep in range(2):
     acc.clear()
-    tree = s_cube.SamplingTree(pt.from_numpy(x), pt.from_numpy(metric), geos, uniform_level=cfg["uniform_levels"], min_metric=cfg["min_metric"])
+    tree = s_cube.SamplingTree(pt.from_numpy(x), pt.from_numpy(metric), geos, **tree_kw)
     pt.cuda.synchronize()
     t0 = time.perf_counter()
     tree.refine()
     pt.cuda.synchronize()
-    print(f"rep {rep}: refine {time.perf_counter() - t0:.4f} s", {k: round(v, 4) for k, v in tree.data_final_mesh.items() if k.startswith("t_")})
+    print(f"rep {rep}: refine {time.perf_counter() - t0:.4f} s", {k: (None if v is None else round(v, 4)) for k, v in tree.data_final_mesh.items() if k.startswith("t_")})
     import ctypes as C
     st = np.zeros(12)
     tree._topo_engine._lib.s3t_stats(tree._topo_engine._h, st.ctypes.data_as(C.c_void_p))

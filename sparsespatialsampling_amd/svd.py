@@ -87,3 +87,31 @@ def compute_svd(data_matrix: pt.Tensor, cell_area: pt.Tensor, rank: int = None) 
         u = u.reshape(n_cells, shape[1], r)
     s, v = s.to(x2.device), v.to(x2.device)
     return (s.cpu(), u.cpu(), v.cpu()) if on_host else (s, u, v)
+
+
+def write_svd_s_cube_to_file(field_names, load_dir: str, file_name: str, new_file: bool, n_modes: int = None, rank=None,
+                             t_start=0) -> None:
+    """weighted SVD of exported fields, written next to them as ``<file_name>_<field>_svd.h5`` + XDMF (signature and file
+    contents of the reference's ``utils.write_svd_s_cube_to_file``, utils.py:349-413): the grid, ``constant/mode_<i>`` for
+    the first ``n_modes`` modes, ``constant/V``, ``constant/s`` and ``constant/cell_area``.  Snapshots with a write time
+    >= ``t_start`` are used, in ascending time."""
+    import logging
+    from .data import Dataloader, Datawriter
+    log = logging.getLogger(__name__)
+    for name in ([field_names] if isinstance(field_names, str) else list(field_names)):
+        log.info(f"Performing SVD for field {name}.")
+        loader = Dataloader(load_dir, f"{file_name}_{name}.h5" if new_file else f"{file_name}.h5", dtype=pt.float64)
+        times = sorted((t for t in loader.write_times if float(t) >= t_start), key=float)
+        s, u, v = compute_svd(loader.load_snapshot(name, times), loader.weights, rank)
+        available = int(u.shape[-1])
+        count = available if n_modes is None else n_modes
+        if count > available:
+            log.warning(f"Number of modes to write is set to {count}, but found only {available} modes to write.")
+            count = available
+        writer = Datawriter(load_dir, f"{file_name}_{name}_svd.h5")
+        writer.write_grid(loader)
+        for i in range(count):
+            writer.write_data(f"mode_{i + 1}", group="constant", data=u[..., i])
+        for key, values in (("V", v), ("s", s), ("cell_area", loader.weights)):
+            writer.write_data(key, group="constant", data=values)
+        writer.write_xdmf_file()

@@ -153,6 +153,20 @@ def test_export_to_real_hdf5_and_back_gpu(tmp_path):
     xdmf = open(os.path.join(str(tmp_path), "case.xdmf")).read()
     assert xdmf.count("<Time Value=") == n_t and f'case.h5:/data/{times[-1]}/U_vertices' in xdmf
 
+    # downstream: weighted SVD of the exported fields written next to them (reference utils.py:349-413)
+    from sparsespatialsampling_amd import svd
+    svd.write_svd_s_cube_to_file(["p", "U"], str(tmp_path), "case", new_file=False, n_modes=3, rank=5)
+    for field, comps in (("p", 1), ("U", 2)):
+        with h5io.open_h5(os.path.join(str(tmp_path), f"case_{field}_svd.h5"), "r") as f:
+            assert f.keys("constant") == ["V", "cell_area", "mode_1", "mode_2", "mode_3", "s"]
+            mode, s_val, v_mat, area = f.read("constant/mode_1"), f.read("constant/s"), f.read("constant/V"), f.read("constant/cell_area")
+            assert mode.shape == ((nc,) if comps == 1 else (nc, comps)) and s_val.shape == (5,) and v_mat.shape == (n_t, 5)
+        data = pt.from_numpy(ref_p[:, 0, :] if comps == 1 else ref_u)
+        xw = (data - data.mean(-1, keepdim=True)) * pt.from_numpy(area).sqrt().reshape((-1,) + (1,) * (data.dim() - 1))
+        s_ref = pt.linalg.svdvals(xw.reshape(-1, n_t))
+        np.testing.assert_allclose(s_val, s_ref[:5].numpy(), rtol=1e-8)
+        assert 'Attribute Name="mode_2"' in open(os.path.join(str(tmp_path), f"case_{field}_svd.xdmf")).read()
+
 
 def _naca_polygon(n=120, chord=1.0, t=0.12):
     """closed NACA-00xx outline (the OAT15-like body of BASELINE config C2)"""

@@ -4,8 +4,8 @@ End-to-end S^3 run on a synthetic stand-in for the reference's cylinder2D_Re100 
 
     python examples/s3_for_synthetic_cylinder2D.py [save_path]
 
-Only the import lines differ from a script written against the reference.  Needs an MI355X; the HDF5/XDMF export needs
-h5py (without it the script stops after the interpolation).
+Only the import lines differ from a script written against the reference.  Needs an MI355X; the HDF5/XDMF files are
+written by the package's own sink (libs3h5.so on the HDF5 C library; h5py is used when that library is missing).
 """
 import sys
 from os.path import abspath, dirname, join
@@ -45,5 +45,9 @@ if __name__ == "__main__":
     try:
         export.export(coord, field.unsqueeze(1), "p")
         print(f"wrote {join(save_path, save_name)}.h5 / .xdmf")
-    except ModuleNotFoundError as e:          # h5py missing: show the interpolated field instead
+        # weighted SVD of the exported field (reference utils.write_svd_s_cube_to_file): modes next to the data
+        from sparsespatialsampling_amd.svd import write_svd_s_cube_to_file
+        write_svd_s_cube_to_file("p", save_path, save_name, export.new_file, n_modes=10, rank=20)
+        print(f"wrote {join(save_path, save_name)}_p_svd.h5 / .xdmf")
+    except ImportError as e:                  # neither libs3h5.so nor h5py: show the interpolated field instead
         print(f"{e}; interpolated field: {tuple(export._interpolated_fields.centers.shape)}")

@@ -8,7 +8,7 @@ the fields are exported batch by batch afterwards.
 
 Differences to a script written against the reference: the import lines, and the metric (temporal standard deviation)
 comes from ``metrics.temporal_moments`` -- one streaming pass per batch on the GPU, merged across batches -- instead of
-torch on the CPU.  Needs an MI355X; the HDF5/XDMF export needs h5py (without it the script stops after the interpolation).
+torch on the CPU.  Needs an MI355X; the HDF5/XDMF files are written by the package's own sink (libs3h5.so).
 """
 import sys
 from os.path import abspath, dirname, join
@@ -71,5 +71,5 @@ if __name__ == "__main__":
         for t0 in range(0, n_snapshots, batch):
             export.export(coord, snapshots(coord, t0, t0 + batch), "p", n_snapshots_total=n_snapshots)
         print(f"wrote {join(save_path, 'metric_0.75')}.h5 / .xdmf in {time() - t_start:.2f} s")
-    except ModuleNotFoundError as e:          # h5py missing: show the interpolated field instead
+    except ImportError as e:                  # neither libs3h5.so nor h5py: show the interpolated field instead
         print(f"{e}; interpolated batch: {tuple(export._interpolated_fields.centers.shape)}")

@@ -628,3 +628,27 @@ print("rccl ok")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     run = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert run.returncode == 0 and "rccl ok" in run.stdout, (run.stdout + run.stderr)[-3000:]
+
+
+def test_sumsq_blocks_independent_of_the_split(ops):
+    """the captured-metric numerator (s_cube.py:317-336) as block sums: however the 1024-cell blocks are dealt to ranks
+    (1, 2, 3, 8 shares, as parallel.batch_slice deals them), the gathered partials and the ordered sum have the same bits"""
+    from sparsespatialsampling_amd import parallel
+    rng = np.random.default_rng(4)
+    n = 1_234_567
+    metric = dev(rng.random(n) * 10.0 ** rng.integers(-3, 4, n))
+    leaf = dev((rng.random(n) < 0.7).astype(np.uint8))
+    n_blocks = -(-n // parallel.SUMSQ_BLOCK)
+    results = []
+    for world in (1, 2, 3, 8):
+        chunk = parallel.batch_slice(n_blocks, 0, world)[0]
+        partial = pt.zeros(chunk * world, dtype=pt.float64, device="cuda")
+        for rank in range(world):                          # every "rank" fills its share of the same array = the all-gather
+            _, b, e = parallel.batch_slice(n_blocks, rank, world)
+            ops.sumsq_blocks(metric, leaf, n, b, e, partial)
+        out = pt.empty(1, dtype=pt.float64, device="cuda")
+        ops.sum_ordered(partial, n_blocks, out)
+        results.append(float(out.item()))
+    assert len(set(results)) == 1
+    m, l = metric.cpu().numpy(), leaf.cpu().numpy().astype(bool)
+    assert abs(results[0] - float((m[l] ** 2).sum())) <= 1e-12 * results[0]

@@ -23,7 +23,7 @@ print(f"weighted_gram N={n} T={t}: {ms:.2f} ms = {flops_alg / ms / 1e9:.1f} TFLO
 t0 = time.perf_counter()
 s, u, v = svd.compute_svd(x, area, rank=50)
 pt.cuda.synchronize()
-print(f"compute_svd rank 50: {time.perf_counter() - t0:.3f} s (mean + Gram + eigh on the host + mode GEMM), s[0:3] = {s[:3].tolist()}")
+print(f"compute_svd rank 50: {time.perf_counter() - t0:.3f} s (mean + Gram + eigh + mode GEMM), s[0:3] = {s[:3].tolist()}")
 t0 = time.perf_counter()
 xw = (x - x.mean(-1, keepdim=True)) * area.sqrt()[:, None]
 gref = xw.T @ xw

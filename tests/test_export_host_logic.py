@@ -241,3 +241,41 @@ def test_async_batches_and_duplicates(tmp_path):
     assert len(got) == 31
     for t, v in want.items():
         assert np.array_equal(got[f"data/{t}/U_center"], v)
+
+
+def test_append_and_file_per_field(export_mod, tmp_path):
+    """the export state machine's other modes on real files: ``append_existing`` adds a field to a finished file (grid and
+    constants are not rewritten, reference export.py:86-92), ``write_new_file_for_each_field`` gives one file per field"""
+    rng = np.random.default_rng(3)
+    n, t_total = 300, 4
+    coords = rng.random((n, 2))
+    times = [str(0.5 * i) for i in range(t_total)]
+    p = rng.standard_normal((n, 1, t_total)).astype(np.float32)
+    u = rng.standard_normal((n, 2, t_total)).astype(np.float32)
+    idx, dist = orc.knn(coords, _scube(tmp_path).centers.numpy(), 8)
+    w = orc.idw_weights(dist)
+
+    s = _scube(tmp_path)
+    s.metric = pt.from_numpy(rng.random(n))
+    export_mod.ExportData(s, write_times=times).export(pt.from_numpy(coords), pt.from_numpy(p), "p")
+    s2 = _scube(tmp_path)
+    s2.metric = pt.from_numpy(rng.random(n))
+    ex = export_mod.ExportData(s2, write_times=times, append_existing=True)
+    ex.export(pt.from_numpy(coords), pt.from_numpy(u[:, :, :2]), "U", n_snapshots_total=t_total)
+    ex.export(pt.from_numpy(coords), pt.from_numpy(u[:, :, 2:]), "U", n_snapshots_total=t_total)
+    h5 = dump(os.path.join(str(tmp_path), "case.h5"))
+    ref_p, ref_u = orc.interp(w, idx, p), orc.interp(w, idx, u)
+    for i, t in enumerate(times):
+        np.testing.assert_allclose(h5[f"data/{t}/p_center"], ref_p[:, 0, i], rtol=1e-13)
+        np.testing.assert_allclose(h5[f"data/{t}/U_center"], ref_u[:, :, i], rtol=1e-13)
+    assert "case.h5:/data/1.5/U_center" in open(os.path.join(str(tmp_path), "case.xdmf")).read()
+
+    s3 = _scube(tmp_path)
+    s3.save_name, s3.metric = "split", pt.from_numpy(rng.random(n))
+    ex = export_mod.ExportData(s3, write_times=times, write_new_file_for_each_field=True)
+    ex.export(pt.from_numpy(coords), pt.from_numpy(p), "p")
+    ex.export(pt.from_numpy(coords), pt.from_numpy(u), "U")
+    for field in ("p", "U"):
+        part = dump(os.path.join(str(tmp_path), f"split_{field}.h5"))
+        assert "grid/faces" in part and f"data/0.0/{field}_center" in part and len([k for k in part if k.startswith("data/")]) == t_total
+        assert os.path.exists(os.path.join(str(tmp_path), f"split_{field}.xdmf"))

@@ -601,13 +601,15 @@ int s3_topn_leaf(const double *d_gain, const uint8_t *d_leaf, int64_t n_cells, i
         S3_HIP_CHECK(hipMemcpyAsync(gs.data(), d_og, sizeof(double) * cnt, hipMemcpyDeviceToHost, st));
         S3_HIP_CHECK(hipStreamSynchronize(st));
     }
-    std::vector<int32_t> order(cnt);
-    for (size_t i = 0; i < cnt; ++i) order[i] = (int32_t)i;
-    std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
-        Key96 ka = make_key(gs[a], (uint32_t)ids[a]), kb = make_key(gs[b], (uint32_t)ids[b]);
-        return ka.hi > kb.hi || (ka.hi == kb.hi && ka.lo > kb.lo);
-    });
-    for (size_t i = 0; i < cnt; ++i) h_out[i] = ids[order[i]];
+    // descending (gain, -id): the keys are formed once, then (key, id) records are sorted as a whole
+    struct Rec { uint64_t hi; uint32_t lo; int32_t id; };
+    std::vector<Rec> rec(cnt);
+    for (size_t i = 0; i < cnt; ++i) {
+        const Key96 kk = make_key(gs[i], (uint32_t)ids[i]);
+        rec[i] = Rec{kk.hi, kk.lo, ids[i]};
+    }
+    std::sort(rec.begin(), rec.end(), [](const Rec &a, const Rec &b) { return a.hi > b.hi || (a.hi == b.hi && a.lo > b.lo); });
+    for (size_t i = 0; i < cnt; ++i) h_out[i] = rec[i].id;
     *h_count = (int64_t)cnt;
     return S3_OK;
 }

@@ -13,8 +13,9 @@ The grid comes from `SamplingTree.refine()` run on the GPU(s) before the timed r
 Multi-GPU (one process per GPU, launched by torch.distributed.run; the collectives run inside libs3hip.so on RCCL):
 * refine: every rank evaluates the KNN metric / gain of its 1/N slice of each batch of new cells, one grouped all-gather
   per batch, block-wise captured-metric sums gathered per iteration (bit-identical for any N);
-* interpolation (default `--shard cells`): the generated leaf cells are split into N contiguous ranges, every rank holds
-  the KNN cache / plan of its range and only the source rows that range references, and interpolates the same snapshot
+* interpolation (default `--shard cells`): the generated leaf cells are split into N spatially compact shards of equal
+  cost (runs of the Hilbert-ordered tile plan, balanced by the bytes a shard moves per snapshot), every rank holds the
+  KNN cache / plan of its shard and only the source rows that shard references, and interpolates the same snapshot
   batch -- no data-path collective; total work is fixed ("scaling": "strong").  `--shard snapshots` gives every rank
   all cells and its own snapshot batches instead ("weak").
 
@@ -269,11 +270,14 @@ def main():
     # ---- KNN cache (once) -------------------------------------------------------------------------------------
     t0 = time.perf_counter()
     nc_total = len(centers)
-    c0, c1 = (0, nc_total)
-    if world > 1 and args.shard == "cells":
-        c0, c1 = parallel.shard_range(nc_total, rank, world)          # contiguous range of the generated leaf cells
-    my_centers = np.ascontiguousarray(centers[c0:c1])
     knn = hipops.KnnIndex(x, hipops.knn_occupancy(k, 3))
+    my_centers, shard_counts = centers, [nc_total]
+    if world > 1 and args.shard == "cells":
+        # this rank's share of the generated leaf cells: a spatially compact blob, cut so that every rank moves the same
+        # number of bytes per snapshot (parallel.LeafShards, what ExportData does with several ranks)
+        shards = parallel.LeafShards(knn, centers, k, rank, world)
+        my_centers, shard_counts = np.ascontiguousarray(centers[shards.mine]), shards.counts
+        del shards
     idx, dist_ = knn.query(my_centers, k)
     w = hipops.idw_weights(dist_)
     knn.close()
@@ -340,7 +344,7 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload, "n_points": len(x), "n_cells": nc_total, "t_batch": t_b, "k": k, "n_comp": 1,
                        "parallelism": f"{'snapshot-axis' if args.shard == 'snapshots' else 'leaf-cell'} shards x{world}",
-                       "collectives": comm.name},
+                       "cells_per_rank": shard_counts, "collectives": comm.name},
             "refine_wall_s": refine_s, "refine_init_s": t_init, "refine_iterations": info["iterations"],
             "refine_cells_created": n_cells_total, "refine_leaves_per_s": nc_total / refine_s, "knn_cache_s": knn_cache_s,
             "captured_metric": info["metric_per_iter"][-1],

@@ -189,6 +189,12 @@ int s3_interp_plan_create(const int32_t *d_idx /*[nc,k]*/, int64_t nc, int k, in
                           s3_stream stream, s3_interp_plan **out);
 void s3_interp_plan_destroy(s3_interp_plan *plan);
 int s3_interp_plan_info(const s3_interp_plan *plan, int64_t *h_n_tiles, int64_t *h_total_rows);
+/* leaf-cell shards for `world` ranks: the plan's tiles (cells in Hilbert order: a run of tiles is a compact
+ * blob of the grid) are cut into `world` consecutive runs of nearly equal cost = bytes the kernel moves per snapshot
+ * (4 per staged source row, halo included, + 8 per output row + the weights' share).  d_order[nc] (may be NULL) receives
+ * the plan's processing order (position -> cell id); rank r owns the cells d_order[h_cuts[r] .. h_cuts[r+1]).
+ * h_cuts: world + 1 entries on the host. */
+int s3_interp_plan_partition(const s3_interp_plan *plan, int world, int32_t *d_order, int64_t *h_cuts, s3_stream stream);
 /* in_stride: elements between consecutive source rows of d_data (>= row_len; 0 = row_len).  Rows padded to a multiple
  * of 128 bytes keep every staged segment on one cache line. */
 /* the weights of the table, [nc,k] in the caller's cell order, are kept inside the plan in tile order (one contiguous

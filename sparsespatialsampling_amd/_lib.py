@@ -70,6 +70,7 @@ HIP_SIGNATURES = {
     "s3_interp_plan_create": (c_int, [c_vp, c_i64, c_int, c_i64, c_vp, c_int, c_int, c_vp, C.POINTER(c_vp)]),
     "s3_interp_plan_destroy": (None, [c_vp]),
     "s3_interp_plan_info": (c_int, [c_vp, C.POINTER(c_i64), C.POINTER(c_i64)]),
+    "s3_interp_plan_partition": (c_int, [c_vp, c_int, c_vp, C.POINTER(c_i64), c_vp]),
     "s3_interp_plan_set_weights": (c_int, [c_vp, c_vp, c_vp]),
     "s3_interp_planned": (c_int, [c_vp, c_vp, c_vp, c_int, c_i64, c_i64, c_vp, c_vp]),
     "s3_comm_unique_id": (c_int, [c_vp, C.c_size_t]),

@@ -26,6 +26,7 @@
 
 #include <cstdlib>
 #include <exception>
+#include <vector>
 
 struct s3_interp_plan : s3::PlanTables {
     int64_t nc = 0, n_src = 0;
@@ -363,6 +364,16 @@ static int short_row_vecs() {
     return v;
 }
 
+// fewest workgroups a launch of the chunk kernel should have before the column chunks are split over blockIdx.y
+// (S3_PLAN_MIN_BLOCKS overrides, for A/B runs)
+static int64_t min_blocks() {
+    static const int64_t v = [] {
+        const char *e = getenv("S3_PLAN_MIN_BLOCKS");
+        return e ? atoll(e) : 2048ll;
+    }();
+    return v;
+}
+
 static int plan_ucap(int k, int tc) {
     const int budget = (tc == 128 ? 160 : 80) * 1024;
     int u = (budget - k * tc * (int)(sizeof(double) + sizeof(uint16_t))) / PL_SEG;
@@ -418,7 +429,7 @@ static int launch_planned(const s3_interp_plan *p, const void *data, int64_t row
     // tiles to fill the chip: one workgroup per tile over ALL chunks is fastest (MI355X, cylinder3D workload: 3.7 ms vs
     // 4.4 ms with 4 chunks per workgroup)
     int gy = 1;
-    while (gx * gy < 2048 && gy < n_chunks) gy *= 2;
+    while (gx * gy < s3::min_blocks() && gy < n_chunks) gy *= 2;
     if (gy > n_chunks) gy = n_chunks;
     if (gy < 1) gy = 1;
     const int chunks_per_block = (n_chunks + gy - 1) / gy;
@@ -492,6 +503,46 @@ int s3_interp_plan_info(const s3_interp_plan *p, int64_t *n_tiles, int64_t *tota
     return S3_OK;
 }
 
+// Leaf-cell shards for `world` ranks: the plan's tiles -- cells in Hilbert order, so a run of tiles is a
+// spatially compact blob -- are cut into `world` consecutive runs of (nearly) equal cost, the cost of a tile being what
+// the interpolation kernel moves for it per snapshot: 4 bytes per staged source row (fp32; the halo of a tile counts,
+// that is the point) + per cell 8 bytes of output and a measured equivalent of its accumulate work.  h_cuts[r] .. h_cuts[r+1] are positions in the
+// plan's processing order (d_order, a copy of `perm`): rank r owns the cells d_order[h_cuts[r] .. h_cuts[r+1]).
+// Equal cell counts in creation order (the survey's first suggestion) leave the slowest of 8 ranks with 1.8x the
+// mean time on the cylinder3D grid: the early, coarse cells reference 26 distinct rows each, the fine ones share theirs.
+int s3_interp_plan_partition(const s3_interp_plan *p, int world, int32_t *d_order, int64_t *h_cuts, s3_stream stream) try {
+    S3_REQUIRE(p != nullptr && h_cuts != nullptr, "s3_interp_plan_partition: null argument");
+    S3_REQUIRE(world >= 1, "s3_interp_plan_partition: world=%d", world);
+    hipStream_t st = as_stream(stream);
+    const size_t nt = (size_t)p->n_tiles;
+    std::vector<int32_t> cb(nt + 1), rb(nt + 1);
+    S3_HIP_CHECK(hipMemcpyAsync(cb.data(), p->tile_cell_begin, sizeof(int32_t) * (nt + 1), hipMemcpyDeviceToHost, st));
+    S3_HIP_CHECK(hipMemcpyAsync(rb.data(), p->tile_row_begin, sizeof(int32_t) * (nt + 1), hipMemcpyDeviceToHost, st));
+    if (d_order)
+        S3_HIP_CHECK(hipMemcpyAsync(d_order, p->perm, sizeof(int32_t) * (size_t)p->nc, hipMemcpyDeviceToDevice, st));
+    S3_HIP_CHECK(hipStreamSynchronize(st));
+    // per snapshot: 4 bytes per staged row; per cell 8 bytes of output + the accumulate phase of its k neighbours, which
+    // is not hidden behind the row traffic in tiles full of cells: a fit of launch times of 15 shards of the cylinder3D
+    // grid (tools/shard_probe.py: t = a * rows + b * cells + c) gives b / a = 3.6 at k = 26
+    const double ROW = 4.0, CELL = 8.0 + 6.0 * p->k / 26.0;
+    std::vector<double> acc(nt + 1, 0.0);
+    for (size_t t = 0; t < nt; ++t)
+        acc[t + 1] = acc[t] + ROW * (rb[t + 1] - rb[t]) + CELL * (cb[t + 1] - cb[t]);
+    h_cuts[0] = 0;
+    size_t t = 0;
+    for (int r = 1; r < world; ++r) {
+        const double goal = acc[nt] * r / world;
+        while (t < nt && acc[t + 1] <= goal) ++t;                              // tiles [.., t) are below the goal
+        if (t < nt && goal - acc[t] > acc[t + 1] - goal) ++t;                  // the nearer tile boundary
+        h_cuts[r] = cb[t];
+    }
+    h_cuts[world] = p->nc;
+    return S3_OK;
+} catch (const std::exception &e) {
+    s3::set_error("s3_interp_plan_partition: %s", e.what());
+    return S3_ENOMEM;
+}
+
 int s3_interp_plan_set_weights(s3_interp_plan *p, const double *d_w, s3_stream stream) {
     S3_REQUIRE(p != nullptr && d_w != nullptr, "s3_interp_plan_set_weights: null argument");
     if (!p->wp) {
@@ -526,9 +577,11 @@ int s3_interp_planned(s3_interp_plan *p, const double *d_w, const void *d_data, 
     S3_REQUIRE(in_stride >= row_len, "s3_interp_planned: in_stride %lld < row_len %lld", (long long)in_stride, (long long)row_len);
     // every source row starts on a 16-byte boundary and is readable up to the next multiple of 16 bytes (the ragged tail
     // of a row is loaded as a whole vector, the surplus lanes are never stored)
-    S3_REQUIRE(in_stride % epv == 0 && in_stride >= (row_len + epv - 1) / epv * epv && a_in % 16 == 0 && a_out % 16 == 0,
+    S3_REQUIRE(in_stride % epv == 0 && in_stride >= (row_len + epv - 1) / epv * epv && a_in % 16 == 0,
                "s3_interp_planned: source rows must be 16-byte aligned with a pitch >= the row length rounded up to %d "
                "elements (row_len %lld, in_stride %lld)", epv, (long long)row_len, (long long)in_stride);
+    // output rows of even length are written as double2 (16-byte aligned rows), odd lengths per element
+    S3_REQUIRE(a_out % ((row_len & 1) ? 8 : 16) == 0, "s3_interp_planned: output not aligned (row_len %lld)", (long long)row_len);
     if (dtype == S3_DTYPE_F32) return launch_planned<float>(p, d_data, row_len, in_stride, d_out, as_stream(stream));
     return launch_planned<double>(p, d_data, row_len, in_stride, d_out, as_stream(stream));
 }

@@ -197,6 +197,15 @@ class InterpPlan:
         check(_lib.hip_lib().s3_interp_plan_set_weights(self._handle, _ptr(w), _stream()), "s3_interp_plan_set_weights")
         self._w_key = (w.data_ptr(), w._version)
 
+    def partition(self, world):
+        """cost-balanced leaf-cell shards (s3_interp_plan_partition): ``(order, cuts)`` -- ``order`` is the plan's processing
+        order (device int32 [nc], position -> cell id: cells in Hilbert order) and rank r owns ``order[cuts[r]:cuts[r + 1]]``"""
+        order = pt.empty(self.nc, dtype=pt.int32, device=device())
+        cuts = (C.c_int64 * (int(world) + 1))()
+        check(_lib.hip_lib().s3_interp_plan_partition(self._handle, int(world), _ptr(order), cuts, _stream()),
+              "s3_interp_plan_partition")
+        return order, [int(c) for c in cuts]
+
     @staticmethod
     def _layout(data):
         """(row_len, in_stride) of a data matrix the planned kernel can read, None otherwise: every source row starts on

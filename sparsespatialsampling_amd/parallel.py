@@ -35,6 +35,43 @@ def shard_range(n, rank=None, world_size=None):
     return begin, begin + base + (1 if rank < rem else 0)
 
 
+class LeafShards:
+    """Cost-balanced, spatially compact shards of a set of target points (generated cell centres / vertices) for the
+    interpolation.  Every rank computes the same partition: neighbour table of ALL targets (the KNN query
+    is cheap next to one snapshot batch), its tile plan, tiles -- Hilbert order, so a run of tiles is a compact blob that
+    shares few source rows with the other ranks -- cut into ``world`` runs of equal cost (bytes moved per snapshot:
+    staged rows incl. halo + output rows).
+
+    ``mine``      int64 host array, the targets of this rank (ascending ids)
+    ``counts``    targets per rank; ``chunk`` = max(counts): slot size of the equal-chunk in-place all-gather
+    ``slot_of``   device int32 [n]: target id -> row of the gathered ``[world * chunk, L]`` array
+    """
+
+    def __init__(self, knn, targets, k, rank, world_size):
+        from . import hipops
+        targets = hipops.to_device(targets, pt.float64)
+        idx, _ = knn.query(targets, k)
+        plan = hipops.InterpPlan(idx, knn.n, targets)
+        order, cuts = plan.partition(world_size)
+        plan.close()
+        del idx
+        self.rank, self.world, self.n = int(rank), int(world_size), int(targets.shape[0])
+        if self.n < self.world:
+            raise ValueError(f"{self.n} target points cannot be sharded over {self.world} ranks")
+        if min(cuts[r + 1] - cuts[r] for r in range(self.world)) == 0:
+            # fewer tiles than ranks (tiny grids): equal counts along the curve instead
+            cuts = [shard_range(self.n, r, self.world)[0] for r in range(self.world)] + [self.n]
+        self.counts = [cuts[r + 1] - cuts[r] for r in range(self.world)]
+        self.chunk = max(self.counts)
+        order_h = order.cpu().numpy()
+        self.mine = np.sort(order_h[cuts[self.rank]:cuts[self.rank + 1]]).astype(np.int64)
+        slot = np.empty(self.n, dtype=np.int32)
+        for r in range(self.world):
+            ids = np.sort(order_h[cuts[r]:cuts[r + 1]])
+            slot[ids] = r * self.chunk + np.arange(len(ids), dtype=np.int32)
+        self.slot_of = pt.from_numpy(slot).to(order.device)
+
+
 def batch_slice(n, rank, world_size):
     """equal-sized chunks for an in-place all-gather: (chunk, begin, end) -- rank r owns [r * chunk, (r + 1) * chunk)
     clipped to n; the gathered array spans world_size * chunk entries"""

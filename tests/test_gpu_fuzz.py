@@ -7,6 +7,7 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -65,3 +66,36 @@ def test_bench_two_ranks_share_one_gpu():
     assert r2["n_gpus"] == 2 and r2["config"]["parallelism"] == "leaf-cell shards x2" and r2["config"]["collectives"] == "gloo"
     assert r1["config"]["n_cells"] == r2["config"]["n_cells"] and r1["refine_cells_created"] == r2["refine_cells_created"]
     assert r1["captured_metric"] == r2["captured_metric"] and r1["refine_iterations"] == r2["refine_iterations"]
+
+
+@pytest.mark.gpu
+def test_sharded_export_matches_single_rank(tmp_path):
+    """``ExportData`` with three ranks (leaf-cell shards: every rank interpolates its compact, cost-balanced share of the
+    cells and of the vertices from the source rows that share references, one all-gather, rank 0 writes) produces the
+    HDF5 file of the single-rank run bit for bit -- every output value is computed by the same kernel arithmetic whichever
+    rank owns its cell.  Three processes share the one GPU, gloo carries the exchange."""
+    from sparsespatialsampling_amd import h5io
+    if h5io.native_lib() is None:
+        pytest.importorskip("h5py")
+    worker = os.path.join(ROOT, "tests", "sharded_export_worker.py")
+    d1, d3 = str(tmp_path / "one"), str(tmp_path / "three")
+    os.makedirs(d1), os.makedirs(d3)
+    one = subprocess.run([sys.executable, worker, d1], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0 and "worker ok" in one.stdout, (one.stdout + one.stderr)[-3000:]
+    env = dict(os.environ, S3_DIST_BACKEND="gloo")
+    three = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr",
+                            "127.0.0.1", "--master-port", "29613", worker, d3], cwd=ROOT, env=env, capture_output=True, text=True,
+                           timeout=900)
+    assert three.returncode == 0 and three.stdout.count("worker ok") == 3, (three.stdout + three.stderr)[-3000:]
+    assert not os.path.exists(os.path.join(d3, "grid_rank1", "case.h5")), "only rank 0 writes the export"
+    with h5io.open_h5(os.path.join(d1, "case.h5"), "r") as a, h5io.open_h5(os.path.join(d3, "case.h5"), "r") as b:
+        assert a.keys("data") == b.keys("data") and len(a.keys("data")) == 11
+        for group in ("grid", "constant"):
+            assert a.keys(group) == b.keys(group)
+            for name in a.keys(group):
+                assert np.array_equal(a.read(f"{group}/{name}"), b.read(f"{group}/{name}")), f"{group}/{name}"
+        for t in a.keys("data"):
+            assert a.keys(f"data/{t}") == b.keys(f"data/{t}") == ["U_center", "U_vertices", "p_center", "p_vertices"]
+            for name in a.keys(f"data/{t}"):
+                assert np.array_equal(a.read(f"data/{t}/{name}"), b.read(f"data/{t}/{name}")), f"data/{t}/{name}"
+    assert open(os.path.join(d1, "case.xdmf")).read() == open(os.path.join(d3, "case.xdmf")).read()

@@ -264,6 +264,34 @@ size_t s3_weighted_gram_scratch_bytes(int64_t n_rows, int64_t t);
 int s3_weighted_gram(const double *d_x, int64_t n_rows, int64_t t, int64_t in_stride, const double *d_mean,
                      const double *d_weight, double *d_gram /*[t,t]*/, void *d_scratch, s3_stream stream);
 
+/* ---- device-resident topology of the sampling tree (a9-a11, a15) ------------------------------------------
+ * Neighbour links, shared-node numbering, invalid-cell bookkeeping and the final renumbering of s_cube.py:904-1536,
+ * 721-728, 734-772, 1695-1736 on tables that live in HBM.  Every update takes the ORDERED id list the host decided on
+ * (the iteration order of the reference's sets) as a host array, copies it, and runs asynchronously on the engine's own
+ * stream; the result is the one of the reference's sequential procedure (stale links included).  s3_topo_sync waits.
+ * The host engine libs3topo.so (csrc/topology.cpp) implements the same operations and serves the 2:1-balance mode. */
+typedef struct s3_topo s3_topo;
+int s3_topo_create(int dim, double width, const double *h_root_center /*[dim]*/, s3_topo **out);
+void s3_topo_destroy(s3_topo *topo);
+/* children of the listed parents in list order (s_cube.py:879-895 / 531-544); relink != 0: all their links once more after
+ * the batch (uniform levels, s_cube.py:547-549).  *h_first (may be NULL) = id of the first new cell */
+int s3_topo_refine(s3_topo *topo, const int64_t *h_parents, int64_t n, int relink, int64_t *h_first);
+/* cell.parent.children = _assign_neighbors(cell.parent, ...) for every listed cell, in list order (s_cube.py:609, 834) */
+int s3_topo_relink_parent_of(s3_topo *topo, const int64_t *h_cells, int64_t n);
+/* children = [] and removal from the neighbours' rows, in list order (s_cube.py:721-728) */
+int s3_topo_mark_invalid(s3_topo *topo, const int64_t *h_cells, int64_t n);
+/* wait for the submitted updates; *h_error != 0: a listed parent was not a leaf or listed twice */
+int s3_topo_sync(s3_topo *topo, int64_t *h_n_cells, int64_t *h_n_nodes, int *h_error);
+/* device pointer of a table: 0 level i32, 1 parent i32, 2 first_child i32 (-1 leaf, -2 invalid), 3 nb i32 [n][8|26],
+ * 4 node_idx i64 [n][2^d], 5 center f64 [n][d], 6 nodes f64 [n_nodes][d]; valid until the next update */
+int s3_topo_table(s3_topo *topo, int which, const void **d_ptr);
+/* renumbering (s_cube.py:734-772): leaves, nodes that keep a slot; then the grid into the caller's DEVICE arrays:
+ * faces [n_leaf][2^d] (int32 when as32, else int64; leaves in ascending cell id), nodes [n_unique][d] */
+int s3_topo_finalize(s3_topo *topo, int64_t *h_n_leaf, int64_t *h_n_unique_nodes);
+int s3_topo_export_grid(s3_topo *topo, void *d_faces, int as32, double *d_nodes);
+/* centres [n][d] / levels [n] (int64) of the listed cells into DEVICE arrays */
+int s3_topo_gather_cells(s3_topo *topo, const int64_t *h_ids, int64_t n, double *d_centers, int64_t *d_levels);
+
 #ifdef __cplusplus
 }
 #endif

@@ -89,6 +89,16 @@ HIP_SIGNATURES = {
     "s3_spatial_order": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp]),
     "s3_positions_of": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp]),
     "s3_gather_rows": (c_int, [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp]),
+    "s3_topo_create": (c_int, [c_int, c_dbl, c_vp, C.POINTER(c_vp)]),
+    "s3_topo_destroy": (None, [c_vp]),
+    "s3_topo_refine": (c_int, [c_vp, c_vp, c_i64, c_int, C.POINTER(c_i64)]),
+    "s3_topo_relink_parent_of": (c_int, [c_vp, c_vp, c_i64]),
+    "s3_topo_mark_invalid": (c_int, [c_vp, c_vp, c_i64]),
+    "s3_topo_sync": (c_int, [c_vp, C.POINTER(c_i64), C.POINTER(c_i64), C.POINTER(c_int)]),
+    "s3_topo_table": (c_int, [c_vp, c_int, C.POINTER(c_vp)]),
+    "s3_topo_finalize": (c_int, [c_vp, C.POINTER(c_i64), C.POINTER(c_i64)]),
+    "s3_topo_export_grid": (c_int, [c_vp, c_vp, c_int, c_vp]),
+    "s3_topo_gather_cells": (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp]),
 }
 
 TOPO_SIGNATURES = {

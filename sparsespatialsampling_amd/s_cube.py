@@ -225,6 +225,138 @@ class _Topology:
         return centers, levels
 
 
+class _DeviceTopology(_Topology):
+    """The same interface on the device-resident engine (csrc/topo_dev.hip, ``s3_topo_*``): the tables live in HBM, every
+    update is a handful of kernel launches on the engine's own stream (it overlaps the KNN kernels of the refine loop the
+    way the host engine's worker thread does), and the host only ever holds what it asks for -- table views are
+    downloads, cached until the next update.  Used whenever the tree runs on the HIP backend without the 2:1-balance
+    mode (``_check_nb`` reads single rows between updates, which the host engine serves better)."""
+
+    _TABLES = {"level": (0, np.int32), "parent": (1, np.int32), "first_child": (2, np.int32), "nb": (3, np.int32),
+               "node_idx": (4, np.int64), "center": (5, np.float64), "nodes": (6, np.float64)}
+
+    def __init__(self, dim, width, root_center):
+        from . import hipops
+        self._ops = hipops
+        hipops.device()
+        self._hip = _lib.hip_lib()
+        self.dim, self.nch, self.nnb = dim, 2 ** dim, 8 if dim == 2 else 26
+        rc = np.ascontiguousarray(root_center, dtype=np.float64)
+        h = C.c_void_p(0)
+        hipops.check(self._hip.s3_topo_create(dim, float(width), rc.ctypes.data_as(C.c_void_p), C.byref(h)), "s3_topo_create")
+        self._h = h
+        self.n_created = 1
+        self._level_shadow = np.zeros(4096, dtype=np.int32)
+        self._n_nodes = self.nch
+        self._cache = {}
+        self._dirty = False
+
+    def _submit(self, kind, ids, relink=0):
+        a = self._ids(ids)
+        ptr = a.ctypes.data_as(C.c_void_p)
+        if kind == 0:
+            rc = self._hip.s3_topo_refine(self._h, ptr, len(a), int(relink), None)
+        elif kind == 1:
+            rc = self._hip.s3_topo_relink_parent_of(self._h, ptr, len(a))
+        else:
+            rc = self._hip.s3_topo_mark_invalid(self._h, ptr, len(a))
+        self._ops.check(rc, "s3_topo update")
+        self._dirty = True
+        self._cache = {}
+
+    def sync(self):
+        if not self._dirty:
+            return
+        n_cells, n_nodes, err = C.c_int64(0), C.c_int64(0), C.c_int(0)
+        self._ops.check(self._hip.s3_topo_sync(self._h, C.byref(n_cells), C.byref(n_nodes), C.byref(err)), "s3_topo_sync")
+        if err.value != 0:
+            raise RuntimeError("topology engine: tried to refine a cell that is not a leaf")
+        if n_cells.value != self.n_created:
+            raise RuntimeError("device topology and device cell arrays disagree about the ids of the new cells")
+        self._n_nodes = n_nodes.value
+        self._dirty = False
+
+    def close(self):
+        h = getattr(self, "_h_raw", None)
+        if h is not None and h.value:
+            self._hip.s3_topo_destroy(h)
+        self._h_raw = None
+
+    __del__ = close
+
+    @property
+    def n_cells(self):
+        self.sync()
+        return self.n_created
+
+    @property
+    def n_nodes(self):
+        self.sync()
+        return self._n_nodes
+
+    def _table(self, name):
+        """host copy of a device table (downloaded once per state of the engine)"""
+        self.sync()
+        if name not in self._cache:
+            which, dtype = self._TABLES[name]
+            rows = self._n_nodes if name == "nodes" else self.n_created
+            per = {"nb": self.nnb, "node_idx": self.nch, "center": self.dim, "nodes": self.dim}.get(name, 1)
+            out = np.empty((rows, per) if per > 1 else (rows,), dtype=dtype)
+            ptr = C.c_void_p(0)
+            self._ops.check(self._hip.s3_topo_table(self._h, which, C.byref(ptr)), "s3_topo_table")
+            self._ops.check(self._hip.s3_memcpy_d2h(out.ctypes.data_as(C.c_void_p), ptr, out.nbytes, None), "s3_memcpy_d2h")
+            self._cache[name] = out
+        return self._cache[name]
+
+    level = property(lambda self: self._table("level"))
+    parent = property(lambda self: self._table("parent"))
+    first_child = property(lambda self: self._table("first_child"))
+    nb = property(lambda self: self._table("nb"))
+    node_idx = property(lambda self: self._table("node_idx"))
+    center = property(lambda self: self._table("center"))
+    nodes = property(lambda self: self._table("nodes"))
+
+    def relink_parent_of(self, cells):
+        self._submit(1, cells)
+
+    def mark_invalid(self, cells):
+        self._submit(2, cells)
+
+    def check_nb(self, cell):
+        nb, fc, level = self.nb[int(cell)], self.first_child, self.level
+        return [int(q) for q in nb if q >= 0 and fc[q] == -1 and level[q] < level[int(cell)]]
+
+    def finalize(self, dtype=np.int64):
+        self.sync()
+        n_leaf, n_nodes = C.c_int64(0), C.c_int64(0)
+        self._ops.check(self._hip.s3_topo_finalize(self._h, C.byref(n_leaf), C.byref(n_nodes)), "s3_topo_finalize")
+        dev = self._ops.device()
+        faces = pt.empty((n_leaf.value, self.nch), dtype=pt.int32 if np.dtype(dtype) == np.int32 else pt.int64, device=dev)
+        nodes = pt.empty((n_nodes.value, self.dim), dtype=pt.float64, device=dev)
+        self._ops.check(self._hip.s3_topo_export_grid(self._h, C.c_void_p(faces.data_ptr()), int(np.dtype(dtype) == np.int32),
+                                                      C.c_void_p(nodes.data_ptr())), "s3_topo_export_grid")
+        return faces.cpu().numpy(), nodes.cpu().numpy()
+
+    def gather_cells(self, ids):
+        a = self._ids(ids)
+        dev = self._ops.device()
+        centers = pt.empty((len(a), self.dim), dtype=pt.float64, device=dev)
+        levels = pt.empty(len(a), dtype=pt.int64, device=dev)
+        self._ops.check(self._hip.s3_topo_gather_cells(self._h, a.ctypes.data_as(C.c_void_p), len(a), C.c_void_p(centers.data_ptr()),
+                                                       C.c_void_p(levels.data_ptr())), "s3_topo_gather_cells")
+        return centers.cpu().numpy(), levels.cpu().numpy()
+
+
+def _make_topology(dim, width, root_center, backend, max_delta_level):
+    """device-resident engine for trees on the HIP backend (S3_TOPOLOGY=host keeps the host engine), host engine for the
+    2:1-balance mode and for the CPU test backend"""
+    import os
+    on_device = type(backend).__name__ == "HipTreeBackend" and not max_delta_level
+    if on_device and os.environ.get("S3_TOPOLOGY", "device") != "host":
+        return _DeviceTopology(dim, width, root_center)
+    return _Topology(dim, width, root_center)
+
+
 class Cell(object):
     """Read-only view of one cell with the attribute names of the reference's ``Cell`` (s_cube.py:32-83).  The tree
     itself is stored as arrays; views are created on demand (``tree._cells[i]``)."""
@@ -387,7 +519,7 @@ class SamplingTree(object):
             gain = 1.0
         self._gain0 = float(gain)
         self._n_cells += 1
-        self._topo_engine = _Topology(nd, self._width, root)
+        self._topo_engine = _make_topology(nd, self._width, root, self._backend, self._max_delta_level)
         self._backend.start(root, self._width, self._gain0, metric[0], self._gain0)
         self._leaf_cells.add(0)
 

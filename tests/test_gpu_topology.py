@@ -34,8 +34,8 @@ def _same_tables(host, dev, what):
             f"(first at {np.argwhere(np.asarray(a) != np.asarray(b))[:3].tolist()})"
 
 
-@pytest.mark.parametrize("dim,seed", [(2, 0), (2, 1), (3, 2), (3, 3)])
-def test_device_engine_equals_host_engine_on_random_sequences(dim, seed):
+@pytest.mark.parametrize("dim,seed,rounds", [(2, 0, 7), (2, 1, 7), (2, 5, 12), (3, 2, 7), (3, 3, 7), (3, 6, 10), (3, 7, 5)])
+def test_device_engine_equals_host_engine_on_random_sequences(dim, seed, rounds):
     rng = np.random.default_rng(seed)
     host, dev = _engines(dim)
     nch = 2 ** dim
@@ -47,7 +47,7 @@ def test_device_engine_equals_host_engine_on_random_sequences(dim, seed):
         first = firsts.pop()
         leaves = np.arange(first, first + len(order) * nch, dtype=np.int64)
     _same_tables(host, dev, "uniform levels")
-    for rnd in range(7):
+    for rnd in range(rounds):
         # a cluster of neighbouring leaves disappears (they list each other: the order of the list decides who is wiped
         # from whose row), plus a few scattered ones
         host.sync()

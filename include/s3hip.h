@@ -51,6 +51,9 @@ int s3_free(void *d_ptr);
 int s3_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes, s3_stream stream);
 int s3_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes, s3_stream stream);
 int s3_stream_synchronize(s3_stream stream);
+/* device -> pageable host array through persistent pinned buffers drained by several host threads (a plain copy into
+ * pageable memory runs at 12-15 GB/s); returns when h_dst is complete */
+int s3_download(void *h_dst, const void *d_src, size_t bytes, s3_stream stream);
 /* upload target of a snapshot batch (the .to(device) of a host tensor handed to ExportData.export, export.py:128-167):
  * pageable host rows [n_rows][row_bytes] -> device rows with pitch dst_pitch_bytes, staged through persistent pinned
  * buffers filled by several host threads; asynchronous on `stream` (the host data may be reused on return).  The

@@ -136,6 +136,74 @@ int s3_upload_rows_indexed(const void *h_src, const int32_t *h_rows, int64_t n_s
     return upload_rows_impl(h_src, h_rows, n_sel, row_bytes, d_dst, dst_pitch_bytes, stream);
 }
 
+// Device -> pageable host memory through the same pinned lanes: every thread brings 8 MiB chunks down into its pinned
+// buffers (asynchronous copies on `stream`) and moves the chunk before last into the caller's array meanwhile.  Returns
+// when h_dst is complete.  A plain hipMemcpy into pageable memory runs at 12-15 GB/s on an MI355X host.
+int s3_download(void *h_dst, const void *d_src, size_t bytes, s3_stream stream) try {
+    using namespace s3;
+    if (bytes == 0) return S3_OK;
+    S3_REQUIRE(h_dst && d_src, "s3_download: null array");
+    hipStream_t st = as_stream(stream);
+    if (bytes < 4 * UP_CHUNK_BYTES) {                                    // small: not worth the threads
+        S3_HIP_CHECK(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, st));
+        S3_HIP_CHECK(hipStreamSynchronize(st));
+        return S3_OK;
+    }
+    std::lock_guard<std::mutex> guard(g_upload_mutex);
+    int dev = 0;
+    S3_HIP_CHECK(hipGetDevice(&dev));
+    S3_HIP_CHECK(hipStreamSynchronize(st));                              // the source is complete; lanes use their own order
+    const int64_t n_chunks = (int64_t)((bytes + UP_CHUNK_BYTES - 1) / UP_CHUNK_BYTES);
+    const int hw = (int)std::thread::hardware_concurrency();
+    const int n_thr = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)8, (int64_t)std::max(1, hw / 2), n_chunks / 2}));
+    for (int t = 0; t < n_thr; ++t) S3_HIP_CHECK(upload_lane_init(g_lanes[t]));
+    std::atomic<int64_t> next{0};
+    std::atomic<int> first_error{(int)hipSuccess};
+    auto work = [&](int t) {
+        if (hipSetDevice(dev) != hipSuccess) { first_error = (int)hipErrorInvalidDevice; return; }
+        UploadLane &l = g_lanes[t];
+        hipStream_t own = nullptr;
+        if (hipStreamCreateWithFlags(&own, hipStreamNonBlocking) != hipSuccess) { first_error = (int)hipErrorUnknown; return; }
+        int64_t pending[UP_BUFS] = {-1, -1};                              // chunk sitting in each pinned buffer
+        auto drain = [&](int b) {
+            if (pending[b] < 0) return hipSuccess;
+            const hipError_t e = hipEventSynchronize(l.ev[b]);
+            if (e != hipSuccess) return e;
+            const size_t off = (size_t)pending[b] * UP_CHUNK_BYTES;
+            std::memcpy(static_cast<char *>(h_dst) + off, l.pinned[b], std::min(UP_CHUNK_BYTES, bytes - off));
+            pending[b] = -1;
+            return hipSuccess;
+        };
+        int b = 0;
+        hipError_t e = hipSuccess;
+        while (e == hipSuccess && first_error.load() == (int)hipSuccess) {
+            const int64_t c = next.fetch_add(1);
+            if (c >= n_chunks) break;
+            e = drain(b);                                                // the buffer's previous chunk goes to the caller first
+            if (e != hipSuccess) break;
+            const size_t off = (size_t)c * UP_CHUNK_BYTES;
+            e = hipMemcpyAsync(l.pinned[b], static_cast<const char *>(d_src) + off, std::min(UP_CHUNK_BYTES, bytes - off),
+                               hipMemcpyDeviceToHost, own);
+            if (e == hipSuccess) e = hipEventRecord(l.ev[b], own);
+            pending[b] = c;
+            b = (b + 1) % UP_BUFS;
+        }
+        for (int k = 0; k < UP_BUFS && e == hipSuccess; ++k) e = drain((b + k) % UP_BUFS);
+        (void)hipStreamSynchronize(own);
+        (void)hipStreamDestroy(own);
+        if (e != hipSuccess) first_error = (int)e;
+    };
+    std::vector<std::thread> workers;
+    for (int t = 1; t < n_thr; ++t) workers.emplace_back(work, t);
+    work(0);
+    for (auto &w : workers) w.join();
+    S3_HIP_CHECK((hipError_t)first_error.load());
+    return S3_OK;
+} catch (const std::exception &e) {
+    s3::set_error("s3_download: %s", e.what());
+    return S3_ENOMEM;
+}
+
 const char *s3_last_error(void) { return s3::g_err; }
 
 int s3_abi_version(void) { return 1; }

@@ -32,6 +32,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <exception>
 #include <vector>
 
@@ -127,6 +128,14 @@ struct s3_topo : TopoView {
     NbEntry *d_nb_table = nullptr;
     NodeRule *d_rules = nullptr;
     double *d_widths = nullptr;
+    // id lists go up through two pinned staging buffers (a pageable source would make every update wait for the stream)
+    int64_t *h_stage[2] = {nullptr, nullptr};
+    int64_t h_stage_cap[2] = {0, 0};
+    hipEvent_t h_stage_free[2] = {nullptr, nullptr};
+    int h_turn = 0;
+    // tables replaced by larger ones: released at the next sync (hipFree waits for the whole device, i.e. for the KNN
+    // kernel of the refine loop that runs beside the engine)
+    std::vector<void *> retired;
 };
 
 namespace s3 {
@@ -479,7 +488,7 @@ __global__ void topo_fill_i32_kernel(int32_t *p, int64_t n, int32_t v) {
 }
 
 template <typename T>
-static int grow(T *&p, int64_t &cap, int64_t want, int64_t keep, hipStream_t st) {
+static int grow(T *&p, int64_t &cap, int64_t want, int64_t keep, hipStream_t st, std::vector<void *> *retired = nullptr) {
     if (want <= cap) return S3_OK;
     const int64_t nc = std::max<int64_t>(std::max(want, cap * 2), 1024);
     T *q = nullptr;
@@ -490,8 +499,12 @@ static int grow(T *&p, int64_t &cap, int64_t want, int64_t keep, hipStream_t st)
     }
     if (p && keep > 0) S3_HIP_CHECK(hipMemcpyAsync(q, p, sizeof(T) * (size_t)keep, hipMemcpyDeviceToDevice, st));
     if (p) {
-        S3_HIP_CHECK(hipStreamSynchronize(st));
-        (void)hipFree(p);
+        if (retired) {
+            retired->push_back(p);                       // kernels in flight may still read it: freed at the next sync
+        } else {
+            S3_HIP_CHECK(hipStreamSynchronize(st));
+            (void)hipFree(p);
+        }
     }
     p = q;
     cap = nc;
@@ -506,7 +519,7 @@ static int reserve_cells(s3_topo *t, int64_t extra) {
 #define S3_GROW_TABLE(PTR, TYPE, PER)                                                        \
     do {                                                                                     \
         c = t->cell_cap * (PER);                                                             \
-        const int rc_ = grow<TYPE>(t->PTR, c, cap * (PER), t->n_used * (PER), t->st);        \
+        const int rc_ = grow<TYPE>(t->PTR, c, cap * (PER), t->n_used * (PER), t->st, &t->retired);        \
         if (rc_ != S3_OK) return rc_;                                                        \
     } while (0)
         S3_GROW_TABLE(level, int32_t, 1);
@@ -533,8 +546,27 @@ static int upload_ids(s3_topo *t, const int64_t *h_ids, int64_t n) {
         if (rc != S3_OK) return rc;
         t->ids_cap = c0;
     }
-    // (pageable source: the call returns once the bytes are staged, the caller may reuse its array)
-    S3_HIP_CHECK(hipMemcpyAsync(t->ids, h_ids, sizeof(int64_t) * (size_t)n, hipMemcpyHostToDevice, t->st));
+    // through a pinned buffer: the caller's array is copied at once (it may be reused), the transfer itself is asynchronous
+    const int b = t->h_turn;
+    t->h_turn ^= 1;
+    if (!t->h_stage_free[b]) S3_HIP_CHECK(hipEventCreateWithFlags(&t->h_stage_free[b], hipEventDisableTiming));
+    S3_HIP_CHECK(hipEventSynchronize(t->h_stage_free[b]));                 // the transfer before last has left the buffer
+    if (n > t->h_stage_cap[b]) {
+        if (t->h_stage[b]) (void)hipHostFree(t->h_stage[b]);
+        t->h_stage[b] = nullptr;
+        t->h_stage_cap[b] = 0;
+        const int64_t cap = std::max<int64_t>(n + n / 2, 1 << 16);
+        if (hipHostMalloc(reinterpret_cast<void **>(&t->h_stage[b]), sizeof(int64_t) * (size_t)cap, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            t->h_stage[b] = nullptr;                                       // no page-locked memory: plain copy
+            S3_HIP_CHECK(hipMemcpyAsync(t->ids, h_ids, sizeof(int64_t) * (size_t)n, hipMemcpyHostToDevice, t->st));
+            return S3_OK;
+        }
+        t->h_stage_cap[b] = cap;
+    }
+    std::memcpy(t->h_stage[b], h_ids, sizeof(int64_t) * (size_t)n);
+    S3_HIP_CHECK(hipMemcpyAsync(t->ids, t->h_stage[b], sizeof(int64_t) * (size_t)n, hipMemcpyHostToDevice, t->st));
+    S3_HIP_CHECK(hipEventRecord(t->h_stage_free[b], t->st));
     return S3_OK;
 }
 
@@ -568,6 +600,11 @@ void s3_topo_destroy(s3_topo *t) {
                     t->d_rules, t->d_widths};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    for (void *p : t->retired) (void)hipFree(p);
+    for (int b = 0; b < 2; ++b) {
+        if (t->h_stage[b]) (void)hipHostFree(t->h_stage[b]);
+        if (t->h_stage_free[b]) (void)hipEventDestroy(t->h_stage_free[b]);
+    }
     if (t->st) (void)hipStreamDestroy(t->st);
     delete t;
 }
@@ -663,7 +700,7 @@ int s3_topo_refine(s3_topo *t, const int64_t *h_parents, int64_t n, int relink, 
     // every parent brings at most 3^d - 2^d new nodes (the lattice points of its children that are not its own corners)
     const int64_t max_new = (t->dim == 2 ? 5 : 19) * n;
     int64_t cap = t->node_cap * t->dim;
-    rc = grow<double>(t->nodes, cap, (t->n_nodes_bound + max_new) * t->dim, t->n_nodes_bound * t->dim, t->st);
+    rc = grow<double>(t->nodes, cap, (t->n_nodes_bound + max_new) * t->dim, t->n_nodes_bound * t->dim, t->st, &t->retired);
     if (rc != S3_OK) return rc;
     t->node_cap = cap / t->dim;
     t->n_nodes_bound += max_new;
@@ -727,6 +764,8 @@ int s3_topo_sync(s3_topo *t, int64_t *h_n_cells, int64_t *h_n_nodes, int *h_erro
     int64_t c[2];
     S3_HIP_CHECK(hipMemcpyAsync(c, t->counters, sizeof(c), hipMemcpyDeviceToHost, t->st));
     S3_HIP_CHECK(hipStreamSynchronize(t->st));
+    for (void *p : t->retired) (void)hipFree(p);
+    t->retired.clear();
     t->n_nodes_bound = c[0];
     if (h_n_cells) *h_n_cells = t->n_used;
     if (h_n_nodes) *h_n_nodes = c[0];

@@ -264,6 +264,17 @@ class InterpPlan:
         return out
 
 
+def to_host(t):
+    """contiguous device tensor -> numpy array in pageable host memory through the native staged download (s3_download);
+    the result is complete on return"""
+    t = t.contiguous()
+    out = np.empty(tuple(t.shape), dtype=pt.empty((), dtype=t.dtype).numpy().dtype)
+    if out.nbytes:
+        synchronize()                      # t was produced on torch's current stream or on an engine stream that was waited for
+        check(_lib.hip_lib().s3_download(out.ctypes.data_as(C.c_void_p), C.c_void_p(t.data_ptr()), out.nbytes, None), "s3_download")
+    return out
+
+
 def upload_rows(host, rows):
     """contiguous host tensor [n_rows, row_len] -> device rows ``rows`` (a ``padded_rows`` view: the bytes between two
     rows are padding and may be overwritten) through the native staged upload (s3_upload_rows); asynchronous on the

@@ -335,7 +335,7 @@ class _DeviceTopology(_Topology):
         nodes = pt.empty((n_nodes.value, self.dim), dtype=pt.float64, device=dev)
         self._ops.check(self._hip.s3_topo_export_grid(self._h, C.c_void_p(faces.data_ptr()), int(np.dtype(dtype) == np.int32),
                                                       C.c_void_p(nodes.data_ptr())), "s3_topo_export_grid")
-        return faces.cpu().numpy(), nodes.cpu().numpy()
+        return self._ops.to_host(faces), self._ops.to_host(nodes)
 
     def gather_cells(self, ids):
         a = self._ids(ids)
@@ -344,7 +344,7 @@ class _DeviceTopology(_Topology):
         levels = pt.empty(len(a), dtype=pt.int64, device=dev)
         self._ops.check(self._hip.s3_topo_gather_cells(self._h, a.ctypes.data_as(C.c_void_p), len(a), C.c_void_p(centers.data_ptr()),
                                                        C.c_void_p(levels.data_ptr())), "s3_topo_gather_cells")
-        return centers.cpu().numpy(), levels.cpu().numpy()
+        return self._ops.to_host(centers), self._ops.to_host(levels)
 
 
 def _make_topology(dim, width, root_center, backend, max_delta_level):

@@ -652,3 +652,14 @@ def test_sumsq_blocks_independent_of_the_split(ops):
     assert len(set(results)) == 1
     m, l = metric.cpu().numpy(), leaf.cpu().numpy().astype(bool)
     assert abs(results[0] - float((m[l] ** 2).sum())) <= 1e-12 * results[0]
+
+
+def test_staged_download_equals_plain_copy(ops):
+    """s3_download (device -> pageable host memory through the pinned lanes, several threads): every byte of a 100-MB
+    array whose size is not a multiple of the chunk, of a small one (plain path) and of an empty one"""
+    for n in (13_107_233, 1_000, 0):
+        t = pt.arange(n, dtype=pt.float64, device="cuda") * 0.37 - 5.0
+        got = ops.to_host(t)
+        assert got.dtype == np.float64 and got.shape == (n,) and np.array_equal(got, t.cpu().numpy())
+    t = pt.arange(9_000_001 * 3, dtype=pt.int32, device="cuda").reshape(-1, 3)
+    assert np.array_equal(ops.to_host(t), t.cpu().numpy())

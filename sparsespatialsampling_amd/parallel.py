@@ -210,8 +210,26 @@ def init(backend=None):
         os.environ.setdefault("MASTER_PORT", "29500")
         store, _, _ = next(dist.rendezvous("env://", rank=rank, world_size=world_size))
         store = dist.PrefixStore("s3_comm", store)
-        _comm = RcclComm(rank, world_size, store)
-        _comm._store = store            # keep the rendezvous alive as long as the communicator
+        try:
+            _comm, reason = RcclComm(rank, world_size, store), ""
+        except Exception as err:         # librccl missing, communicator refused, ...
+            _comm, reason = None, str(err)
+        # every rank must end up with the same kind of communicator: agree through the store
+        store.set(f"rccl_ok_{rank}", b"1" if _comm is not None else b"0")
+        if all(store.get(f"rccl_ok_{r}") == b"1" for r in range(world_size)):
+            _comm._store = store         # keep the rendezvous alive as long as the communicator
+        else:
+            import logging
+            logging.getLogger(__name__).warning("RCCL communicator not available on every rank (%s): the exchange steps go "
+                                                "through a gloo group instead.", reason or "another rank failed")
+            if _comm is not None:
+                _comm.close()
+            own = not dist.is_initialized()
+            if own:
+                dist.init_process_group("gloo", rank=rank, world_size=world_size)
+            _comm = GlooComm()
+            _comm._own_group = own
+            _comm.name = "gloo (RCCL communicator could not be created)"
     else:
         _comm = SoloComm()
     return _comm
@@ -237,6 +255,10 @@ def shutdown():
     global _comm
     if _comm is not None:
         _comm.close()
+        if getattr(_comm, "_own_group", False):
+            import torch.distributed as dist
+            if dist.is_initialized():
+                dist.destroy_process_group()
         _comm = None
 
 

@@ -99,3 +99,21 @@ def test_sharded_export_matches_single_rank(tmp_path):
             for name in a.keys(f"data/{t}"):
                 assert np.array_equal(a.read(f"data/{t}/{name}"), b.read(f"data/{t}/{name}")), f"data/{t}/{name}"
     assert open(os.path.join(d1, "case.xdmf")).read() == open(os.path.join(d3, "case.xdmf")).read()
+
+
+@pytest.mark.gpu
+def test_ranks_agree_on_a_gloo_group_when_rccl_refuses():
+    """two ranks on ONE GPU ask for the RCCL communicator: RCCL refuses the duplicate device on both, the ranks find that out
+    through the rendezvous store and carry the exchange steps of the refine over a gloo group instead; the bench line says
+    so and the grid is the single-rank one"""
+    import json
+    env = dict(os.environ, S3_BENCH_SHARE_GPU="1")
+    env.pop("S3_DIST_BACKEND", None)
+    base = [os.path.join(ROOT, "bench.py"), "--workload", "cylinder3D_small", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", "29617"] + base + ["--gpus", "2"], cwd=ROOT, env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert two.returncode == 0, two.stderr[-3000:]
+    r2 = json.loads(two.stdout.strip().splitlines()[-1])
+    assert r2["n_gpus"] == 2 and r2["config"]["collectives"].startswith("gloo (RCCL")
+    assert r2["config"]["n_cells"] == 12942 and sum(r2["config"]["cells_per_rank"]) == 12942

@@ -65,10 +65,15 @@ class SparseSpatialSampling:
 
     def execute_grid_generation(self) -> None:
         """Run S^3, take over the grid and persist the mesh info and this object (reference lines 116-146)."""
-        os.makedirs(self.save_path, exist_ok=True)
+        # with several ranks (one process per GPU, parallel.py) every rank generates the same grid and rank 0 writes the files
+        from . import parallel
+        writes = parallel.get_comm().rank == 0
+        if writes:
+            os.makedirs(self.save_path, exist_ok=True)
         tree = self._sampling
         tree.refine()
-        pt.save(tree.data_final_mesh, os.path.join(self.save_path, f"mesh_info_{self.save_name}.pt"))
+        if writes:
+            pt.save(tree.data_final_mesh, os.path.join(self.save_path, f"mesh_info_{self.save_name}.pt"))
 
         self.centers, self.levels = tree.all_centers, tree.all_levels
         self.vertices, self.faces = tree.all_nodes, tree.face_ids
@@ -77,7 +82,8 @@ class SparseSpatialSampling:
         # drop the tree: frees the device arrays and leaves a CPU-only, picklable object
         tree.close()
         self._sampling = None
-        pt.save(self, os.path.join(self.save_path, f"s_cube_{self.save_name}.pt"))
+        if writes:
+            pt.save(self, os.path.join(self.save_path, f"s_cube_{self.save_name}.pt"))
 
     def _check_input(self) -> None:
         """Validate / repair the user input (same conditions and exception types as reference lines 148-186)."""

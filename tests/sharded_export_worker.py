@@ -25,18 +25,15 @@ def main(out_dir):
     comm = parallel.init()
     assert (comm.rank, comm.world) == (rank, world)
     x, y, geos, kw = refine_inputs("refine_3d_metric", geometry)
-    own = os.path.join(out_dir, f"grid_rank{rank}")          # the grid files of SparseSpatialSampling: one copy per rank
-    os.makedirs(own, exist_ok=True)
-    s3 = SparseSpatialSampling(pt.from_numpy(x), pt.from_numpy(y), geos, own, "case", uniform_levels=kw["uniform_level"],
+    s3 = SparseSpatialSampling(pt.from_numpy(x), pt.from_numpy(y), geos, out_dir, "case", uniform_levels=kw["uniform_level"],
                                min_metric=kw["min_metric"])
-    s3.execute_grid_generation()
+    s3.execute_grid_generation()                              # every rank generates the grid, rank 0 writes its files
     n_t = 11
     times = [f"{0.1 * i:.1f}" for i in range(n_t)]
     rng = np.random.default_rng(21)
     p = rng.standard_normal((len(x), 1, n_t)).astype(np.float32)
     u = rng.standard_normal((len(x), 3, n_t))                 # float64 rows
     ex = ExportData(s3, write_times=times, interpolate_at_vertices=True)
-    ex.save_dir = out_dir
     for a, b in ((0, 6), (6, 11)):
         ex.export(pt.from_numpy(x), pt.from_numpy(p[:, :, a:b]), "p", n_snapshots_total=n_t)
     ex.export(pt.from_numpy(x), pt.from_numpy(u), "U")

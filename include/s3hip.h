@@ -283,7 +283,8 @@ int s3_topo_refine(s3_topo *topo, const int64_t *h_parents, int64_t n, int relin
 int s3_topo_relink_parent_of(s3_topo *topo, const int64_t *h_cells, int64_t n);
 /* children = [] and removal from the neighbours' rows, in list order (s_cube.py:721-728) */
 int s3_topo_mark_invalid(s3_topo *topo, const int64_t *h_cells, int64_t n);
-/* wait for the submitted updates; *h_error != 0: a listed parent was not a leaf or listed twice */
+/* wait for the submitted updates; *h_error: 0 ok, 1 a listed parent was not a leaf or listed twice, 2 internal (a node
+ * reference chain of a batch did not resolve) */
 int s3_topo_sync(s3_topo *topo, int64_t *h_n_cells, int64_t *h_n_nodes, int *h_error);
 /* device pointer of a table: 0 level i32, 1 parent i32, 2 first_child i32 (-1 leaf, -2 invalid), 3 nb i32 [n][8|26],
  * 4 node_idx i64 [n][2^d], 5 center f64 [n][d], 6 nodes f64 [n_nodes][d]; valid until the next update */

@@ -278,7 +278,13 @@ topo_resolve_kernel(TopoView t, int64_t n, int64_t first) {
     const size_t at = (size_t)first * t.nch + (size_t)e;
     int64_t v = tab[at];
     if (!is_ref(v)) return;
-    while (is_ref(v)) v = tab[(size_t)dec_ref(v)];
+    // a lattice point is shared by at most 2^d cells, so a chain has at most 2^d - 1 links; the bound is the exit every
+    // wave reaches whatever the tables hold
+    for (int hop = 0; hop < 64 && is_ref(v); ++hop) v = tab[(size_t)dec_ref(v)];
+    if (is_ref(v)) {
+        atomicExch(reinterpret_cast<unsigned long long *>(&t.counters[1]), 2ull);
+        return;
+    }
     tab[at] = v;
 }
 
@@ -346,6 +352,7 @@ topo_relink_compute_kernel(TopoView t, const int64_t *__restrict__ cells, int64_
         if (g < 0) break;
         const int32_t tg = last_refresh_before(t, g, when);
         if (tg < 0) break;
+        if (depth == 63) break;                            // (deeper than any tree: level <= 63)
         path[depth++] = (int8_t)(a - t.first_child[g]);
         a = g;
         when = tg;

@@ -269,6 +269,8 @@ class _DeviceTopology(_Topology):
             return
         n_cells, n_nodes, err = C.c_int64(0), C.c_int64(0), C.c_int(0)
         self._ops.check(self._hip.s3_topo_sync(self._h, C.byref(n_cells), C.byref(n_nodes), C.byref(err)), "s3_topo_sync")
+        if err.value == 2:
+            raise RuntimeError("topology engine: a node reference chain did not resolve (internal error)")
         if err.value != 0:
             raise RuntimeError("topology engine: tried to refine a cell that is not a leaf")
         if n_cells.value != self.n_created:

@@ -361,7 +361,8 @@ def main():
                          "copy_kernel_GBs": copy_bw, "frac_of_copy_kernel": achieved / copy_bw,
                          "traffic": traffic, "traffic_source": None if traffic is None else f"recorded, not measured in this run: {traffic_src}",
                          "kernel": "interp_kernel<float,4>" if plan is None else
-                                   ("interp_planned_short_reg_kernel<float,26>" if short else "interp_planned_kernel<float,64>"),
+                                   (("interp_planned_short_quad_kernel<float,7>" if t_b * 4 == 64 and not os.environ.get("S3_SHORT_NO_QUAD")
+                                     else "interp_planned_short_reg_kernel<float,26>") if short else "interp_planned_kernel<float,64>"),
                          "staged_rows_per_launch": None if plan is None else plan.total_rows, "kernel_ms": kernel_ms,
                          "algorithmic_bytes": b_alg, "resident_source_rows": n_rows, "cells_on_this_rank": nc,
                          "gather_upper_bound_bytes": nc * k * t_b * 4 + nc * t_b * 8},

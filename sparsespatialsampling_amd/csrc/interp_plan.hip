@@ -241,6 +241,92 @@ interp_planned_short_reg_kernel(const int32_t *__restrict__ perm, const int32_t 
     store_piece<EPV>(out + cell * row_len + col, acc, row_len - col, even_rows);
 }
 
+// Short rows of exactly four vectors (16 fp32 snapshots -- SURVEY C4 -- or 8 f64 values): the four lanes of a cell are one
+// DPP quad, so each lane loads only every fourth weight / position of its cell (7 + 7 loads instead of 26 + 26 one-line
+// transactions per lane: the memory pipeline of the kernel above spends more instructions on the tile's tables than on
+// its rows) and the quad broadcasts them when the neighbour's turn comes.  45 fewer registers per lane: five workgroups
+// per CU.  Same arithmetic, same results.
+template <int J>
+__device__ __forceinline__ int quad_bcast_i32(int v) {
+    return __builtin_amdgcn_update_dpp(v, v, J | (J << 2) | (J << 4) | (J << 6), 0xf, 0xf, false);
+}
+template <int J>
+__device__ __forceinline__ double quad_bcast_f64(double x) {
+    const long long b = __double_as_longlong(x);
+    const int lo = quad_bcast_i32<J>((int)(b & 0xffffffffll)), hi = quad_bcast_i32<J>((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+template <typename T, int KQ>        // KQ = ceil(k / 4) values of each table per lane
+__global__ void __launch_bounds__(256, 5)
+interp_planned_short_quad_kernel(const int32_t *__restrict__ perm, const int32_t *__restrict__ tile_cell_begin,
+                                 const int32_t *__restrict__ tile_row_begin, const int32_t *__restrict__ rows,
+                                 const uint16_t *__restrict__ loc, const double *__restrict__ w /*plan order*/, int k,
+                                 const T *__restrict__ data, int64_t row_len, int64_t in_stride, double *__restrict__ out,
+                                 int64_t n_tiles, int64_t tiles_per_xcd) {
+    using V = typename Vec16<T>::type;
+    constexpr int EPV = Vec16<T>::N;
+    constexpr int BLOCK = 256, UN = 8, VC = 4;
+    extern __shared__ float4 lds_raw[];
+    V *s_data = reinterpret_cast<V *>(lds_raw);                  // [n_r][4]
+
+    const int64_t b = blockIdx.x;
+    const int64_t tile = (b & 7) * tiles_per_xcd + (b >> 3);
+    if (tile >= n_tiles) return;
+    const int c_begin = tile_cell_begin[tile], n_c = tile_cell_begin[tile + 1] - c_begin;
+    const int r_begin = tile_row_begin[tile], n_r = tile_row_begin[tile + 1] - r_begin;
+    const bool even_rows = (row_len & 1) == 0;
+
+    const int n_items = n_r * VC;
+    V reg[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+        const int item = min(u * BLOCK + (int)threadIdx.x, n_items - 1);
+        reg[u] = *reinterpret_cast<const V *>(data + (int64_t)rows[r_begin + (item >> 2)] * in_stride + (int64_t)(item & 3) * EPV);
+    }
+    const int cl = min((int)threadIdx.x >> 2, n_c - 1), v = (int)threadIdx.x & 3;
+    const bool has_item = ((int)threadIdx.x >> 2) < n_c;
+    const double *wt = w + (int64_t)c_begin * k + cl;
+    const uint16_t *lt = loc + (int64_t)c_begin * k + cl;
+    double wq[KQ];
+    int pq[KQ];
+#pragma unroll
+    for (int i = 0; i < KQ; ++i) {
+        const int m = i * 4 + v, mm = m < k ? m : 0;
+        wq[i] = wt[(int64_t)mm * n_c];
+        pq[i] = lt[(int64_t)mm * n_c];
+    }
+    const int64_t cell = perm[c_begin + cl];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+        const int item = u * BLOCK + (int)threadIdx.x;
+        if (item < n_items) s_data[item] = reg[u];
+    }
+    __syncthreads();
+    double acc[EPV];
+#pragma unroll
+    for (int i = 0; i < EPV; ++i) acc[i] = 0.0;
+    auto step = [&](double wm, int pos) {
+        const V a = s_data[pos * VC + v];
+        const T *ae = reinterpret_cast<const T *>(&a);
+#pragma unroll
+        for (int i = 0; i < EPV; ++i) acc[i] = fma(wm, (double)ae[i], acc[i]);
+    };
+#pragma unroll
+    for (int i = 0; i < KQ; ++i) {
+        // (every lane of the wavefront takes part in the broadcasts; lanes without a cell hold a clamped copy)
+        const double w0 = quad_bcast_f64<0>(wq[i]), w1 = quad_bcast_f64<1>(wq[i]), w2 = quad_bcast_f64<2>(wq[i]), w3 = quad_bcast_f64<3>(wq[i]);
+        const int p0 = quad_bcast_i32<0>(pq[i]), p1 = quad_bcast_i32<1>(pq[i]), p2 = quad_bcast_i32<2>(pq[i]), p3 = quad_bcast_i32<3>(pq[i]);
+        if (i * 4 + 0 < k) step(w0, p0);
+        if (i * 4 + 1 < k) step(w1, p1);
+        if (i * 4 + 2 < k) step(w2, p2);
+        if (i * 4 + 3 < k) step(w3, p3);
+    }
+    if (!has_item) return;
+    const int64_t col = (int64_t)v * EPV;
+    store_piece<EPV>(out + cell * row_len + col, acc, row_len - col, even_rows);
+}
+
 template <typename T, int TC>
 __global__ void __launch_bounds__(TC * 4, 2)  // 226 VGPRs: two waves per SIMD
 interp_planned_kernel(const int32_t *__restrict__ perm, const int32_t *__restrict__ tile_cell_begin,
@@ -397,6 +483,23 @@ static int launch_planned(const s3_interp_plan *p, const void *data, int64_t row
     S3_REQUIRE(gx < ((int64_t)1 << 31), "s3_interp_planned: too many tiles");
     if ((row_len + EPV - 1) / EPV <= s3::short_row_vecs() && p->tc == 64) {
         const int vpr = (int)((row_len + EPV - 1) / EPV);
+        if (vpr == 4 && p->ucap * vpr <= 256 * 8 && p->k <= 32 && !getenv("S3_SHORT_NO_QUAD") && !getenv("S3_SHORT_LDS_WEIGHTS")) {
+            // four vectors per row: the lanes of a cell are a DPP quad and share the loads of its weights / positions
+            const size_t lds = (size_t)p->ucap * vpr * 16;
+#define S3_LAUNCH_SHORT_QUAD(KQ)                                                                                                 \
+    do {                                                                                                                         \
+        auto kern = interp_planned_short_quad_kernel<T, KQ>;                                                                     \
+        kern<<<dim3((unsigned)gx), 256, lds, st>>>(p->perm, p->tile_cell_begin, p->tile_row_begin, p->rows, p->loc, p->wp, p->k, \
+                                                   static_cast<const T *>(data), row_len, in_stride, out, p->n_tiles,            \
+                                                   tiles_per_xcd);                                                               \
+    } while (0)
+            if (p->k <= 8) S3_LAUNCH_SHORT_QUAD(2);
+            else if (p->k <= 28) S3_LAUNCH_SHORT_QUAD(7);
+            else S3_LAUNCH_SHORT_QUAD(8);
+#undef S3_LAUNCH_SHORT_QUAD
+            S3_LAUNCH_CHECK();
+            return S3_OK;
+        }
         if (vpr <= 4 && p->ucap * vpr <= 256 * 8 && p->k <= 32 && !getenv("S3_SHORT_LDS_WEIGHTS")) {
             // one lane per (cell, vector) pair, weights in registers
             const size_t lds = (size_t)p->ucap * vpr * 16;

@@ -122,3 +122,27 @@ def test_refine_runs_on_the_device_engine_and_equals_the_host_engine(monkeypatch
     tree = SamplingTree(pt.from_numpy(x2), pt.from_numpy(y2), geometry_obj=geos2, **kw2)
     assert type(tree._topo_engine).__name__ == "_Topology"          # max_delta_level=True reads single rows between updates
     tree.close()
+
+
+def test_device_engine_releases_its_memory():
+    """create / refine / finalize / close in a loop: the free device memory (hipMemGetInfo, which sees the engine's own
+    hipMalloc allocations) ends where it started"""
+    import torch as pt
+    from sparsespatialsampling_amd.s_cube import _DeviceTopology
+    pt.cuda.synchronize()
+    free_before = None
+    for it in range(12):
+        dev = _DeviceTopology(3, 1.0, np.array([0.5, 0.5, 0.5]))
+        leaves = np.array([0], dtype=np.int64)
+        for _ in range(5):                                           # 8^5 = 32768 leaves, several table growths
+            first = dev.submit_refine(leaves, relink=1)
+            leaves = np.arange(first, first + len(leaves) * 8, dtype=np.int64)
+        dev.submit_mark_invalid(leaves[:100])
+        dev.submit_relink_parent_of(leaves[100:5000])
+        faces, nodes = dev.finalize(np.int32)
+        assert faces.shape == (len(leaves) - 100, 8)
+        dev.close()
+        pt.cuda.synchronize()
+        if it == 1:                                                  # (the first round also loads code objects / creates pools)
+            free_before = pt.cuda.mem_get_info()[0]
+    assert abs(pt.cuda.mem_get_info()[0] - free_before) <= (8 << 20), "device memory of closed engines is not released"

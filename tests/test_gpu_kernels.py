@@ -663,3 +663,24 @@ def test_staged_download_equals_plain_copy(ops):
         assert got.dtype == np.float64 and got.shape == (n,) and np.array_equal(got, t.cpu().numpy())
     t = pt.arange(9_000_001 * 3, dtype=pt.int32, device="cuda").reshape(-1, 3)
     assert np.array_equal(ops.to_host(t), t.cpu().numpy())
+
+
+@pytest.mark.parametrize("k", [1, 5, 8, 9, 26, 28, 29, 32])
+def test_short_quad_kernel_equals_direct_gather(ops, k):
+    """rows of exactly four 16-byte vectors take the quad-sharing kernel (the lanes of a cell split the loads of its weights /
+    positions and broadcast them with DPP): every k class (2, 7, 8 values per lane), full and ragged rows, both dtypes,
+    partly filled last tiles -- bit-equal to the direct gather kernel"""
+    rng = np.random.default_rng(100 + k)
+    n, nc = 9000, 1000 + 37 * k
+    x = rng.random((n, 3))
+    knn = ops.KnnIndex(x)
+    idx, dist = knn.query(rng.random((nc, 3)), k)
+    knn.close()
+    w = ops.idw_weights(dist)
+    plan = ops.InterpPlan(idx, n, None)
+    for dtype, lengths in ((pt.float32, (13, 14, 15, 16)), (pt.float64, (7, 8))):
+        for row_len in lengths:
+            data = ops.padded_rows(n, row_len, dtype, "cuda")
+            data.normal_()
+            assert pt.equal(plan.interp(w, data), ops.interp(w, idx, data.contiguous())), (k, dtype, row_len)
+    plan.close()

@@ -14,7 +14,11 @@ tree = SamplingTree(pt.from_numpy(x), pt.from_numpy(metric), geos, **kw); tree.r
 centers = tree.all_centers.numpy(); tree.close()
 k, nc_total = 26, len(centers)
 knn = hipops.KnnIndex(x, hipops.knn_occupancy(k, 3))
-for world in (1, 2, 4, 8):
+# S3_PROBE_T_SPLIT=2: at 8 ranks the hybrid decomposition of bench.py (4 leaf-cell shards x 2 halves of the snapshot axis)
+t_split = int(os.environ.get("S3_PROBE_T_SPLIT", "1"))
+for world_total in (1, 2, 4, 8):
+    wt = t_split if world_total >= 8 else 1
+    world, T = world_total // wt, 1000 // wt
     worst = 0.0
     for rank in range(world):
         if world > 1 and os.environ.get("S3_PROBE_CREATION_ORDER") != "1":
@@ -41,5 +45,5 @@ for world in (1, 2, 4, 8):
         worst = max(worst, ms)
         print(f"  W={world} rank {rank}: {len(mine)} cells, {n} resident rows, {plan.total_rows} staged rows, {plan.n_tiles} tiles: {ms:.3f} ms", flush=True)
         del plan, data, out, idx, w
-    print(f"W={world}: slowest shard {worst:.3f} ms -> {nc_total * T / worst / 1e6:.0f} G cell*snapshots/s whole job")
+    print(f"W={world_total} ({world} cell shards x {wt} snapshot parts): slowest shard {worst:.3f} ms -> {nc_total * 1000 / worst / 1e6:.0f} G cell*snapshots/s whole job")
 knn.close()

@@ -284,7 +284,11 @@ class _DeviceTopology(_Topology):
             self._hip.s3_topo_destroy(h)
         self._h_raw = None
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # interpreter shutdown
+            pass
 
     @property
     def n_cells(self):

@@ -51,7 +51,9 @@ int s3h5_write(s3h5_file *f, const char *path, int dtype, int ndim, const int64_
 /* the datasets of one snapshot batch: for i < n_snapshots the dataset `data/<times[i]>/<name>` of shape dims[0..ndim)
  * is written from h_base + i * stride_bytes (snapshot-major host buffer).  Asynchronous: the call
  * returns once the batch is queued; h_base must stay valid until s3h5_flush / s3h5_close / the next s3h5_wait_buffer on it.
- * Datasets that exist already are skipped and counted (reference data.py:404-407 logs and skips). */
+ * Datasets that exist already are skipped and counted (reference data.py:404-407 logs and skips).  Datasets of a megabyte
+ * or more are created by the library (contiguous, allocated at creation) and their values written by several threads
+ * straight into the file at the offsets the library reports. */
 int s3h5_write_snapshots_async(s3h5_file *f, const char *group /* "data" */, const char *const *times, int64_t n_snapshots,
                                const char *name, int dtype, int ndim, const int64_t *dims, const void *h_base,
                                int64_t stride_bytes);

@@ -4,11 +4,20 @@
 // data/<time>/), the per-write-time loop of ExportData._write_data_to_hdf5 (export.py:283-299) and the reads of Dataloader /
 // XDMFWriter (data.py:22-300, 504-777).  The on-disk layout is the reference's; what differs is how it gets there: a whole
 // snapshot batch is queued with one call and written by a background thread from the snapshot-major host buffer while
-// the GPU works on the next batch.
+// the GPU works on the next batch.  The HDF5 library does one thing at a time, and a single thread copies into the page
+// cache at ~4 GB/s -- less than the GPU path delivers -- so the background thread only lets HDF5 create the datasets of a
+// batch (contiguous layout, space allocated at creation, no fill values), asks for their file offsets (H5Dget_offset) and
+// has a few threads pwrite() the raw values there through a second descriptor of the same file.
 #include "s3h5.h"
 
 #include <hdf5.h>
 
+#include <fcntl.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cerrno>
 #include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
@@ -52,9 +61,15 @@ struct Job {
 
 }  // namespace
 
+struct Segment { off_t offset; const char *data; size_t bytes; };
+
 struct s3h5_file {
     hid_t fid = -1;
     bool writable = false;
+    std::string os_path;                 // for the second descriptor of the raw writes
+    int raw_fd = -1;
+    bool raw_refused = false;
+    std::vector<std::pair<const char *, size_t>> busy_batch;      // buffers of the batch being written
     std::deque<Job> queue;
     std::mutex m;
     std::condition_variable cv_work, cv_idle;
@@ -92,6 +107,92 @@ struct s3h5_file {
         return rc;
     }
 
+    // values of a dataset that exists already, through the library (the fallback of the raw path)
+    int write_existing_locked(const std::string &path, int dtype, const void *data) {
+        hid_t ds = H5Dopen2(fid, path.c_str(), H5P_DEFAULT);
+        if (ds < 0) { set_error("could not open dataset '%s'", path.c_str()); return S3H5_EIO; }
+        const int rc = H5Dwrite(ds, mem_type(dtype), H5S_ALL, H5S_ALL, H5P_DEFAULT, data) < 0 ? S3H5_EIO : S3H5_OK;
+        if (rc != S3H5_OK) set_error("could not write dataset '%s'", path.c_str());
+        H5Dclose(ds);
+        return rc;
+    }
+
+    // dataset with its space allocated now and no fill values written: returns its address in the file through *offset, or
+    // S3H5_EIO with *offset = -1 when the library gives none (the caller then writes through H5Dwrite).  Holds g_hdf5.
+    int create_raw_locked(const std::string &path, int dtype, int ndim, const hsize_t *dims, off_t *offset) {
+        *offset = -1;
+        const hid_t mt = mem_type(dtype);
+        if (mt < 0) { set_error("unknown element type %d", dtype); return S3H5_EINVAL; }
+        hid_t lcpl = H5Pcreate(H5P_LINK_CREATE), dcpl = H5Pcreate(H5P_DATASET_CREATE);
+        H5Pset_create_intermediate_group(lcpl, 1);
+        H5Pset_layout(dcpl, H5D_CONTIGUOUS);
+        H5Pset_alloc_time(dcpl, H5D_ALLOC_TIME_EARLY);
+        H5Pset_fill_time(dcpl, H5D_FILL_TIME_NEVER);
+        hid_t space = H5Screate_simple(ndim, dims, nullptr);
+        hid_t ds = H5Dcreate2(fid, path.c_str(), mt, space, lcpl, dcpl, H5P_DEFAULT);
+        int rc = S3H5_OK;
+        if (ds < 0) {
+            set_error("could not create dataset '%s'", path.c_str());
+            rc = S3H5_EIO;
+        } else {
+            const haddr_t a = H5Dget_offset(ds);
+            if (a != HADDR_UNDEF) *offset = (off_t)a;
+            H5Dclose(ds);
+        }
+        H5Sclose(space);
+        H5Pclose(dcpl);
+        H5Pclose(lcpl);
+        return rc;
+    }
+
+    // the second descriptor of the file (without it every dataset goes through H5Dwrite)
+    bool raw_ready() {
+        if (raw_fd < 0 && !raw_refused) {
+            raw_fd = ::open(os_path.c_str(), O_WRONLY);
+            raw_refused = raw_fd < 0;
+        }
+        return raw_fd >= 0;
+    }
+
+    // raw values of several datasets straight into the file, a few threads, 4-MiB pieces; 0 or an errno
+    int write_segments(const std::vector<Segment> &segs) {
+        if (segs.empty()) return 0;
+        constexpr size_t PIECE = (size_t)4 << 20;
+        struct Piece { off_t off; const char *p; size_t n; };
+        std::vector<Piece> pieces;
+        size_t total = 0;
+        for (const Segment &g : segs) {
+            for (size_t o = 0; o < g.bytes; o += PIECE) pieces.push_back({g.offset + (off_t)o, g.data + o, std::min(PIECE, g.bytes - o)});
+            total += g.bytes;
+        }
+        std::atomic<size_t> next{0};
+        std::atomic<int> err{0};
+        auto work = [&] {
+            while (err.load() == 0) {
+                const size_t i = next.fetch_add(1);
+                if (i >= pieces.size()) break;
+                const Piece &pc = pieces[i];
+                size_t done = 0;
+                while (done < pc.n) {
+                    const ssize_t w = ::pwrite(raw_fd, pc.p + done, pc.n - done, pc.off + (off_t)done);
+                    if (w < 0) {
+                        if (errno == EINTR) continue;
+                        err = errno ? errno : EIO;
+                        return;
+                    }
+                    done += (size_t)w;
+                }
+            }
+        };
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        const int n_thr = (int)std::min<size_t>({(size_t)6, (size_t)std::max(1u, hw / 2), std::max<size_t>(1, total / ((size_t)8 << 20))});
+        std::vector<std::thread> threads;
+        for (int t = 1; t < n_thr; ++t) threads.emplace_back(work);
+        work();
+        for (auto &t : threads) t.join();
+        return err.load();
+    }
+
     // an intermediate path component that exists as a link makes H5Lexists on the full path safe only step by step
     bool exists_locked(const std::string &path) {
         size_t pos = 0;
@@ -109,29 +210,57 @@ struct s3h5_file {
             H5Eset_auto2(H5E_DEFAULT, nullptr, nullptr);      // the error stack (and its printing) is per thread
         }
         while (true) {
-            Job j;
+            std::vector<Job> batch;
             {
                 std::unique_lock<std::mutex> lk(m);
                 cv_work.wait(lk, [this] { return stop || !queue.empty(); });
                 if (queue.empty()) return;
-                j = std::move(queue.front());
-                queue.pop_front();
-                busy_data = j.data;
-                busy_bytes = j.bytes;
+                // everything queued so far (one snapshot batch, normally) is written together
+                while (!queue.empty()) {
+                    batch.push_back(std::move(queue.front()));
+                    queue.pop_front();
+                }
+                busy_batch.clear();
+                for (const Job &j : batch) busy_batch.emplace_back(static_cast<const char *>(j.data), j.bytes);
+                busy_data = batch.front().data;
+                busy_bytes = batch.front().bytes;
             }
-            int rc;
+            int rc = S3H5_OK, n_skipped = 0;
             std::string msg;
+            std::vector<Segment> segs;
             {
                 std::lock_guard<std::mutex> h(g_hdf5);
-                rc = exists_locked(j.path) ? S3H5_EEXIST : write_locked(j.path, j.dtype, j.ndim, j.dims, j.data);
-                if (rc != S3H5_OK) msg = g_err;
+                for (const Job &j : batch) {
+                    int r;
+                    if (exists_locked(j.path)) {
+                        r = S3H5_EEXIST;
+                    } else if (j.ndim >= 1 && j.bytes >= ((size_t)1 << 20) && raw_ready()) {
+                        off_t off = -1;
+                        r = create_raw_locked(j.path, j.dtype, j.ndim, j.dims, &off);
+                        if (r == S3H5_OK && off >= 0) segs.push_back({off, static_cast<const char *>(j.data), j.bytes});
+                        else if (r == S3H5_OK) r = write_existing_locked(j.path, j.dtype, j.data);
+                    } else {
+                        r = write_locked(j.path, j.dtype, j.ndim, j.dims, j.data);
+                    }
+                    if (r == S3H5_EEXIST) ++n_skipped;
+                    else if (r != S3H5_OK && rc == S3H5_OK) { rc = r; msg = g_err; }
+                }
+                if (!segs.empty()) H5Fflush(fid, H5F_SCOPE_LOCAL);      // the datasets' space exists in the file before it is written to
+            }
+            if (rc == S3H5_OK) {
+                const int e = write_segments(segs);
+                if (e != 0) {
+                    rc = S3H5_EIO;
+                    msg = std::string("raw write failed: ") + strerror(e);
+                }
             }
             {
                 std::lock_guard<std::mutex> lk(m);
-                if (rc == S3H5_EEXIST) ++skipped;
-                else if (rc != S3H5_OK && async_error == 0) { async_error = rc; async_message = msg; }
+                skipped += n_skipped;
+                if (rc != S3H5_OK && async_error == 0) { async_error = rc; async_message = msg; }
                 busy_data = nullptr;
                 busy_bytes = 0;
+                busy_batch.clear();
             }
             cv_idle.notify_all();
         }
@@ -171,6 +300,7 @@ int s3h5_open(const char *path, const char *mode, s3h5_file **out) {
     s3h5_file *f = new s3h5_file();
     f->fid = fid;
     f->writable = writable;
+    f->os_path = path;
     *out = f;
     return S3H5_OK;
 }
@@ -200,6 +330,8 @@ int s3h5_wait_buffer(s3h5_file *f, const void *h_base, size_t bytes) {
     std::unique_lock<std::mutex> lk(f->m);
     f->cv_idle.wait(lk, [&] {
         if (overlaps(f->busy_data, f->busy_bytes)) return false;
+        for (const auto &b : f->busy_batch)
+            if (overlaps(b.first, b.second)) return false;
         for (const Job &j : f->queue)
             if (overlaps(j.data, j.bytes)) return false;
         return true;
@@ -216,6 +348,7 @@ int s3h5_close(s3h5_file *f) {
     }
     f->cv_work.notify_all();
     if (f->worker.joinable()) f->worker.join();
+    if (f->raw_fd >= 0) ::close(f->raw_fd);
     {
         std::lock_guard<std::mutex> h(g_hdf5);
         if (f->fid >= 0 && H5Fclose(f->fid) < 0 && rc == S3H5_OK) { set_error("H5Fclose failed"); rc = S3H5_EIO; }

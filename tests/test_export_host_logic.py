@@ -279,3 +279,40 @@ def test_append_and_file_per_field(export_mod, tmp_path):
         part = dump(os.path.join(str(tmp_path), f"split_{field}.h5"))
         assert "grid/faces" in part and f"data/0.0/{field}_center" in part and len([k for k in part if k.startswith("data/")]) == t_total
         assert os.path.exists(os.path.join(str(tmp_path), f"split_{field}.xdmf"))
+
+
+def test_large_snapshots_take_the_raw_write_path_and_read_back(tmp_path):
+    """datasets of a megabyte or more are created by HDF5 (space allocated at creation) and their values written by several
+    threads straight into the file at the offsets HDF5 reports: the file must read back -- through the library -- exactly
+    as written, also mixed with small datasets, a second batch, an existing dataset in the batch and a re-opened file"""
+    from sparsespatialsampling_amd import h5io
+    if h5io.native_lib() is None:
+        pytest.skip("native HDF5 sink not built")
+    rng = np.random.default_rng(11)
+    path = os.path.join(str(tmp_path), "raw.h5")
+    n = 300_001                                               # 2.4 MB per scalar snapshot, not a multiple of anything
+    a = rng.standard_normal((5, n))
+    b = rng.standard_normal((3, n, 2)).astype(np.float32)     # 2.4 MB per snapshot, two components
+    small = rng.standard_normal((4, 100))
+    with h5io.open_h5(path, "w") as f:
+        f.write("grid/centers", rng.random((n, 2)))
+        f.write_snapshots([f"{0.1 * i:.1f}" for i in range(5)], "p_center", a)
+        f.write_snapshots([f"{0.1 * i:.1f}" for i in range(3)], "U_center", b)
+        f.write_snapshots([f"{0.1 * i:.1f}" for i in range(4)], "q_center", small)
+        assert f.flush() == 0
+        f.write_snapshots(["0.4", "0.5"], "p_center", a[:2].copy())            # "0.4" exists: skipped, "0.5" is new
+        assert f.flush() == 1
+        assert np.array_equal(f.read("data/0.3/p_center"), a[3])               # readable while the file is still open
+    with h5io.open_h5(path, "r") as f:
+        for i in range(5):
+            assert np.array_equal(f.read(f"data/{0.1 * i:.1f}/p_center"), a[i])
+        for i in range(3):
+            got = f.read(f"data/{0.1 * i:.1f}/U_center")
+            assert got.dtype == np.float32 and np.array_equal(got, b[i])
+        for i in range(4):
+            assert np.array_equal(f.read(f"data/{0.1 * i:.1f}/q_center"), small[i])
+        assert np.array_equal(f.read("data/0.5/p_center"), a[1])
+    with h5io.open_h5(path, "a") as f:                                         # append to the finished file
+        f.write_snapshots(["0.6"], "p_center", a[4:5].copy())
+    with h5io.open_h5(path, "r") as f:
+        assert np.array_equal(f.read("data/0.6/p_center"), a[4]) and np.array_equal(f.read("data/0.0/p_center"), a[0])

@@ -95,3 +95,34 @@ def test_shard_range_covers_everything():
             assert all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
             sizes = [b - a for a, b in parts]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _fallback_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT) if ROOT not in sys.path else None
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.pop("S3_DIST_BACKEND", None)
+    import logging
+    logging.getLogger().setLevel(logging.ERROR)
+    from sparsespatialsampling_amd import parallel
+    comm = parallel.init()                   # asks for RCCL; there is no GPU here, so no rank gets a communicator
+    a = pt.zeros(2 * 5, dtype=pt.float64)
+    a[rank * 5:(rank + 1) * 5] = pt.arange(5, dtype=pt.float64) + 10 * rank
+    comm.allgather_inplace([a], [5])
+    res = dict(name=comm.name, world=(comm.rank, comm.world), gathered=a.numpy().copy(), mx=comm.allreduce_max(float(rank + 1)))
+    gathered = [None] * world
+    dist.all_gather_object(gathered, res)
+    if rank == 0:
+        pt.save(gathered, out)
+    parallel.shutdown()
+    assert not dist.is_initialized()         # the group the fallback created is the fallback's to destroy
+
+
+def test_ranks_without_rccl_agree_on_gloo(tmp_path):
+    """``parallel.init()`` with two ranks and no usable RCCL communicator (no GPU in the process): the ranks learn through the
+    rendezvous store that nobody has one and carry the exchange steps over a gloo group they create themselves"""
+    out = str(tmp_path / "res.pt")
+    mp.spawn(_fallback_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = pt.load(out, weights_only=False)
+    for r, res in enumerate((r0, r1)):
+        assert res["name"].startswith("gloo (RCCL") and res["world"] == (r, 2) and res["mx"] == 2.0
+        assert np.array_equal(res["gathered"], np.array([0, 1, 2, 3, 4, 10, 11, 12, 13, 14], dtype=np.float64))

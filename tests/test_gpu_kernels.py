@@ -684,3 +684,28 @@ def test_short_quad_kernel_equals_direct_gather(ops, k):
             data.normal_()
             assert pt.equal(plan.interp(w, data), ops.interp(w, idx, data.contiguous())), (k, dtype, row_len)
     plan.close()
+
+
+def test_leaf_shards_partition_every_target_once(ops):
+    """``s3_interp_plan_partition`` / ``parallel.LeafShards``: for 1, 2, 3, 8 ranks the shards are disjoint, cover every target,
+    follow the plan's (Hilbert) order, and the gather slots form a permutation of the ``world * chunk`` positions in use"""
+    from sparsespatialsampling_amd import parallel
+    rng = np.random.default_rng(77)
+    x = np.concatenate([rng.random((40000, 3)), 0.5 + 0.05 * rng.standard_normal((40000, 3))])
+    targets = np.concatenate([rng.random((3000, 3)), 0.5 + 0.04 * rng.standard_normal((9000, 3))])
+    knn = ops.KnnIndex(x)
+    idx, _ = knn.query(targets, 26)
+    plan = ops.InterpPlan(idx, len(x), targets)
+    for world in (1, 2, 3, 8):
+        order, cuts = plan.partition(world)
+        order = order.cpu().numpy()
+        assert cuts[0] == 0 and cuts[-1] == len(targets) and all(a <= b for a, b in zip(cuts, cuts[1:]))
+        assert np.array_equal(np.sort(order), np.arange(len(targets)))
+        shards = [parallel.LeafShards(knn, targets, 26, r, world) for r in range(world)]
+        assert [len(s.mine) for s in shards] == [cuts[r + 1] - cuts[r] for r in range(world)] == shards[0].counts
+        assert np.array_equal(np.sort(np.concatenate([s.mine for s in shards])), np.arange(len(targets)))
+        slot = shards[0].slot_of.cpu().numpy()
+        assert len(np.unique(slot)) == len(targets) and slot.max() < world * shards[0].chunk
+        for r, s in enumerate(shards):
+            assert np.array_equal(slot[s.mine], r * s.chunk + np.arange(len(s.mine)))
+    plan.close(), knn.close()

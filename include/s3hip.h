@@ -178,6 +178,10 @@ int s3_snapshot_major(const double *d_in, int64_t nc, int n_comp, int64_t n_snap
  * the data.  ddof = 1: torch's default (unbiased), 0: population.  Either output may be NULL. */
 int s3_row_moments(const void *d_data, int dtype, int64_t n_rows, int64_t row_len, int64_t in_stride, int ddof,
                    double *d_mean /*[n_rows] or NULL*/, double *d_std /*[n_rows] or NULL*/, s3_stream stream);
+/* the same of |x|: mean_t sum_c |U_c| of a vector field [N, n_comp, T] (examples/s3_for_cylinder2D_Re100.py:55) is n_comp times
+ * the mean over the cell's [n_comp * T] row */
+int s3_row_abs_moments(const void *d_data, int dtype, int64_t n_rows, int64_t row_len, int64_t in_stride, int ddof,
+                   double *d_mean /*[n_rows] or NULL*/, double *d_std /*[n_rows] or NULL*/, s3_stream stream);
 
 /* Planned form of a17 for a static neighbour table (the table ExportData caches at export.py:431-432 and reuses for
  * every snapshot batch and field): the plan de-duplicates the source rows of spatially adjacent cells once (built on the

@@ -41,6 +41,7 @@ HIP_SIGNATURES = {
     "s3_memcpy_d2h": (c_int, [c_vp, c_vp, C.c_size_t, c_vp]),
     "s3_download": (c_int, [c_vp, c_vp, C.c_size_t, c_vp]),
     "s3_row_moments": (c_int, [c_vp, c_int, c_i64, c_i64, c_i64, c_int, c_vp, c_vp, c_vp]),
+    "s3_row_abs_moments": (c_int, [c_vp, c_int, c_i64, c_i64, c_i64, c_int, c_vp, c_vp, c_vp]),
     "s3_upload_rows_indexed": (c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp]),
     "s3_upload_rows": (c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp]),
     "s3_stream_synchronize": (c_int, [c_vp]),

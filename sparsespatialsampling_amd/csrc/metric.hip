@@ -42,7 +42,9 @@ __device__ __forceinline__ double group_sum(double v) {
 // (each lane four 16-byte loads in flight): chunk sum -> chunk mean (one division, the count is known), squared
 // deviations from the values still in registers -> chunk M2; chunks are merged with Chan's update (group-uniform).
 // A row of up to 4*G vectors (T <= 1024 for fp32 at G = 64) is one chunk: the classic two-pass formula, one read.
-template <typename T, int VEC, int G>
+// ABS: moments of |x| (the time-mean of sum_c |U_c| of examples/s3_for_cylinder2D_Re100.py:55 is n_comp times the mean of |x|
+// over the [n_comp * T] row of a cell)
+template <typename T, int VEC, int G, bool ABS>
 __global__ void __launch_bounds__(256)
 row_moments_kernel(const T *__restrict__ data, int64_t n_rows, int64_t row_len, int64_t in_stride, int ddof,
                    double *__restrict__ mean_out, double *__restrict__ std_out) {
@@ -67,7 +69,7 @@ row_moments_kernel(const T *__restrict__ data, int64_t n_rows, int64_t row_len, 
             const V raw = *reinterpret_cast<const V *>(p + (ok[u] ? v : 0) * VEC);
             const T *e = reinterpret_cast<const T *>(&raw);
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) x[u][i] = (double)e[i];
+            for (int i = 0; i < VEC; ++i) x[u][i] = ABS ? fabs((double)e[i]) : (double)e[i];
         }
         const bool last_chunk = base + (int64_t)G * 4 >= n_vec;
         const bool with_tail = last_chunk && lane == 0 && n_tail > 0;
@@ -77,7 +79,7 @@ row_moments_kernel(const T *__restrict__ data, int64_t n_rows, int64_t row_len, 
 #pragma unroll
             for (int i = 0; i < VEC; ++i) s += ok[u] ? x[u][i] : 0.0;
         if (with_tail)
-            for (int64_t i = 0; i < n_tail; ++i) s += (double)p[tail0 + i];
+            for (int64_t i = 0; i < n_tail; ++i) s += ABS ? fabs((double)p[tail0 + i]) : (double)p[tail0 + i];
         const double n_chunk = (double)(max((int64_t)0, min((int64_t)G * 4, n_vec - base)) * VEC + (last_chunk ? n_tail : 0));
         const double m = group_sum<G>(s) / n_chunk;
         double q = 0.0;
@@ -86,7 +88,10 @@ row_moments_kernel(const T *__restrict__ data, int64_t n_rows, int64_t row_len, 
 #pragma unroll
             for (int i = 0; i < VEC; ++i) q += ok[u] ? (x[u][i] - m) * (x[u][i] - m) : 0.0;
         if (with_tail)
-            for (int64_t i = 0; i < n_tail; ++i) q += ((double)p[tail0 + i] - m) * ((double)p[tail0 + i] - m);
+            for (int64_t i = 0; i < n_tail; ++i) {
+                const double xv = ABS ? fabs((double)p[tail0 + i]) : (double)p[tail0 + i];
+                q += (xv - m) * (xv - m);
+            }
         acc = merge(acc, Moments{n_chunk, m, group_sum<G>(q)});
     }
     if (live && lane == 0) {
@@ -95,7 +100,7 @@ row_moments_kernel(const T *__restrict__ data, int64_t n_rows, int64_t row_len, 
     }
 }
 
-template <typename T, int VEC>
+template <typename T, int VEC, bool ABS>
 int launch_moments(const void *data, int64_t n_rows, int64_t row_len, int64_t in_stride, int ddof, double *mean, double *sd,
                    hipStream_t st) {
     const T *d = static_cast<const T *>(data);
@@ -105,7 +110,7 @@ int launch_moments(const void *data, int64_t n_rows, int64_t row_len, int64_t in
         const int64_t rows_per_block = 256 / G;                                                                         \
         const int64_t grid = (n_rows + rows_per_block - 1) / rows_per_block;                                            \
         S3_REQUIRE(grid < ((int64_t)1 << 31), "s3_row_moments: too many rows");                                         \
-        row_moments_kernel<T, VEC, G><<<(unsigned)grid, 256, 0, st>>>(d, n_rows, row_len, in_stride, ddof, mean, sd);   \
+        row_moments_kernel<T, VEC, G, ABS><<<(unsigned)grid, 256, 0, st>>>(d, n_rows, row_len, in_stride, ddof, mean, sd); \
     } while (0)
     // lanes per row: few lanes with many vectors each beat many lanes with few (fewer shuffle reductions and divisions
     // per byte).  MI355X, 4 991 774 fp32 rows: T = 1000 (250 vectors) 64 / 32 / 16 lanes: 3.73 / 3.38 / 3.21 ms;
@@ -127,10 +132,8 @@ int launch_moments(const void *data, int64_t n_rows, int64_t row_len, int64_t in
 
 using namespace s3;
 
-extern "C" {
-
-int s3_row_moments(const void *d_data, int dtype, int64_t n_rows, int64_t row_len, int64_t in_stride, int ddof,
-                   double *d_mean, double *d_std, s3_stream stream) {
+static int row_moments_impl(const void *d_data, int dtype, int64_t n_rows, int64_t row_len, int64_t in_stride, int ddof,
+                            double *d_mean, double *d_std, bool absolute, s3_stream stream) {
     S3_REQUIRE(n_rows >= 0 && row_len >= 1, "s3_row_moments: bad shape n_rows=%lld row_len=%lld", (long long)n_rows,
                (long long)row_len);
     S3_REQUIRE(dtype == S3_DTYPE_F32 || dtype == S3_DTYPE_F64, "s3_row_moments: unknown dtype %d", dtype);
@@ -141,13 +144,29 @@ int s3_row_moments(const void *d_data, int dtype, int64_t n_rows, int64_t row_le
     S3_REQUIRE(in_stride >= row_len, "s3_row_moments: in_stride %lld < row_len %lld", (long long)in_stride, (long long)row_len);
     hipStream_t st = as_stream(stream);
     const uintptr_t a = reinterpret_cast<uintptr_t>(d_data);
+#define S3_MOMENTS(T, VEC)                                                                                                        \
+    return absolute ? launch_moments<T, VEC, true>(d_data, n_rows, row_len, in_stride, ddof, d_mean, d_std, st)                   \
+                    : launch_moments<T, VEC, false>(d_data, n_rows, row_len, in_stride, ddof, d_mean, d_std, st)
     if (dtype == S3_DTYPE_F32) {
-        if (in_stride % 4 == 0 && a % 16 == 0) return launch_moments<float, 4>(d_data, n_rows, row_len, in_stride, ddof, d_mean, d_std, st);
-        if (in_stride % 2 == 0 && a % 8 == 0) return launch_moments<float, 2>(d_data, n_rows, row_len, in_stride, ddof, d_mean, d_std, st);
-        return launch_moments<float, 1>(d_data, n_rows, row_len, in_stride, ddof, d_mean, d_std, st);
+        if (in_stride % 4 == 0 && a % 16 == 0) S3_MOMENTS(float, 4);
+        if (in_stride % 2 == 0 && a % 8 == 0) S3_MOMENTS(float, 2);
+        S3_MOMENTS(float, 1);
     }
-    if (in_stride % 2 == 0 && a % 16 == 0) return launch_moments<double, 2>(d_data, n_rows, row_len, in_stride, ddof, d_mean, d_std, st);
-    return launch_moments<double, 1>(d_data, n_rows, row_len, in_stride, ddof, d_mean, d_std, st);
+    if (in_stride % 2 == 0 && a % 16 == 0) S3_MOMENTS(double, 2);
+    S3_MOMENTS(double, 1);
+#undef S3_MOMENTS
+}
+
+extern "C" {
+
+int s3_row_moments(const void *d_data, int dtype, int64_t n_rows, int64_t row_len, int64_t in_stride, int ddof,
+                   double *d_mean, double *d_std, s3_stream stream) {
+    return row_moments_impl(d_data, dtype, n_rows, row_len, in_stride, ddof, d_mean, d_std, false, stream);
+}
+
+int s3_row_abs_moments(const void *d_data, int dtype, int64_t n_rows, int64_t row_len, int64_t in_stride, int ddof,
+                       double *d_mean, double *d_std, s3_stream stream) {
+    return row_moments_impl(d_data, dtype, n_rows, row_len, in_stride, ddof, d_mean, d_std, true, stream);
 }
 
 }  // extern "C"

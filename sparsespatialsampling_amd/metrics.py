@@ -36,6 +36,28 @@ def temporal_moments(field: pt.Tensor, unbiased: bool = True):
     return mean, std
 
 
+def temporal_mean_abs_sum(field: pt.Tensor) -> pt.Tensor:
+    """``torch.mean(field.abs().sum(1), 1)`` of a field ``[N, n_comp, T]`` (the metric of the reference's cylinder2D script,
+    examples/s3_for_cylinder2D_Re100.py:55) in one pass on the GPU, accumulated in float64: the sum of |x| over a cell's
+    ``n_comp * T`` values divided by T"""
+    if field.dim() != 3:
+        raise ValueError(f"expected a field of shape [N, n_comp, T], got {tuple(field.shape)}")
+    if field.dtype not in hipops.DTYPE_CODE:
+        field = field.to(pt.float64)
+    on_host = not field.is_cuda
+    dev = hipops.to_device(field)
+    n, n_comp, t = (int(v) for v in dev.shape)
+    mean = pt.empty(n, dtype=pt.float64, device=dev.device)
+    hipops.check(_lib.hip_lib().s3_row_abs_moments(C.c_void_p(dev.data_ptr()), hipops.DTYPE_CODE[dev.dtype], n, n_comp * t,
+                                                   n_comp * t, 0, C.c_void_p(mean.data_ptr()), None, hipops._stream()),
+                 "s3_row_abs_moments")
+    mean *= float(n_comp)                                   # mean over n_comp * T values -> sum over components, mean over T
+    if on_host:
+        hipops.synchronize()
+        return mean.cpu()
+    return mean
+
+
 def temporal_std(field: pt.Tensor, unbiased: bool = True) -> pt.Tensor:
     """``torch.std(field, dim=-1)`` (unbiased by default, as torch) computed in float64 in one pass on the GPU"""
     return temporal_moments(field, unbiased)[1]

@@ -709,3 +709,19 @@ def test_leaf_shards_partition_every_target_once(ops):
         for r, s in enumerate(shards):
             assert np.array_equal(slot[s.mine], r * s.chunk + np.arange(len(s.mine)))
     plan.close(), knn.close()
+
+
+@pytest.mark.parametrize("shape,dtype", [((5000, 2, 400), pt.float32), ((3001, 3, 37), pt.float32), ((777, 1, 1000), pt.float64),
+                                         ((1200, 2, 5), pt.float64), ((64, 3, 1), pt.float32)])
+def test_temporal_mean_abs_sum(shape, dtype):
+    """the metric of the reference's cylinder2D script, ``pt.mean(field.abs().sum(1), 1)`` (examples/s3_for_cylinder2D_Re100.py:55),
+    in one pass on the GPU: equal to torch's float64 evaluation to rounding, for host and device tensors"""
+    from sparsespatialsampling_amd import metrics
+    gen = pt.Generator().manual_seed(shape[0])
+    field = (pt.randn(shape, generator=gen, dtype=pt.float64) * 3 + 0.5).to(dtype)
+    ref = field.double().abs().sum(1).mean(1)
+    got_host = metrics.temporal_mean_abs_sum(field)
+    got_dev = metrics.temporal_mean_abs_sum(field.cuda())
+    assert not got_host.is_cuda and got_dev.is_cuda and got_host.dtype == pt.float64
+    for got in (got_host, got_dev.cpu()):
+        assert got.shape == (shape[0],) and pt.allclose(got, ref, rtol=1e-12, atol=0)

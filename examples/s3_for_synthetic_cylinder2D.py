@@ -15,6 +15,7 @@ import torch as pt
 sys.path.insert(0, dirname(dirname(abspath(__file__))))
 from sparsespatialsampling_amd.export import ExportData                                 # noqa: E402
 from sparsespatialsampling_amd.geometry import CubeGeometry, SphereGeometry             # noqa: E402
+from sparsespatialsampling_amd.metrics import temporal_std                              # noqa: E402
 from sparsespatialsampling_amd.sparse_spatial_sampling import SparseSpatialSampling     # noqa: E402
 
 if __name__ == "__main__":
@@ -36,7 +37,8 @@ if __name__ == "__main__":
     domain = CubeGeometry("domain", True, bounds[0], bounds[1])
     geometry = SphereGeometry("cylinder", False, cylinder[0], cylinder[1], refine=True, min_refinement_level=9)
 
-    s_cube = SparseSpatialSampling(coord, pt.std(field, dim=1).double(), [domain, geometry], save_path, save_name,
+    # metric = pt.std(field, dim=1) of the reference's script (OAT15 example, line 91), one streaming pass on the GPU
+    s_cube = SparseSpatialSampling(coord, temporal_std(field), [domain, geometry], save_path, save_name,
                                    "cylinder2D", min_metric=min_metric)
     s_cube.execute_grid_generation()
     print(f"generated {s_cube.centers.shape[0]} cells from {coord.shape[0]} original cells")

@@ -33,6 +33,8 @@ struct s3_interp_plan : s3::PlanTables {
     int k = 0, ucap = 0, tc = 64;
     double *wp = nullptr;                // [nc*k] weights in the layout of `loc`: per tile [m][cell in tile]
     bool has_weights = false;
+    double *dump = nullptr;              // per-lane slots for the stores the persistent kernel must not make
+    size_t dump_doubles = 0;
 };
 
 namespace s3 {
@@ -248,7 +250,9 @@ interp_planned_short_reg_kernel(const int32_t *__restrict__ perm, const int32_t 
 // per CU.  Same arithmetic, same results.
 template <int J>
 __device__ __forceinline__ int quad_bcast_i32(int v) {
-    return __builtin_amdgcn_update_dpp(v, v, J | (J << 2) | (J << 4) | (J << 6), 0xf, 0xf, false);
+    // (old = 0 with bound_ctrl: every source lane of a quad_perm exists, so `old` is never used and the compiler need not
+    // copy the source into the destination first -- one v_mov_b32_dpp instead of two moves)
+    return __builtin_amdgcn_update_dpp(0, v, J | (J << 2) | (J << 4) | (J << 6), 0xf, 0xf, true);
 }
 template <int J>
 __device__ __forceinline__ double quad_bcast_f64(double x) {
@@ -435,6 +439,328 @@ interp_planned_kernel(const int32_t *__restrict__ perm, const int32_t *__restric
 #undef S3_STORE_A
 #undef S3_STORE_B
 #undef S3_DECL
+
+// 16 bytes of a source row.  ALIGNED: the row starts on a 16-byte boundary and is readable up to the next multiple of 16
+// bytes (pitched batches).  Otherwise (a batch read where it lies, [N, n_comp*T] dense: rows start on element boundaries
+// only) the vector is loaded with element alignment, and the ragged tail of a row -- `valid` < EPV elements -- as the
+// LAST EPV elements of the row (the load ends where the row ends; nothing beyond the row is touched), to be rotated into
+// place by rotate_tail.  One load instruction per piece on every path: the s_waitcnt counts of the caller stay exact.
+template <typename T> struct VecElemAligned;
+template <> struct VecElemAligned<float> { typedef float type __attribute__((ext_vector_type(4), aligned(4))); };
+template <> struct VecElemAligned<double> { typedef double type __attribute__((ext_vector_type(2), aligned(8))); };
+
+template <typename T, bool ALIGNED>
+__device__ __forceinline__ typename Vec16<T>::type load_piece(const T *__restrict__ p, int valid) {
+    using V = typename Vec16<T>::type;
+    constexpr int EPV = Vec16<T>::N;
+    if constexpr (ALIGNED) {
+        return *reinterpret_cast<const V *>(p);
+    } else {
+        const typename VecElemAligned<T>::type u = *reinterpret_cast<const typename VecElemAligned<T>::type *>(p - (EPV - valid));
+        V r;
+        T *re = reinterpret_cast<T *>(&r);
+#pragma unroll
+        for (int i = 0; i < EPV; ++i) re[i] = u[i];
+        return r;
+    }
+}
+// a piece loaded by load_piece<T, false> with `valid` < EPV holds its elements in the upper lanes: move them down
+template <typename T>
+__device__ __forceinline__ void rotate_tail(typename Vec16<T>::type &v, int valid) {
+    constexpr int EPV = Vec16<T>::N;
+    T *e = reinterpret_cast<T *>(&v);
+    const int sh = EPV - valid;
+#pragma unroll
+    for (int i = 0; i < EPV; ++i) {
+        T x = e[i];
+#pragma unroll
+        for (int s = 1; s < EPV; ++s)
+            if (i + s < EPV) x = sh == s ? e[i + s] : x;
+        e[i] = x;
+    }
+}
+
+// Short and medium batches (the reference exports cylinder3D in batches of 25 snapshots, examples/s3_for_cylinder3D_Re3900.py:
+// 28-69 -> utils.py:204: rows of 100 or 300 bytes): a tile has one to a few column chunks, so the start-up of a tile --
+// its row ids, its weights, the first row segments: three dependent round trips to HBM -- is most of its life, and the
+// chunk kernel above, two workgroups per CU each waiting for its own start-up, moves 3.1 TB/s.  Here the workgroups are
+// PERSISTENT (two per CU) and walk a flat sequence of (tile, chunk) steps with everything the next step needs already
+// on its way while the current one is accumulated:
+//   * row segments of step s+1: sixteen named registers per lane, issued right after the barrier of step s;
+//   * weights / positions of the next tile: in REGISTERS, shared by the four lanes of a cell (each lane loads every fourth
+//     entry of its cell, the DPP quad broadcasts them when the neighbour's turn comes) -- LDS holds row data only, so there
+//     is nothing to double-buffer there;
+//   * row ids of the tile after next: two coalesced loads per lane, handed to the staging lanes through 2 KiB of LDS when
+//     the issue pointer enters that tile.
+// s_waitcnt vmcnt counts loads AND stores in issue order, and the compiler takes the smallest count over all paths that
+// reach a use: a step must therefore issue the same number of vector-memory instructions on every path, or the wait for
+// the next step's first row segment silently becomes a wait for this step's output stores (that version ran no faster
+// than the chunk kernel).  Hence no branch around a load or a store: lanes without a cell accumulate a clamped copy,
+// elements beyond the end of a row and lanes without a cell store to a per-lane dump slot, EVEN (row length) is a
+// template parameter, LDS has room for 16 x 32 rows so that the staging stores need no bounds check.
+// The workgroups of an XCD take that XCD's run of the Hilbert-ordered tiles round robin: tiles in flight at the same
+// time are neighbours in space, so most of a tile's halo is served by the XCD's L2.  Same arithmetic (f64 FMA in neighbour
+// order), same results as every other variant.
+// neighbours M, M+1, ... of this lane's cell, two per step.  K is a compile-time constant so that the whole accumulate phase is
+// ONE basic block (with a run-time k every neighbour sits behind its own branch), and the LDS reads of the next pair are
+// issued before the current pair is accumulated -- left to itself the compiler reads a neighbour's two vectors into the same
+// registers every time and waits for them at once: 26 exposed LDS round trips per step.
+template <int M, int K, bool BOTH, typename T>
+__device__ __forceinline__ void stream_read_pair(const int (&pq)[(K + 3) / 4], const typename Vec16<T>::type *__restrict__ s_data,
+                                                 int v0, typename Vec16<T>::type (&buf)[4]) {
+    if constexpr (M < K) {
+        const int pos = quad_bcast_i32<M % 4>(pq[M / 4]);
+        buf[0] = s_data[pos * 8 + v0];
+        if constexpr (BOTH) buf[1] = s_data[pos * 8 + v0 + 4];
+    }
+    if constexpr (M + 1 < K) {
+        const int pos = quad_bcast_i32<(M + 1) % 4>(pq[(M + 1) / 4]);
+        buf[2] = s_data[pos * 8 + v0];
+        if constexpr (BOTH) buf[3] = s_data[pos * 8 + v0 + 4];
+    }
+}
+
+// acc0 += wm * a, acc1 += wm * b (element-wise, f64 FMA).  fp32 data: the conversions run four instructions ahead of the
+// FMAs that consume them (written as volatile asm, which the compiler keeps in this order: scheduled freely it converts
+// into one register pair and multiplies from it in the very next instruction -- a dependent f64 pair every other
+// instruction, 51 % of the wave's cycles stalled at issue).
+__device__ __forceinline__ double cvt_f64_asm(float x) {
+    double d;
+    asm volatile("v_cvt_f64_f32_e32 %0, %1" : "=v"(d) : "v"(x));
+    return d;
+}
+__device__ __forceinline__ void fmac_f64_asm(double &acc, double wm, double x) {
+    asm volatile("v_fmac_f64_e32 %0, %1, %2" : "+v"(acc) : "v"(wm), "v"(x));
+}
+template <bool BOTH>
+__device__ __forceinline__ void stream_fma_row(double wm, const float4 &a, const float4 &b, double (&acc0)[4], double (&acc1)[4]) {
+    if constexpr (BOTH) {
+        double t0 = cvt_f64_asm(a.x), t1 = cvt_f64_asm(b.x), t2 = cvt_f64_asm(a.y), t3 = cvt_f64_asm(b.y);
+        fmac_f64_asm(acc0[0], wm, t0); t0 = cvt_f64_asm(a.z);
+        fmac_f64_asm(acc1[0], wm, t1); t1 = cvt_f64_asm(b.z);
+        fmac_f64_asm(acc0[1], wm, t2); t2 = cvt_f64_asm(a.w);
+        fmac_f64_asm(acc1[1], wm, t3); t3 = cvt_f64_asm(b.w);
+        fmac_f64_asm(acc0[2], wm, t0);
+        fmac_f64_asm(acc1[2], wm, t1);
+        fmac_f64_asm(acc0[3], wm, t2);
+        fmac_f64_asm(acc1[3], wm, t3);
+    } else {
+        const double t0 = cvt_f64_asm(a.x), t1 = cvt_f64_asm(a.y), t2 = cvt_f64_asm(a.z), t3 = cvt_f64_asm(a.w);
+        fmac_f64_asm(acc0[0], wm, t0);
+        fmac_f64_asm(acc0[1], wm, t1);
+        fmac_f64_asm(acc0[2], wm, t2);
+        fmac_f64_asm(acc0[3], wm, t3);
+    }
+}
+template <bool BOTH>
+__device__ __forceinline__ void stream_fma_row(double wm, const double2 &a, const double2 &b, double (&acc0)[2], double (&acc1)[2]) {
+    acc0[0] = fma(wm, a.x, acc0[0]);
+    acc0[1] = fma(wm, a.y, acc0[1]);
+    if constexpr (BOTH) {
+        acc1[0] = fma(wm, b.x, acc1[0]);
+        acc1[1] = fma(wm, b.y, acc1[1]);
+    }
+}
+
+// BOTH = false: the upper four vectors of the chunk lie beyond the end of the row (the last chunk of a ragged row) -- nobody
+// reads or accumulates them
+template <int M, int K, bool BOTH, typename T>
+__device__ __forceinline__ void stream_accumulate(const double (&wq)[(K + 3) / 4], const int (&pq)[(K + 3) / 4],
+                                                  const typename Vec16<T>::type *__restrict__ s_data, int v0,
+                                                  typename Vec16<T>::type (&cur)[4], typename Vec16<T>::type (&nxt)[4],
+                                                  double (&acc0)[Vec16<T>::N], double (&acc1)[Vec16<T>::N]) {
+    if constexpr (M < K) {
+        stream_read_pair<M + 2, K, BOTH, T>(pq, s_data, v0, nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        stream_fma_row<BOTH>(quad_bcast_f64<M % 4>(wq[M / 4]), cur[0], cur[1], acc0, acc1);
+        if constexpr (M + 1 < K) stream_fma_row<BOTH>(quad_bcast_f64<(M + 1) % 4>(wq[(M + 1) / 4]), cur[2], cur[3], acc0, acc1);
+        __builtin_amdgcn_sched_barrier(0);
+        stream_accumulate<M + 2, K, BOTH, T>(wq, pq, s_data, v0, nxt, cur, acc0, acc1);
+    }
+}
+
+template <typename T, int K, bool ALIGNED, bool EVEN>
+__global__ void __launch_bounds__(256, 2)
+interp_planned_stream_kernel(const int32_t *__restrict__ perm, const int32_t *__restrict__ tile_cell_begin,
+                             const int32_t *__restrict__ tile_row_begin, const int32_t *__restrict__ rows,
+                             const uint16_t *__restrict__ loc, const double *__restrict__ w /*plan order*/,
+                             const T *__restrict__ data, int64_t row_len, int64_t in_stride, double *__restrict__ out,
+                             double *__restrict__ dump, int64_t n_tiles, int64_t tiles_per_xcd, int slots_per_xcd,
+                             int n_chunks) {
+    using V = typename Vec16<T>::type;
+    constexpr int EPV = Vec16<T>::N;
+    constexpr int EPC = PL_SEG / (int)sizeof(T);
+    constexpr int BLOCK = 256, RPP = BLOCK / 8;
+    constexpr int KQ = (K + 3) / 4, k = K;           // every lane of a quad holds KQ entries of its cell's tables
+    extern __shared__ float4 lds_raw[];
+    V *s_data = reinterpret_cast<V *>(lds_raw);                                           // [PL_NP * RPP][8] 16-byte vectors
+    int32_t *s_ids = reinterpret_cast<int32_t *>(lds_raw + (size_t)PL_NP * RPP * 8);      // [2 * BLOCK] row ids of the issue tile
+
+    const int tid = threadIdx.x;
+    const int64_t t_lo = (int64_t)(blockIdx.x & 7) * tiles_per_xcd, t_hi = min(n_tiles, t_lo + tiles_per_xcd);
+    const int64_t first = t_lo + (blockIdx.x >> 3);
+    if (first >= t_hi) return;
+    const int n_my = (int)((t_hi - first + slots_per_xcd - 1) / slots_per_xcd);   // tiles first, first + S, ...
+    const int srow = tid >> 3, svec = tid & 7;       // staging role: 8 lanes per 128-byte segment
+    const int qcl = tid >> 2, v0 = tid & 3;          // accumulate role: 4 lanes per cell, vectors v0 and v0 + 4
+    double *const dump_lane = dump + ((int64_t)blockIdx.x * BLOCK + tid) * 2;
+    const bool ragged = !ALIGNED && row_len % EPV != 0;
+    const uint32_t stride32 = (uint32_t)in_stride;   // (row pitch in elements < 2^31: one v_mad_u64_u32 per row address)
+
+#define S3S_DECL(P) int rid##P = 0; V pre##P;
+    S3_REP16(S3S_DECL)
+    static_assert(PL_NP == 16, "S3_REP16 expands PL_NP staging passes");
+    int ida = 0, idb = 0;                            // row ids of the tile after the issue tile (coalesced image)
+    double wq[KQ], wqn[KQ];
+    int pq[KQ], pqn[KQ];
+    int64_t cell = 0;
+    int celln = 0;                                   // (kept as loaded: a conversion here would wait for the load)
+    int nc_c = 0, nc_n = 0, nr_n = 0;                // cells of the compute tile; cells / rows of the issue tile
+
+    auto load_ids = [&](int64_t tile) {
+        const int rb = tile_row_begin[tile], nr = tile_row_begin[tile + 1] - rb;
+        ida = rows[rb + min(tid, nr - 1)];
+        idb = rows[rb + min(BLOCK + tid, nr - 1)];
+    };
+    auto load_tables = [&](int64_t tile) {
+        const int cb = tile_cell_begin[tile];
+        nc_n = tile_cell_begin[tile + 1] - cb;
+        const int cl = min(qcl, nc_n - 1);
+        const double *wt = w + (int64_t)cb * k + cl;
+        const uint16_t *lt = loc + (int64_t)cb * k + cl;
+#pragma unroll
+        for (int i = 0; i < KQ; ++i) {
+            const int m = i * 4 + v0, mm = m < k ? m : 0;
+            wqn[i] = wt[(int64_t)mm * nc_n];
+            pqn[i] = lt[(int64_t)mm * nc_n];
+        }
+        celln = perm[cb + cl];
+    };
+#define S3S_RID(P) rid##P = s_ids[min(P * RPP + srow, nr_n - 1)];
+#define S3S_LOAD(P) pre##P = load_piece<T, ALIGNED>(data + (uint64_t)(uint32_t)rid##P * stride32 + col_, valid_);
+#define S3S_ISSUE(CH)                                                                    \
+    do {                                                                                 \
+        const int64_t c0_ = (int64_t)(CH) * EPC;                                         \
+        const bool ok_ = c0_ + (int64_t)svec * EPV < row_len;                            \
+        const int64_t col_ = c0_ + (ok_ ? svec : 0) * EPV;                               \
+        const int valid_ = (int)min((int64_t)EPV, row_len - col_);                       \
+        S3_REP16(S3S_LOAD)                                                               \
+    } while (0)
+#define S3S_ROTATE(P) rotate_tail<T>(pre##P, valid_);
+#define S3S_STORE(P) s_data[(P * RPP + srow) * 8 + svec] = pre##P;
+
+    // prologue: the first tile's ids are the one exposed round trip of the workgroup
+    load_ids(first);
+    s_ids[tid] = ida;
+    s_ids[BLOCK + tid] = idb;
+    nr_n = tile_row_begin[first + 1] - tile_row_begin[first];
+    __syncthreads();
+    S3_REP16(S3S_RID)
+    __syncthreads();                                 // (the first step may already refill s_ids)
+    S3S_ISSUE(0);
+    load_tables(first);
+    if (n_my > 1) load_ids(first + slots_per_xcd);
+    // as many stores behind these loads as behind the loads of a step of the loop, or the count of the loop's first wait
+    // (the smallest over all ways into the loop) would be that of this prologue: every step would wait for its own stores
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *reinterpret_cast<volatile double *>(dump_lane) = 0.0;
+
+    for (int j = 0; j < n_my; ++j) {
+        // the tile whose steps are accumulated now: its tables arrived behind its first row segments
+#pragma unroll
+        for (int i = 0; i < KQ; ++i) {
+            wq[i] = wqn[i];
+            pq[i] = pqn[i];
+        }
+        cell = celln;
+        nc_c = nc_n;
+        const bool live = qcl < nc_c;                // lanes without a cell work on a clamped copy and store to the dump slot
+        for (int c = 0; c < n_chunks; ++c) {
+            const bool last_chunk = c + 1 == n_chunks;
+            const bool enter_next = last_chunk && j + 1 < n_my;      // the issue pointer moves on to this workgroup's next tile
+            if (ragged && last_chunk) {              // (uniform) the ragged tail of an element-aligned row: into place
+                const int64_t c0_ = (int64_t)c * EPC;
+                const bool ok_ = c0_ + (int64_t)svec * EPV < row_len;
+                const int valid_ = (int)min((int64_t)EPV, row_len - (c0_ + (ok_ ? svec : 0) * EPV));
+                S3_REP16(S3S_ROTATE)
+            }
+            S3_REP16(S3S_STORE)
+            if (enter_next) {
+                s_ids[tid] = ida;
+                s_ids[BLOCK + tid] = idb;
+            }
+            __syncthreads();
+            // ONE issue site for the row segments (two would look to the compiler as if the second could overwrite registers
+            // the first has loads pending for: it then waits for vmcnt(0), i.e. for the previous step's stores)
+            const int64_t tile_n = first + (int64_t)(j + 1) * slots_per_xcd;
+            if (enter_next) {
+                nr_n = tile_row_begin[tile_n + 1] - tile_row_begin[tile_n];
+                S3_REP16(S3S_RID)
+            }
+            if (enter_next || !last_chunk) S3S_ISSUE(enter_next ? 0 : c + 1);
+            if (enter_next) {
+                load_tables(tile_n);
+                if (j + 2 < n_my) load_ids(tile_n + slots_per_xcd);
+            }
+            const int64_t col0 = (int64_t)c * EPC;
+            double acc0[EPV], acc1[EPV];
+#pragma unroll
+            for (int i = 0; i < EPV; ++i) acc0[i] = acc1[i] = 0.0;
+            V buf_a[4], buf_b[4];
+            if (col0 + 4 * EPV < row_len) {          // (uniform) the chunk's upper four vectors exist
+                stream_read_pair<0, K, true, T>(pq, s_data, v0, buf_a);
+                stream_accumulate<0, K, true, T>(wq, pq, s_data, v0, buf_a, buf_b, acc0, acc1);
+            } else {
+                stream_read_pair<0, K, false, T>(pq, s_data, v0, buf_a);
+                stream_accumulate<0, K, false, T>(wq, pq, s_data, v0, buf_a, buf_b, acc0, acc1);
+            }
+            // the same number of stores on every path: what must not be written goes to this lane's dump slot.  Pairs of
+            // doubles; rows of odd length start on 8-byte boundaries only (element-aligned 16-byte stores) and end in a
+            // single element, which one lane of the cell stores separately.
+            double *const orow = out + cell * row_len;
+            const int64_t e0 = col0 + (int64_t)v0 * EPV, e1 = col0 + (int64_t)(v0 + 4) * EPV;
+            typedef double pair_t __attribute__((ext_vector_type(2), aligned(8)));
+#pragma unroll
+            for (int i = 0; i < EPV; i += 2) {
+                double *p0 = live && e0 + i + 1 < row_len ? orow + e0 + i : dump_lane;
+                pair_t v = {acc0[i], acc0[i + 1]};
+                *reinterpret_cast<pair_t *>(p0) = v;
+            }
+#pragma unroll
+            for (int i = 0; i < EPV; i += 2) {
+                double *p1 = live && e1 + i + 1 < row_len ? orow + e1 + i : dump_lane;
+                pair_t v = {acc1[i], acc1[i + 1]};
+                *reinterpret_cast<pair_t *>(p1) = v;
+            }
+            if constexpr (!EVEN) {
+                const int64_t t = row_len - 1;       // even: the last element of the row is the first of a pair
+                double tv = acc0[0];
+                bool mine = t == e0;
+#pragma unroll
+                for (int i = 2; i < EPV; i += 2) {
+                    tv = t == e0 + i ? acc0[i] : tv;
+                    mine = mine || t == e0 + i;
+                }
+#pragma unroll
+                for (int i = 0; i < EPV; i += 2) {
+                    tv = t == e1 + i ? acc1[i] : tv;
+                    mine = mine || t == e1 + i;
+                }
+                double *pt = live && mine ? orow + t : dump_lane;
+                *pt = tv;
+            }
+            __syncthreads();
+        }
+    }
+#undef S3S_DECL
+#undef S3S_RID
+#undef S3S_LOAD
+#undef S3S_ISSUE
+#undef S3S_ROTATE
+#undef S3S_STORE
+}
+
 #undef S3_REP16
 
 // distinct rows a tile of `tc` cells may hold: what is left of the LDS budget (80 KiB -> two 256-thread workgroups per CU
@@ -472,8 +798,73 @@ static int plan_ucap(int k, int tc) {
 
 using namespace s3;
 
+// the persistent kernel (interp_planned_stream_kernel) takes batches of up to this many 128-byte column chunks per row
+// (S3_STREAM_MAX_CHUNKS overrides; 0 switches it off) on plans with at least S3_STREAM_MIN_TILES tiles
+static int stream_max_chunks() {
+    const char *e = getenv("S3_STREAM_MAX_CHUNKS");
+    return e ? atoi(e) : 8;
+}
+static int64_t stream_min_tiles() {
+    const char *e = getenv("S3_STREAM_MIN_TILES");
+    return e ? atoll(e) : 64ll;
+}
+static int stream_workgroups() {
+    static const int v = [] {
+        const char *e = getenv("S3_STREAM_WORKGROUPS");
+        if (e) return atoi(e);
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        return 2 * cus;                                   // LDS: two workgroups per CU
+    }();
+    return v;
+}
+
+// (the neighbour counts of the reference's exports: 8 in 2-D, 26 in 3-D, export.py:84-85; any other k takes the chunk kernel)
+static bool stream_can_take(const s3_interp_plan *p) { return p->tc == 64 && p->ucap <= 512 && (p->k == 8 || p->k == 26); }
+
+template <typename T, bool ALIGNED, bool EVEN>
+static int launch_stream_e(s3_interp_plan *p, const int32_t *rows, const void *data, int64_t row_len, int64_t in_stride,
+                           double *out, hipStream_t st) {
+    constexpr int EPC = PL_SEG / (int)sizeof(T);
+    const int n_chunks = (int)((row_len + EPC - 1) / EPC);
+    const int64_t tiles_per_xcd = (p->n_tiles + 7) / 8;
+    int slots = stream_workgroups() / 8;
+    if (slots < 1) slots = 1;
+    if (slots > tiles_per_xcd) slots = (int)tiles_per_xcd;
+    const size_t lds = (size_t)PL_NP * 32 * PL_SEG + 2 * 256 * sizeof(int32_t);
+    const size_t dump_doubles = (size_t)slots * 8 * 256 * 2;           // one 16-byte slot per lane of the launch
+    if (p->dump_doubles < dump_doubles) {
+        if (p->dump) (void)hipFree(p->dump);
+        p->dump = nullptr;
+        p->dump_doubles = 0;
+        S3_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&p->dump), dump_doubles * sizeof(double)));
+        p->dump_doubles = dump_doubles;
+    }
+#define S3_LAUNCH_STREAM(K)                                                                                                   \
+    do {                                                                                                                      \
+        auto kern = interp_planned_stream_kernel<T, K, ALIGNED, EVEN>;                                                             \
+        S3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                         (int)lds));                                                                          \
+        kern<<<dim3((unsigned)(slots * 8)), 256, lds, st>>>(p->perm, p->tile_cell_begin, p->tile_row_begin, rows, p->loc,     \
+                                                            p->wp, static_cast<const T *>(data), row_len, in_stride,           \
+                                                            out, p->dump, p->n_tiles, tiles_per_xcd, slots, n_chunks);        \
+    } while (0)
+    if (p->k == 8) S3_LAUNCH_STREAM(8);
+    else S3_LAUNCH_STREAM(26);
+#undef S3_LAUNCH_STREAM
+    S3_LAUNCH_CHECK();
+    return S3_OK;
+}
+
+template <typename T, bool ALIGNED>
+static int launch_stream(s3_interp_plan *p, const int32_t *rows, const void *data, int64_t row_len, int64_t in_stride,
+                         double *out, hipStream_t st) {
+    if (row_len & 1) return launch_stream_e<T, ALIGNED, false>(p, rows, data, row_len, in_stride, out, st);
+    return launch_stream_e<T, ALIGNED, true>(p, rows, data, row_len, in_stride, out, st);
+}
+
 template <typename T>
-static int launch_planned(const s3_interp_plan *p, const void *data, int64_t row_len,
+static int launch_planned(s3_interp_plan *p, const void *data, int64_t row_len,
                           int64_t in_stride, double *out, hipStream_t st) {
     constexpr int EPC = PL_SEG / (int)sizeof(T);
     constexpr int EPV = 16 / (int)sizeof(T);
@@ -481,6 +872,9 @@ static int launch_planned(const s3_interp_plan *p, const void *data, int64_t row
     const int64_t tiles_per_xcd = (p->n_tiles + 7) / 8;
     const int64_t gx = tiles_per_xcd * 8;
     S3_REQUIRE(gx < ((int64_t)1 << 31), "s3_interp_planned: too many tiles");
+    if ((row_len + EPV - 1) / EPV > s3::short_row_vecs() && n_chunks <= stream_max_chunks() && stream_can_take(p) &&
+        p->n_tiles >= stream_min_tiles())
+        return launch_stream<T, true>(p, p->rows, data, row_len, in_stride, out, st);
     if ((row_len + EPV - 1) / EPV <= s3::short_row_vecs() && p->tc == 64) {
         const int vpr = (int)((row_len + EPV - 1) / EPV);
         if (vpr == 4 && p->ucap * vpr <= 256 * 8 && p->k <= 32 && !getenv("S3_SHORT_NO_QUAD") && !getenv("S3_SHORT_LDS_WEIGHTS")) {
@@ -567,6 +961,7 @@ void s3_interp_plan_destroy(s3_interp_plan *p) {
     if (p->rows) (void)hipFree(p->rows);
     if (p->loc) (void)hipFree(p->loc);
     if (p->wp) (void)hipFree(p->wp);
+    if (p->dump) (void)hipFree(p->dump);
     delete p;
 }
 

@@ -38,6 +38,10 @@ extern "C" {
 
 #define S3_MAX_K 64
 
+/* what s3_abi_version() of a library built from this header returns; the bindings refuse a library that reports another
+ * number (a stale build) with the command that rebuilds it */
+#define S3_ABI_VERSION 3
+
 typedef struct s3_knn s3_knn; /* opaque: grid-sorted copy of the original point cloud, resident in HBM */
 typedef void *s3_stream;
 
@@ -189,7 +193,9 @@ int s3_row_abs_moments(const void *d_data, int dtype, int64_t n_rows, int64_t ro
  * Same results as s3_interp.  Source rows must start on 16-byte boundaries and be readable up to the next multiple of
  * 16 bytes (in_stride % 4 == 0 for f32 / % 2 == 0 for f64, in_stride >= row_len rounded up to that multiple); the row
  * length itself is arbitrary (25-snapshot batches of examples/s3_for_cylinder3D_Re3900.py:28-69: pitch 28 or 32).
- * Rows of up to 64 bytes take a short-row kernel (several workgroups per CU, no chunk pipeline). */
+ * Rows of up to 64 bytes take a short-row kernel (several workgroups per CU, no chunk pipeline); rows of up to 1 KiB on
+ * plans with the reference's neighbour counts (k = 8 | 26, export.py:84-85) the persistent kernel (two workgroups per CU
+ * walking all tiles, the next tile's rows / weights / ids in flight while the current one is accumulated). */
 typedef struct s3_interp_plan s3_interp_plan;
 int s3_interp_plan_create(const int32_t *d_idx /*[nc,k]*/, int64_t nc, int k, int64_t n_src,
                           const double *d_centers /*[nc,dim] or NULL*/, int dim, int tile_cells /*0 (=64), 64 or 128*/,
@@ -210,6 +216,18 @@ int s3_interp_plan_partition(const s3_interp_plan *plan, int world, int32_t *d_o
 int s3_interp_plan_set_weights(s3_interp_plan *plan, const double *d_w /*[nc,k]*/, s3_stream stream);
 int s3_interp_planned(s3_interp_plan *plan, const double *d_w /*[nc,k] or NULL*/, const void *d_data, int dtype,
                       int64_t row_len, int64_t in_stride, double *d_out /*[nc,row_len]*/, s3_stream stream);
+/* A batch that already lives in HBM as the reference hands it over -- data[N, n_comp * T], every row of the CFD mesh,
+ * export.py:446-468 -- is read WHERE IT LIES: no pass that first gathers the referenced rows into a pitched copy.
+ *   s3_interp_plan_set_source_ids  d_ids[n_src]: the row of the full table behind each source row the plan was built on
+ *                                  (the `used` list of s3_compact_rows); once per KNN cache
+ *   s3_interp_planned_src          d_table[n_table_rows][in_stride]: the full batch; same results as s3_interp_planned on
+ *                                  the gathered copy
+ * Rows that are not 16-byte aligned (25 fp32 snapshots: 100-byte rows) are read with element alignment by the persistent
+ * kernel (plans with k = 8 | 26, rows of at least 16 bytes); nothing beyond the end of a row is touched.  The same
+ * relaxed alignment holds for s3_interp_planned on such plans. */
+int s3_interp_plan_set_source_ids(s3_interp_plan *plan, const int32_t *d_ids /*[n_src]*/, int64_t n_table_rows, s3_stream stream);
+int s3_interp_planned_src(s3_interp_plan *plan, const void *d_table, int dtype, int64_t n_table_rows, int64_t row_len,
+                          int64_t in_stride, double *d_out /*[nc,row_len]*/, s3_stream stream);
 
 
 /* ---- device-side bookkeeping of the KNN cache (replaces torch.unique / fancy indexing on the a16 path) ----------

@@ -26,6 +26,8 @@ class S3HipError(RuntimeError):
 
 _hip = None
 _topo = None
+ABI_VERSION = 3          # S3_ABI_VERSION of include/s3hip.h this file was written against
+_REBUILD = "python -c 'import __graft_entry__ as g; g.build()'"
 
 c_i64, c_i32, c_int, c_dbl, c_vp = C.c_int64, C.c_int32, C.c_int, C.c_double, C.c_void_p
 
@@ -75,6 +77,8 @@ HIP_SIGNATURES = {
     "s3_interp_plan_partition": (c_int, [c_vp, c_int, c_vp, C.POINTER(c_i64), c_vp]),
     "s3_interp_plan_set_weights": (c_int, [c_vp, c_vp, c_vp]),
     "s3_interp_planned": (c_int, [c_vp, c_vp, c_vp, c_int, c_i64, c_i64, c_vp, c_vp]),
+    "s3_interp_plan_set_source_ids": (c_int, [c_vp, c_vp, c_i64, c_vp]),
+    "s3_interp_planned_src": (c_int, [c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_vp, c_vp]),
     "s3_comm_unique_id": (c_int, [c_vp, C.c_size_t]),
     "s3_comm_init": (c_int, [c_vp, C.c_size_t, c_int, c_int, C.POINTER(c_vp)]),
     "s3_comm_destroy": (None, [c_vp]),
@@ -144,9 +148,12 @@ TOPO_SIGNATURES = {
 }
 
 
-def _bind(lib, signatures):
+def _bind(lib, signatures, path):
     for name, (res, args) in signatures.items():
-        fn = getattr(lib, name)
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:                 # a library older than these bindings
+            raise HipUnavailableError(f"{path} does not export {name}: stale build -- rebuild it with `{_REBUILD}`.") from e
         fn.restype = res
         fn.argtypes = args
     return lib
@@ -164,9 +171,13 @@ def hip_lib():
             raise HipUnavailableError(f"{HIP_SO} not found -- build it with `python -c 'import __graft_entry__ as g; "
                                       f"g.build()'`.  This package has no CPU fallback.")
         try:
-            _hip = _bind(C.CDLL(HIP_SO), HIP_SIGNATURES)
+            lib = _bind(C.CDLL(HIP_SO), HIP_SIGNATURES, HIP_SO)
         except OSError as e:
             raise HipUnavailableError(f"cannot load {HIP_SO}: {e}") from e
+        if lib.s3_abi_version() != ABI_VERSION:
+            raise HipUnavailableError(f"{HIP_SO} reports ABI version {lib.s3_abi_version()}, these bindings need "
+                                      f"{ABI_VERSION}: stale build -- rebuild it with `{_REBUILD}`.")
+        _hip = lib
     return _hip
 
 
@@ -175,7 +186,7 @@ def topo_lib():
     if _topo is None:
         if not os.path.exists(TOPO_SO):
             raise HipUnavailableError(f"{TOPO_SO} not found -- build it with `__graft_entry__.build()`.")
-        _topo = _bind(C.CDLL(TOPO_SO), TOPO_SIGNATURES)
+        _topo = _bind(C.CDLL(TOPO_SO), TOPO_SIGNATURES, TOPO_SO)
     return _topo
 
 

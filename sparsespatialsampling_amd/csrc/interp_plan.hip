@@ -24,6 +24,7 @@
 #include "common.h"
 #include "plan_build.h"
 
+#include <algorithm>
 #include <cstdlib>
 #include <exception>
 #include <vector>
@@ -35,6 +36,11 @@ struct s3_interp_plan : s3::PlanTables {
     bool has_weights = false;
     double *dump = nullptr;              // per-lane slots for the stores the persistent kernel must not make
     size_t dump_doubles = 0;
+    int32_t *rows_src = nullptr;         // [total_rows] `rows` as row ids of the caller's full table (s3_interp_plan_set_source_ids)
+    int64_t n_table = 0;                 // rows of that table
+    int32_t *sched_begin = nullptr;      // [sched_wgs + 1] tile lists of the persistent workgroups (plan_schedule)
+    int32_t *sched_tiles = nullptr;      // [n_tiles]
+    int sched_wgs = 0;
 };
 
 namespace s3 {
@@ -498,9 +504,9 @@ __device__ __forceinline__ void rotate_tail(typename Vec16<T>::type &v, int vali
 // than the chunk kernel).  Hence no branch around a load or a store: lanes without a cell accumulate a clamped copy,
 // elements beyond the end of a row and lanes without a cell store to a per-lane dump slot, EVEN (row length) is a
 // template parameter, LDS has room for 16 x 32 rows so that the staging stores need no bounds check.
-// The workgroups of an XCD take that XCD's run of the Hilbert-ordered tiles round robin: tiles in flight at the same
-// time are neighbours in space, so most of a tile's halo is served by the XCD's L2.  Same arithmetic (f64 FMA in neighbour
-// order), same results as every other variant.
+// The workgroups of an XCD take that XCD's run of the Hilbert-ordered tiles round robin (plan_schedule: explicit tile lists,
+// fixed at plan creation): tiles in flight at the same time are neighbours in space, so most of a tile's halo is served by
+// the XCD's L2.  Same arithmetic (f64 FMA in neighbour order), same results as every other variant.
 // neighbours M, M+1, ... of this lane's cell, two per step.  K is a compile-time constant so that the whole accumulate phase is
 // ONE basic block (with a run-time k every neighbour sits behind its own branch), and the LDS reads of the next pair are
 // issued before the current pair is accumulated -- left to itself the compiler reads a neighbour's two vectors into the same
@@ -585,8 +591,8 @@ interp_planned_stream_kernel(const int32_t *__restrict__ perm, const int32_t *__
                              const int32_t *__restrict__ tile_row_begin, const int32_t *__restrict__ rows,
                              const uint16_t *__restrict__ loc, const double *__restrict__ w /*plan order*/,
                              const T *__restrict__ data, int64_t row_len, int64_t in_stride, double *__restrict__ out,
-                             double *__restrict__ dump, int64_t n_tiles, int64_t tiles_per_xcd, int slots_per_xcd,
-                             int n_chunks) {
+                             double *__restrict__ dump, const int32_t *__restrict__ sched_begin,
+                             const int32_t *__restrict__ sched_tiles, int n_chunks) {
     using V = typename Vec16<T>::type;
     constexpr int EPV = Vec16<T>::N;
     constexpr int EPC = PL_SEG / (int)sizeof(T);
@@ -597,10 +603,11 @@ interp_planned_stream_kernel(const int32_t *__restrict__ perm, const int32_t *__
     int32_t *s_ids = reinterpret_cast<int32_t *>(lds_raw + (size_t)PL_NP * RPP * 8);      // [2 * BLOCK] row ids of the issue tile
 
     const int tid = threadIdx.x;
-    const int64_t t_lo = (int64_t)(blockIdx.x & 7) * tiles_per_xcd, t_hi = min(n_tiles, t_lo + tiles_per_xcd);
-    const int64_t first = t_lo + (blockIdx.x >> 3);
-    if (first >= t_hi) return;
-    const int n_my = (int)((t_hi - first + slots_per_xcd - 1) / slots_per_xcd);   // tiles first, first + S, ...
+    // this workgroup's tiles: sched_tiles[my_begin .. my_begin + n_my) (plan_schedule below)
+    const int my_begin = sched_begin[blockIdx.x], n_my = sched_begin[blockIdx.x + 1] - my_begin;
+    if (n_my <= 0) return;
+    const int32_t *const my_tiles = sched_tiles + my_begin;
+    const int64_t first = my_tiles[0];
     const int srow = tid >> 3, svec = tid & 7;       // staging role: 8 lanes per 128-byte segment
     const int qcl = tid >> 2, v0 = tid & 3;          // accumulate role: 4 lanes per cell, vectors v0 and v0 + 4
     double *const dump_lane = dump + ((int64_t)blockIdx.x * BLOCK + tid) * 2;
@@ -659,7 +666,8 @@ interp_planned_stream_kernel(const int32_t *__restrict__ perm, const int32_t *__
     __syncthreads();                                 // (the first step may already refill s_ids)
     S3S_ISSUE(0);
     load_tables(first);
-    if (n_my > 1) load_ids(first + slots_per_xcd);
+    if (n_my > 1) load_ids(my_tiles[1]);
+    int t_n1 = n_my > 1 ? my_tiles[1] : 0, t_n2 = n_my > 2 ? my_tiles[2] : 0;       // the next two tiles of the list
     // as many stores behind these loads as behind the loads of a step of the loop, or the count of the loop's first wait
     // (the smallest over all ways into the loop) would be that of this prologue: every step would wait for its own stores
     __builtin_amdgcn_sched_barrier(0);
@@ -693,7 +701,7 @@ interp_planned_stream_kernel(const int32_t *__restrict__ perm, const int32_t *__
             __syncthreads();
             // ONE issue site for the row segments (two would look to the compiler as if the second could overwrite registers
             // the first has loads pending for: it then waits for vmcnt(0), i.e. for the previous step's stores)
-            const int64_t tile_n = first + (int64_t)(j + 1) * slots_per_xcd;
+            const int64_t tile_n = t_n1;
             if (enter_next) {
                 nr_n = tile_row_begin[tile_n + 1] - tile_row_begin[tile_n];
                 S3_REP16(S3S_RID)
@@ -701,7 +709,9 @@ interp_planned_stream_kernel(const int32_t *__restrict__ perm, const int32_t *__
             if (enter_next || !last_chunk) S3S_ISSUE(enter_next ? 0 : c + 1);
             if (enter_next) {
                 load_tables(tile_n);
-                if (j + 2 < n_my) load_ids(tile_n + slots_per_xcd);
+                if (j + 2 < n_my) load_ids(t_n2);
+                t_n1 = t_n2;
+                t_n2 = j + 3 < n_my ? my_tiles[j + 3] : 0;
             }
             const int64_t col0 = (int64_t)c * EPC;
             double acc0[EPV], acc1[EPV];
@@ -822,17 +832,69 @@ static int stream_workgroups() {
 // (the neighbour counts of the reference's exports: 8 in 2-D, 26 in 3-D, export.py:84-85; any other k takes the chunk kernel)
 static bool stream_can_take(const s3_interp_plan *p) { return p->tc == 64 && p->ucap <= 512 && (p->k == 8 || p->k == 26); }
 
+// Tile lists of the persistent workgroups.  Workgroup b runs on XCD b % 8 (round-robin dispatch); XCD x owns the x-th eighth
+// of the Hilbert-ordered tiles and hands them out IN ORDER to its workgroups; the lists are fixed here, so the kernel needs
+// no atomics and can issue the loads of the next tiles' ids two tiles ahead.
+static int plan_schedule(s3_interp_plan *p, hipStream_t st) {
+    const size_t nt = (size_t)p->n_tiles;
+    std::vector<int32_t> cb(nt + 1), rb(nt + 1);
+    S3_HIP_CHECK(hipMemcpyAsync(cb.data(), p->tile_cell_begin, sizeof(int32_t) * (nt + 1), hipMemcpyDeviceToHost, st));
+    S3_HIP_CHECK(hipMemcpyAsync(rb.data(), p->tile_row_begin, sizeof(int32_t) * (nt + 1), hipMemcpyDeviceToHost, st));
+    S3_HIP_CHECK(hipStreamSynchronize(st));
+    int wgs = stream_workgroups() / 8 * 8;
+    if (wgs < 8) wgs = 8;
+    const int slots = wgs / 8;
+    const size_t per_xcd = (nt + 7) / 8;
+    std::vector<std::vector<int32_t>> lists((size_t)wgs);
+    std::vector<double> busy((size_t)slots);
+    // Default: plain round robin -- the workgroups of an XCD then work on adjacent tiles at the same time and find most of a
+    // tile's halo in the XCD's L2.  S3_STREAM_SCHEDULE=cost: each tile to the workgroup expected to be free first (list
+    // scheduling with a byte-count cost model).  Measured on MI355X, cylinder3D grid, interleaved in one process
+    // (tools/ab_plan.py): round robin 0.158 / 0.151 / 0.454 ms at 25 / 32 / 128 snapshots, cost model 0.162 / 0.153 / 0.476 --
+    // the balance it buys is worth less than the locality it loses.
+    const char *mode = getenv("S3_STREAM_SCHEDULE");
+    const bool round_robin = !(mode && mode[0] == 'c');
+    for (int x = 0; x < 8; ++x) {
+        const size_t lo = std::min(nt, x * per_xcd), hi = std::min(nt, lo + per_xcd);
+        std::fill(busy.begin(), busy.end(), 0.0);
+        for (size_t t = lo; t < hi; ++t) {
+            int best = 0;
+            if (round_robin) {
+                best = (int)((t - lo) % (size_t)slots);
+            } else {
+                for (int s = 1; s < slots; ++s)
+                    if (busy[s] < busy[best]) best = s;                 // (first of equals: the first `slots` tiles go out in order)
+            }
+            busy[best] += 128.0 * (rb[t + 1] - rb[t]) + (10.0 * p->k + 256.0) * (cb[t + 1] - cb[t]) + 4096.0;
+            lists[(size_t)best * 8 + x].push_back((int32_t)t);
+        }
+    }
+    std::vector<int32_t> begin((size_t)wgs + 1, 0), tiles;
+    tiles.reserve(nt);
+    for (int b = 0; b < wgs; ++b) {
+        tiles.insert(tiles.end(), lists[b].begin(), lists[b].end());
+        begin[b + 1] = (int32_t)tiles.size();
+    }
+    S3_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&p->sched_tiles), sizeof(int32_t) * std::max<size_t>(nt, 1)));
+    S3_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&p->sched_begin), sizeof(int32_t) * ((size_t)wgs + 1)));
+    S3_HIP_CHECK(hipMemcpyAsync(p->sched_tiles, tiles.data(), sizeof(int32_t) * nt, hipMemcpyHostToDevice, st));
+    S3_HIP_CHECK(hipMemcpyAsync(p->sched_begin, begin.data(), sizeof(int32_t) * ((size_t)wgs + 1), hipMemcpyHostToDevice, st));
+    S3_HIP_CHECK(hipStreamSynchronize(st));
+    p->sched_wgs = wgs;
+    return S3_OK;
+}
+
 template <typename T, bool ALIGNED, bool EVEN>
 static int launch_stream_e(s3_interp_plan *p, const int32_t *rows, const void *data, int64_t row_len, int64_t in_stride,
                            double *out, hipStream_t st) {
     constexpr int EPC = PL_SEG / (int)sizeof(T);
     const int n_chunks = (int)((row_len + EPC - 1) / EPC);
-    const int64_t tiles_per_xcd = (p->n_tiles + 7) / 8;
-    int slots = stream_workgroups() / 8;
-    if (slots < 1) slots = 1;
-    if (slots > tiles_per_xcd) slots = (int)tiles_per_xcd;
+    if (!p->sched_begin) {
+        const int rc = plan_schedule(p, st);
+        if (rc != S3_OK) return rc;
+    }
     const size_t lds = (size_t)PL_NP * 32 * PL_SEG + 2 * 256 * sizeof(int32_t);
-    const size_t dump_doubles = (size_t)slots * 8 * 256 * 2;           // one 16-byte slot per lane of the launch
+    const size_t dump_doubles = (size_t)p->sched_wgs * 256 * 2;        // one 16-byte slot per lane of the launch
     if (p->dump_doubles < dump_doubles) {
         if (p->dump) (void)hipFree(p->dump);
         p->dump = nullptr;
@@ -845,9 +907,9 @@ static int launch_stream_e(s3_interp_plan *p, const int32_t *rows, const void *d
         auto kern = interp_planned_stream_kernel<T, K, ALIGNED, EVEN>;                                                             \
         S3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,   \
                                          (int)lds));                                                                          \
-        kern<<<dim3((unsigned)(slots * 8)), 256, lds, st>>>(p->perm, p->tile_cell_begin, p->tile_row_begin, rows, p->loc,     \
+        kern<<<dim3((unsigned)p->sched_wgs), 256, lds, st>>>(p->perm, p->tile_cell_begin, p->tile_row_begin, rows, p->loc,    \
                                                             p->wp, static_cast<const T *>(data), row_len, in_stride,           \
-                                                            out, p->dump, p->n_tiles, tiles_per_xcd, slots, n_chunks);        \
+                                                            out, p->dump, p->sched_begin, p->sched_tiles, n_chunks);          \
     } while (0)
     if (p->k == 8) S3_LAUNCH_STREAM(8);
     else S3_LAUNCH_STREAM(26);
@@ -864,8 +926,12 @@ static int launch_stream(s3_interp_plan *p, const int32_t *rows, const void *dat
 }
 
 template <typename T>
-static int launch_planned(s3_interp_plan *p, const void *data, int64_t row_len,
+static int launch_planned(s3_interp_plan *p, const int32_t *rows, bool aligned, const void *data, int64_t row_len,
                           int64_t in_stride, double *out, hipStream_t st) {
+    if (!aligned) {                              // element-aligned rows read where they lie: the persistent kernel only
+        S3_REQUIRE(stream_can_take(p), "s3_interp_planned: rows that are not 16-byte aligned need k = 8 | 26 and 64-cell tiles");
+        return launch_stream<T, false>(p, rows, data, row_len, in_stride, out, st);
+    }
     constexpr int EPC = PL_SEG / (int)sizeof(T);
     constexpr int EPV = 16 / (int)sizeof(T);
     const int n_chunks = (int)((row_len + EPC - 1) / EPC);
@@ -874,7 +940,7 @@ static int launch_planned(s3_interp_plan *p, const void *data, int64_t row_len,
     S3_REQUIRE(gx < ((int64_t)1 << 31), "s3_interp_planned: too many tiles");
     if ((row_len + EPV - 1) / EPV > s3::short_row_vecs() && n_chunks <= stream_max_chunks() && stream_can_take(p) &&
         p->n_tiles >= stream_min_tiles())
-        return launch_stream<T, true>(p, p->rows, data, row_len, in_stride, out, st);
+        return launch_stream<T, true>(p, rows, data, row_len, in_stride, out, st);
     if ((row_len + EPV - 1) / EPV <= s3::short_row_vecs() && p->tc == 64) {
         const int vpr = (int)((row_len + EPV - 1) / EPV);
         if (vpr == 4 && p->ucap * vpr <= 256 * 8 && p->k <= 32 && !getenv("S3_SHORT_NO_QUAD") && !getenv("S3_SHORT_LDS_WEIGHTS")) {
@@ -883,7 +949,7 @@ static int launch_planned(s3_interp_plan *p, const void *data, int64_t row_len,
 #define S3_LAUNCH_SHORT_QUAD(KQ)                                                                                                 \
     do {                                                                                                                         \
         auto kern = interp_planned_short_quad_kernel<T, KQ>;                                                                     \
-        kern<<<dim3((unsigned)gx), 256, lds, st>>>(p->perm, p->tile_cell_begin, p->tile_row_begin, p->rows, p->loc, p->wp, p->k, \
+        kern<<<dim3((unsigned)gx), 256, lds, st>>>(p->perm, p->tile_cell_begin, p->tile_row_begin, rows, p->loc, p->wp, p->k, \
                                                    static_cast<const T *>(data), row_len, in_stride, out, p->n_tiles,            \
                                                    tiles_per_xcd);                                                               \
     } while (0)
@@ -900,7 +966,7 @@ static int launch_planned(s3_interp_plan *p, const void *data, int64_t row_len,
 #define S3_LAUNCH_SHORT_REG(KM)                                                                                                  \
     do {                                                                                                                         \
         auto kern = interp_planned_short_reg_kernel<T, KM>;                                                                      \
-        kern<<<dim3((unsigned)gx), 256, lds, st>>>(p->perm, p->tile_cell_begin, p->tile_row_begin, p->rows, p->loc, p->wp, p->k, \
+        kern<<<dim3((unsigned)gx), 256, lds, st>>>(p->perm, p->tile_cell_begin, p->tile_row_begin, rows, p->loc, p->wp, p->k, \
                                                    static_cast<const T *>(data), row_len, in_stride, out, p->n_tiles,            \
                                                    tiles_per_xcd, vpr);                                                          \
     } while (0)
@@ -916,7 +982,7 @@ static int launch_planned(s3_interp_plan *p, const void *data, int64_t row_len,
                            (size_t)p->tc * sizeof(int32_t);
         auto kern = interp_planned_short_kernel<T, 64>;
         S3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        kern<<<dim3((unsigned)gx), 256, lds, st>>>(p->perm, p->tile_cell_begin, p->tile_row_begin, p->rows, p->loc, p->wp, p->k,
+        kern<<<dim3((unsigned)gx), 256, lds, st>>>(p->perm, p->tile_cell_begin, p->tile_row_begin, rows, p->loc, p->wp, p->k,
                                                    p->ucap, static_cast<const T *>(data), row_len, in_stride, out, p->n_tiles,
                                                    tiles_per_xcd, vpr, pitch);
         S3_LAUNCH_CHECK();
@@ -937,13 +1003,13 @@ static int launch_planned(s3_interp_plan *p, const void *data, int64_t row_len,
     if (p->tc == 128) {
         auto kern = interp_planned_kernel<T, 128>;
         S3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        kern<<<grid, 512, lds, st>>>(p->perm, p->tile_cell_begin, p->tile_row_begin, p->rows, p->loc, p->wp, p->k, p->ucap,
+        kern<<<grid, 512, lds, st>>>(p->perm, p->tile_cell_begin, p->tile_row_begin, rows, p->loc, p->wp, p->k, p->ucap,
                                      static_cast<const T *>(data), row_len, in_stride, out, p->n_tiles, tiles_per_xcd,
                                      chunks_per_block, n_chunks);
     } else {
         auto kern = interp_planned_kernel<T, 64>;
         S3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        kern<<<grid, 256, lds, st>>>(p->perm, p->tile_cell_begin, p->tile_row_begin, p->rows, p->loc, p->wp, p->k, p->ucap,
+        kern<<<grid, 256, lds, st>>>(p->perm, p->tile_cell_begin, p->tile_row_begin, rows, p->loc, p->wp, p->k, p->ucap,
                                      static_cast<const T *>(data), row_len, in_stride, out, p->n_tiles, tiles_per_xcd,
                                      chunks_per_block, n_chunks);
     }
@@ -962,6 +1028,9 @@ void s3_interp_plan_destroy(s3_interp_plan *p) {
     if (p->loc) (void)hipFree(p->loc);
     if (p->wp) (void)hipFree(p->wp);
     if (p->dump) (void)hipFree(p->dump);
+    if (p->rows_src) (void)hipFree(p->rows_src);
+    if (p->sched_begin) (void)hipFree(p->sched_begin);
+    if (p->sched_tiles) (void)hipFree(p->sched_tiles);
     delete p;
 }
 
@@ -986,6 +1055,13 @@ int s3_interp_plan_create(const int32_t *d_idx, int64_t nc, int k, int64_t n_src
     if (rc != S3_OK) {
         s3_interp_plan_destroy(p);
         return rc;
+    }
+    if (stream_can_take(p)) {                // tile lists of the persistent kernel
+        const int rs = plan_schedule(p, st);
+        if (rs != S3_OK) {
+            s3_interp_plan_destroy(p);
+            return rs;
+        }
     }
     *out = p;
     return S3_OK;
@@ -1057,6 +1133,35 @@ int s3_interp_plan_set_weights(s3_interp_plan *p, const double *d_w, s3_stream s
     return S3_OK;
 }
 
+// common part of the two launches: `rows` = the plan's row list in the numbering of d_data's rows
+static int planned_dispatch(s3_interp_plan *p, const int32_t *rows, const char *who, const void *d_data, int dtype,
+                            int64_t row_len, int64_t in_stride, double *d_out, s3_stream stream) {
+    S3_REQUIRE(p->has_weights, "%s: no weights (pass d_w or call s3_interp_plan_set_weights first)", who);
+    S3_REQUIRE(dtype == S3_DTYPE_F32 || dtype == S3_DTYPE_F64, "%s: unknown dtype %d", who, dtype);
+    S3_REQUIRE(row_len >= 0, "%s: bad row_len", who);
+    if (row_len == 0) return S3_OK;
+    S3_REQUIRE(d_data && d_out, "%s: null array", who);
+    const int epv = dtype == S3_DTYPE_F32 ? 4 : 2;
+    const uintptr_t a_in = reinterpret_cast<uintptr_t>(d_data), a_out = reinterpret_cast<uintptr_t>(d_out);
+    if (in_stride <= 0) in_stride = row_len;
+    S3_REQUIRE(in_stride >= row_len && in_stride < ((int64_t)1 << 31), "%s: in_stride %lld < row_len %lld (or >= 2^31)", who,
+               (long long)in_stride, (long long)row_len);
+    // pitched rows: every source row starts on a 16-byte boundary and is readable up to the next multiple of 16 bytes (the
+    // ragged tail of a row is loaded as a whole vector, the surplus lanes are never stored).  Anything else -- a dense
+    // [N, n_comp * T] batch read where it lies -- is read with element alignment by the persistent kernel, which touches
+    // nothing beyond the end of a row; it wants rows of at least one 16-byte vector.
+    const bool aligned = in_stride % epv == 0 && in_stride >= (row_len + epv - 1) / epv * epv && a_in % 16 == 0;
+    if (!aligned)
+        S3_REQUIRE(a_in % (16 / epv) == 0 && row_len >= epv && stream_can_take(p),
+                   "%s: source rows must be 16-byte aligned with a pitch >= the row length rounded up to %d elements, or "
+                   "element-aligned rows of >= %d elements on a plan with k = 8 | 26 (row_len %lld, in_stride %lld)", who, epv, epv,
+                   (long long)row_len, (long long)in_stride);
+    // output rows start on 8-byte boundaries (pairs are written with element alignment where the row length is odd)
+    S3_REQUIRE(a_out % ((row_len & 1) ? 8 : 16) == 0, "%s: output not aligned (row_len %lld)", who, (long long)row_len);
+    if (dtype == S3_DTYPE_F32) return launch_planned<float>(p, rows, aligned, d_data, row_len, in_stride, d_out, as_stream(stream));
+    return launch_planned<double>(p, rows, aligned, d_data, row_len, in_stride, d_out, as_stream(stream));
+}
+
 int s3_interp_planned(s3_interp_plan *p, const double *d_w, const void *d_data, int dtype, int64_t row_len,
                       int64_t in_stride, double *d_out, s3_stream stream) {
     S3_REQUIRE(p != nullptr, "s3_interp_planned: null plan");
@@ -1064,24 +1169,50 @@ int s3_interp_planned(s3_interp_plan *p, const double *d_w, const void *d_data, 
         const int rc = s3_interp_plan_set_weights(p, d_w, stream);
         if (rc != S3_OK) return rc;
     }
-    S3_REQUIRE(p->has_weights, "s3_interp_planned: no weights (pass d_w or call s3_interp_plan_set_weights first)");
-    S3_REQUIRE(dtype == S3_DTYPE_F32 || dtype == S3_DTYPE_F64, "s3_interp_planned: unknown dtype %d", dtype);
-    S3_REQUIRE(row_len >= 0, "s3_interp_planned: bad row_len");
-    if (row_len == 0) return S3_OK;
-    S3_REQUIRE(d_data && d_out, "s3_interp_planned: null array");
-    const int epv = dtype == S3_DTYPE_F32 ? 4 : 2;
-    const uintptr_t a_in = reinterpret_cast<uintptr_t>(d_data), a_out = reinterpret_cast<uintptr_t>(d_out);
-    if (in_stride <= 0) in_stride = row_len;
-    S3_REQUIRE(in_stride >= row_len, "s3_interp_planned: in_stride %lld < row_len %lld", (long long)in_stride, (long long)row_len);
-    // every source row starts on a 16-byte boundary and is readable up to the next multiple of 16 bytes (the ragged tail
-    // of a row is loaded as a whole vector, the surplus lanes are never stored)
-    S3_REQUIRE(in_stride % epv == 0 && in_stride >= (row_len + epv - 1) / epv * epv && a_in % 16 == 0,
-               "s3_interp_planned: source rows must be 16-byte aligned with a pitch >= the row length rounded up to %d "
-               "elements (row_len %lld, in_stride %lld)", epv, (long long)row_len, (long long)in_stride);
-    // output rows of even length are written as double2 (16-byte aligned rows), odd lengths per element
-    S3_REQUIRE(a_out % ((row_len & 1) ? 8 : 16) == 0, "s3_interp_planned: output not aligned (row_len %lld)", (long long)row_len);
-    if (dtype == S3_DTYPE_F32) return launch_planned<float>(p, d_data, row_len, in_stride, d_out, as_stream(stream));
-    return launch_planned<double>(p, d_data, row_len, in_stride, d_out, as_stream(stream));
+    return planned_dispatch(p, p->rows, "s3_interp_planned", d_data, dtype, row_len, in_stride, d_out, stream);
 }
+
+__global__ void source_ids_kernel(const int32_t *__restrict__ rows, int64_t n, const int32_t *__restrict__ ids, int32_t n_table,
+                                  int32_t *__restrict__ rows_src, int32_t *__restrict__ bad) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t r = ids[rows[i]];
+    if (r < 0 || r >= n_table) atomicExch(bad, 1);
+    rows_src[i] = r < 0 || r >= n_table ? 0 : r;
+}
+
+int s3_interp_plan_set_source_ids(s3_interp_plan *p, const int32_t *d_ids, int64_t n_table_rows, s3_stream stream) {
+    S3_REQUIRE(p != nullptr && d_ids != nullptr, "s3_interp_plan_set_source_ids: null argument");
+    S3_REQUIRE(n_table_rows >= 1 && n_table_rows < ((int64_t)1 << 31), "s3_interp_plan_set_source_ids: bad table size");
+    hipStream_t st = as_stream(stream);
+    if (!p->rows_src)
+        S3_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&p->rows_src), sizeof(int32_t) * (size_t)std::max<int64_t>(p->total_rows, 1)));
+    p->n_table = 0;
+    int32_t *d_bad = nullptr, bad = 0;
+    S3_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&d_bad), sizeof(int32_t)));
+    hipError_t e = hipMemsetAsync(d_bad, 0, sizeof(int32_t), st);
+    if (e == hipSuccess && p->total_rows > 0) {
+        source_ids_kernel<<<s3::grid_for(p->total_rows, 256), 256, 0, st>>>(p->rows, p->total_rows, d_ids, (int32_t)n_table_rows,
+                                                                            p->rows_src, d_bad);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, sizeof(int32_t), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(d_bad);
+    S3_HIP_CHECK(e);
+    S3_REQUIRE(bad == 0, "s3_interp_plan_set_source_ids: id outside [0, %lld)", (long long)n_table_rows);
+    p->n_table = n_table_rows;
+    return S3_OK;
+}
+
+int s3_interp_planned_src(s3_interp_plan *p, const void *d_table, int dtype, int64_t n_table_rows, int64_t row_len,
+                          int64_t in_stride, double *d_out, s3_stream stream) {
+    S3_REQUIRE(p != nullptr, "s3_interp_planned_src: null plan");
+    S3_REQUIRE(p->rows_src != nullptr && p->n_table > 0, "s3_interp_planned_src: call s3_interp_plan_set_source_ids first");
+    S3_REQUIRE(n_table_rows == p->n_table, "s3_interp_planned_src: the table has %lld rows, the ids were given for %lld",
+               (long long)n_table_rows, (long long)p->n_table);
+    return planned_dispatch(p, p->rows_src, "s3_interp_planned_src", d_table, dtype, row_len, in_stride, d_out, stream);
+}
+
 
 }  // extern "C"

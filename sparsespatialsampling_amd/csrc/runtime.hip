@@ -206,7 +206,7 @@ int s3_download(void *h_dst, const void *d_src, size_t bytes, s3_stream stream) 
 
 const char *s3_last_error(void) { return s3::g_err; }
 
-int s3_abi_version(void) { return 1; }
+int s3_abi_version(void) { return S3_ABI_VERSION; }
 
 int s3_device_count(int *h_count) {
     S3_REQUIRE(h_count != nullptr, "s3_device_count: null output");

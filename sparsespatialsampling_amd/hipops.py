@@ -188,14 +188,29 @@ class InterpPlan:
         nt, nr = C.c_int64(0), C.c_int64(0)
         check(_lib.hip_lib().s3_interp_plan_info(self._handle, C.byref(nt), C.byref(nr)), "s3_interp_plan_info")
         self.n_tiles, self.total_rows = nt.value, nr.value
-        self._w_key = None
+        self._w_ref = None              # the weights tensor whose values the plan holds (kept alive: see interp)
+        self._w_version = None
+        self.n_table = None             # rows of the full table behind the source rows (set_source_ids)
 
     def set_weights(self, w):
-        """attach the weights of the table ([nc, k] float64, caller's cell order); the plan keeps them in tile order"""
+        """attach the weights of the table ([nc, k] float64, caller's cell order); the plan keeps a COPY in tile order.
+        Call it again after rewriting ``w`` in place through a raw pointer (``idw_weights`` writes that way): such writes
+        do not change the tensor's version counter, so ``interp`` cannot see them."""
         if not (w.is_cuda and w.dtype == pt.float64 and w.is_contiguous() and tuple(w.shape) == (self.nc, self.k)):
             raise TypeError("InterpPlan: weights must be a contiguous float64 [nc, k] device tensor")
         check(_lib.hip_lib().s3_interp_plan_set_weights(self._handle, _ptr(w), _stream()), "s3_interp_plan_set_weights")
-        self._w_key = (w.data_ptr(), w._version)
+        # the tensor itself, not its address: while the plan holds it the allocator cannot hand the same address to
+        # another weights tensor, so `is` identifies it (ADVICE r2)
+        self._w_ref, self._w_version = w, w._version
+
+    def set_source_ids(self, ids, n_table):
+        """``ids`` (int32 device tensor [n_src]): the row of the caller's full table behind each source row the plan was built
+        on; afterwards ``interp_src`` reads a full ``[n_table, ...]`` batch where it lies (s3_interp_plan_set_source_ids)"""
+        if not (ids.is_cuda and ids.dtype == pt.int32 and ids.is_contiguous() and ids.numel() == self.n_src):
+            raise TypeError("InterpPlan.set_source_ids: contiguous int32 device tensor with one id per source row required")
+        check(_lib.hip_lib().s3_interp_plan_set_source_ids(self._handle, _ptr(ids), int(n_table), _stream()),
+              "s3_interp_plan_set_source_ids")
+        self.n_table = int(n_table)
 
     def partition(self, world):
         """cost-balanced leaf-cell shards (s3_interp_plan_partition): ``(order, cuts)`` -- ``order`` is the plan's processing
@@ -207,10 +222,12 @@ class InterpPlan:
         return order, [int(c) for c in cuts]
 
     @staticmethod
-    def _layout(data):
-        """(row_len, in_stride) of a data matrix the planned kernel can read, None otherwise: every source row starts on
-        a 16-byte boundary and is readable up to the next multiple of 16 bytes (``padded_rows`` views always are; dense
-        rows when their length is a multiple of 16 bytes)"""
+    def _layout(data, k=None):
+        """(row_len, in_stride) of a data matrix the planned kernels can read, None otherwise.  Every kernel takes rows
+        that start on a 16-byte boundary and are readable up to the next multiple of 16 bytes (``padded_rows`` views always
+        are; dense rows when their length is a multiple of 16 bytes).  Plans with the reference's neighbour counts
+        (``k`` = 8 | 26) also take dense rows of any length >= 16 bytes where they lie (element alignment; the persistent
+        kernel, s3hip.h)."""
         if data.dtype not in DTYPE_CODE or data.dim() < 1:
             return None
         epv = 16 // data.element_size()
@@ -221,14 +238,17 @@ class InterpPlan:
             in_stride = int(data.stride(0))
         else:
             return None
+        if in_stride >= 1 << 31:
+            return None
         padded = (row_len + epv - 1) // epv * epv
         if in_stride % epv or in_stride < padded or (data.is_cuda and data.data_ptr() % 16):
-            return None
+            if not (k in (8, 26) and row_len >= epv):
+                return None
         return row_len, in_stride
 
     @staticmethod
     def supports(k, data):
-        return k <= 64 and InterpPlan._layout(data) is not None
+        return k <= 64 and InterpPlan._layout(data, k) is not None
 
     def close(self):
         if getattr(self, "_handle", None) is not None and self._handle.value:
@@ -247,20 +267,38 @@ class InterpPlan:
         if not (w.dtype == pt.float64 and tuple(w.shape) == (self.nc, self.k) and int(data.shape[0]) == self.n_src
                 and data.dtype in DTYPE_CODE):
             raise TypeError("InterpPlan.interp: weights / data do not match the plan")
-        layout = self._layout(data)
+        row_len, in_stride, out = self._check_batch(data, out, "interp")
+        if w is not self._w_ref or w._version != self._w_version:    # another tensor, or modified through torch: re-attach
+            self.set_weights(w)
+        check(_lib.hip_lib().s3_interp_planned(self._handle, C.c_void_p(0), C.c_void_p(data.data_ptr()),
+                                               DTYPE_CODE[data.dtype], row_len, in_stride, _ptr(out), _stream()),
+              "s3_interp_planned")
+        return out
+
+    def _check_batch(self, data, out, who):
+        layout = self._layout(data, self.k)
         if layout is None:
-            raise TypeError("InterpPlan.interp: source rows must be 16-byte aligned (see padded_rows / repitch_rows)")
+            raise TypeError(f"InterpPlan.{who}: source rows must be 16-byte aligned (see padded_rows), or dense rows of at "
+                            f"least 16 bytes on a plan with k = 8 | 26")
         row_len, in_stride = layout
         if out is None:
             out = pt.empty((self.nc,) + tuple(data.shape[1:]), dtype=pt.float64, device=data.device)
         if not (data.is_cuda and out.is_cuda and out.is_contiguous() and out.dtype == pt.float64
                 and out.numel() == self.nc * row_len):
-            raise TypeError("InterpPlan.interp: device tensors required, out must be contiguous float64 [nc, ...]")
-        if self._w_key != (w.data_ptr(), w._version):            # new or modified weights: re-attach
-            self.set_weights(w)
-        check(_lib.hip_lib().s3_interp_planned(self._handle, C.c_void_p(0), C.c_void_p(data.data_ptr()),
-                                               DTYPE_CODE[data.dtype], row_len, in_stride, _ptr(out), _stream()),
-              "s3_interp_planned")
+            raise TypeError(f"InterpPlan.{who}: device tensors required, out must be contiguous float64 [nc, ...]")
+        return row_len, in_stride, out
+
+    def interp_src(self, table, out=None):
+        """like ``interp`` for a FULL batch ``table`` [n_table, ...] that is read where it lies (no gather of the referenced
+        rows first); needs ``set_weights`` and ``set_source_ids``"""
+        if self.n_table is None or self._w_ref is None:
+            raise RuntimeError("InterpPlan.interp_src: call set_weights and set_source_ids first")
+        if int(table.shape[0]) != self.n_table or table.dtype not in DTYPE_CODE:
+            raise TypeError("InterpPlan.interp_src: the table does not match the ids given to set_source_ids")
+        row_len, in_stride, out = self._check_batch(table, out, "interp_src")
+        check(_lib.hip_lib().s3_interp_planned_src(self._handle, C.c_void_p(table.data_ptr()), DTYPE_CODE[table.dtype],
+                                                   self.n_table, row_len, in_stride, _ptr(out), _stream()),
+              "s3_interp_planned_src")
         return out
 
 

@@ -14,6 +14,28 @@ def declared_symbols():
     return sorted(set(re.findall(r"\b(s3_[a-z0-9_]+)\s*\(", text)))
 
 
+def header_abi_version():
+    m = re.search(r"#define\s+S3_ABI_VERSION\s+(\d+)", open(os.path.join(ROOT, "include", "s3hip.h")).read())
+    return int(m.group(1))
+
+
+def test_stale_library_is_refused_with_a_rebuild_hint(monkeypatch):
+    """a libs3hip.so built from another revision of the header must not be used silently"""
+    from sparsespatialsampling_amd import _lib
+    _lib.hip_lib()
+    monkeypatch.setattr(_lib, "_hip", None)
+    monkeypatch.setattr(_lib, "ABI_VERSION", _lib.ABI_VERSION + 1)
+    with pytest.raises(_lib.HipUnavailableError, match="rebuild"):
+        _lib.hip_lib()
+    monkeypatch.setattr(_lib, "ABI_VERSION", _lib.ABI_VERSION - 1)
+    monkeypatch.setattr(_lib, "_hip", None)
+    sigs = dict(_lib.HIP_SIGNATURES)
+    sigs["s3_no_such_symbol"] = (None, [])
+    monkeypatch.setattr(_lib, "HIP_SIGNATURES", sigs)
+    with pytest.raises(_lib.HipUnavailableError, match="s3_no_such_symbol"):
+        _lib.hip_lib()
+
+
 def test_header_symbols_exported_and_bound():
     from sparsespatialsampling_amd import _lib
     lib = _lib.hip_lib()
@@ -23,7 +45,7 @@ def test_header_symbols_exported_and_bound():
         assert hasattr(lib, n), f"libs3hip.so does not export {n}"
         assert n in _lib.HIP_SIGNATURES, f"{n} has no ctypes prototype in _lib.py"
     assert set(_lib.HIP_SIGNATURES) == set(names)
-    assert lib.s3_abi_version() == 1
+    assert lib.s3_abi_version() == _lib.ABI_VERSION == header_abi_version()
 
 
 def test_h5_sink_symbols_exported_and_bound():

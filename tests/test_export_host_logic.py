@@ -59,7 +59,9 @@ def _cpu_ops():
     ops.idw_weights = lambda dist: pt.from_numpy(orc.idw_weights(dist.numpy()))
     ops.interp = lambda w, idx, data, out=None: pt.from_numpy(orc.interp(w.numpy(), idx.numpy().astype(np.int64),
                                                                           data.numpy()))
-    ops.InterpPlan = type("InterpPlan", (), {"__init__": lambda self, *a, **k: None,
+    ops.InterpPlan = type("InterpPlan", (), {"__init__": lambda self, *a, **k: None, "n_table": None,
+                                            "set_weights": lambda self, w: None,
+                                            "set_source_ids": lambda self, ids, n: setattr(self, "n_table", n),
                                             "supports": staticmethod(lambda k, d: False)})
     ops.padded_rows = lambda n_rows, row_len, dtype, dev, extra_lines=0: pt.empty((n_rows, row_len + 3), dtype=dtype)[:, :row_len]
 

@@ -140,8 +140,15 @@ def test_interp_planned_random_table_no_centers(ops, orc):
     ref = orc.interp(w, idx, data)
     assert np.abs(out - ref).max() <= 1e-13 * np.abs(ref).max()
     from sparsespatialsampling_amd._lib import S3HipError
+    # dense ragged rows: read where they lie on plans with the reference's neighbour counts (persistent kernel) ...
+    ragged = rng.standard_normal((n, 1, 25)).astype(np.float32)
+    out = plan.interp(dev(w), dev(ragged)).cpu().numpy()
+    ref = orc.interp(w, idx, ragged)
+    assert np.abs(out - ref).max() <= 1e-13 * np.abs(ref).max()
+    # ... and refused on any other plan (the other kernels need 16-byte aligned rows)
+    plan5 = ops.InterpPlan(dev(idx[:, :5], pt.int32), n)
     with pytest.raises(TypeError):
-        plan.interp(dev(w), dev(rng.standard_normal((n, 1, 25)).astype(np.float32)))     # dense ragged rows: not aligned
+        plan5.interp(dev(np.ascontiguousarray(w[:, :5])), dev(ragged))
     with pytest.raises(S3HipError):
         ops.InterpPlan(dev(np.full((4, 8), n), pt.int32), n)                              # index out of range
 
@@ -171,6 +178,98 @@ def test_interp_planned_short_and_ragged_rows(ops, orc, row_len, dtype):
     ref = orc.interp(w.cpu().numpy(), idx.cpu().numpy(), dense.cpu().numpy().reshape(n, 1, row_len)).reshape(nc, row_len)
     assert np.abs(got.cpu().numpy() - ref).max() <= 1e-13 * np.abs(ref).max()
     plan.close(); knn.close()
+
+
+@pytest.mark.parametrize("k,d", [(26, 3), (8, 2)])
+@pytest.mark.parametrize("row_len,dtype,dense", [(25, pt.float32, False), (25, pt.float32, True), (32, pt.float32, True),
+                                                 (75, pt.float32, True), (75, pt.float32, False), (100, pt.float32, True),
+                                                 (131, pt.float32, True), (256, pt.float32, False), (17, pt.float64, True),
+                                                 (9, pt.float64, False), (64, pt.float64, True), (5, pt.float32, True),
+                                                 (4, pt.float32, True), (2, pt.float64, True), (300, pt.float32, True)])
+def test_stream_kernel_equals_direct(ops, orc, monkeypatch, k, d, row_len, dtype, dense):
+    """the persistent kernel (interp_planned_stream_kernel: the reference's neighbour counts, rows of more than four 16-byte
+    vectors -- the 25-snapshot batches of examples/s3_for_cylinder3D_Re3900.py:28-69 as scalar (100 B) and 3-component
+    (300 B) rows) on pitched batches and on DENSE batches read where they lie (element-aligned rows, ragged tails loaded as
+    the last vector of the row): bit-equal to the direct gather kernel, 1e-13 against the oracle; also with fewer tiles
+    than persistent workgroups and with partial tiles"""
+    monkeypatch.setenv("S3_STREAM_MIN_TILES", "1")
+    rng = np.random.default_rng(row_len * 7 + k)
+    for n, nc in ((30_000, 7_777), (400, 65), (3000, 1)):
+        x, c = rng.random((n, d)), rng.random((nc, d)) * 1.2 - 0.1
+        knn = ops.KnnIndex(x)
+        idx, dist = knn.query(c, k)
+        w = ops.idw_weights(dist)
+        plan = ops.InterpPlan(idx, n, c)
+        if dense:
+            data = pt.empty((n, row_len), dtype=dtype, device="cuda")
+        else:
+            data = ops.padded_rows(n, row_len, dtype, "cuda")
+        data.normal_()
+        got = plan.interp(w, data)
+        ref_d = ops.interp(w, idx, data.contiguous())
+        assert got.shape == (nc, row_len) and pt.equal(got, ref_d)
+        if nc <= 7_777:
+            ref = orc.interp(w.cpu().numpy(), idx.cpu().numpy(), data.contiguous().cpu().numpy().reshape(n, 1, row_len))
+            assert np.abs(got.cpu().numpy() - ref.reshape(nc, row_len)).max() <= 1e-13 * np.abs(ref).max()
+        plan.close(); knn.close()
+
+
+@pytest.mark.parametrize("row_len,dtype", [(25, pt.float32), (75, pt.float32), (1000, pt.float32), (16, pt.float32),
+                                           (3, pt.float32), (33, pt.float64), (8, pt.float64)])
+def test_interp_src_reads_the_full_table_in_place(ops, orc, row_len, dtype):
+    """a device-resident batch [N, L] is read where it lies through the plan's source ids (s3_interp_planned_src): same
+    bits as the planned kernel on the gathered, pitched copy of the referenced rows and as the direct kernel on the table
+    (reference semantics: interpolate_data consumes data[N, n_comp, T] as it stands, export.py:446-468)"""
+    rng = np.random.default_rng(row_len)
+    n, nc, k = 60_000, 4_000, 26
+    x, c = rng.random((n, 3)), rng.random((nc, 3)) * 0.4 + 0.3           # the cells reference a part of the points only
+    knn = ops.KnnIndex(x)
+    idx, dist = knn.query(c, k)
+    w = ops.idw_weights(dist)
+    table = pt.empty((n, row_len), dtype=dtype, device="cuda").normal_()
+    direct = ops.interp(w, idx, table)
+    used, remap = ops.referenced_rows([idx], n, coords=x)
+    assert used.numel() < n
+    idx_c = idx.clone()
+    ops.remap_indices(idx_c, remap)
+    plan = ops.InterpPlan(idx_c, int(used.numel()), c)
+    plan.set_weights(w)
+    with pytest.raises(RuntimeError):
+        plan.interp_src(table)                                           # ids not set yet
+    plan.set_source_ids(used.contiguous(), n)
+    epv = 16 // table.element_size()
+    if row_len % epv == 0 or row_len >= epv:
+        got = plan.interp_src(table)
+        assert pt.equal(got, direct)
+        rows = ops.gather_rows(table, used.contiguous(), ops.padded_rows(int(used.numel()), row_len, dtype, "cuda"))
+        assert pt.equal(plan.interp(w, rows), direct)
+        ref = orc.interp(w.cpu().numpy(), idx.cpu().numpy(), table.cpu().numpy().reshape(n, 1, row_len)).reshape(nc, row_len)
+        assert np.abs(got.cpu().numpy() - ref).max() <= 1e-13 * np.abs(ref).max()
+    else:
+        with pytest.raises(TypeError):
+            plan.interp_src(table)                                       # rows shorter than one vector: the gather path
+    with pytest.raises(TypeError):
+        plan.interp_src(table[:-1])
+    plan.close(); knn.close()
+
+
+def test_plan_weights_are_identified_by_the_tensor_not_its_address(ops):
+    """a plan must not mistake a new weights tensor that the allocator placed at a freed tensor's address for the
+    one it holds"""
+    rng = np.random.default_rng(3)
+    n, nc, k = 5000, 900, 8
+    idx = dev(rng.integers(0, n, (nc, k)), pt.int32)
+    data = pt.empty((n, 32), dtype=pt.float32, device="cuda").normal_()
+    plan = ops.InterpPlan(idx, n)
+    w1 = dev(rng.random((nc, k)))
+    out1 = plan.interp(w1, data).clone()
+    ptr = w1.data_ptr()
+    del w1                                                               # the plan still holds it: the address stays taken
+    w2 = dev(rng.random((nc, k)))
+    assert w2.data_ptr() != ptr
+    out2 = plan.interp(w2, data)
+    assert pt.equal(out2, ops.interp(w2, idx, data)) and not pt.equal(out1, out2)
+    plan.close()
 
 
 def test_referenced_rows_and_gather(ops):

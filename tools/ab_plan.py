@@ -18,7 +18,7 @@ geos = [geometry.CubeGeometry("domain", True, cfg["lo"], [float(v) for v in cfg[
 tree = SamplingTree(pt.from_numpy(x), pt.from_numpy(metric), geos, uniform_level=cfg["uniform_levels"], min_metric=cfg["min_metric"])
 tree.refine()
 centers = tree.all_centers.numpy()
-k, T = 26, 1000
+k, T = 26, int(os.environ.get('AB_T', '1000'))
 idx, dist = hipops.KnnIndex(x).query(centers, k)
 w = hipops.idw_weights(dist)
 nc = len(centers)
@@ -36,7 +36,7 @@ for item in spec.split(";"):
     if extra not in buffers:
         buffers[extra] = hipops.padded_rows(len(x), T, pt.float32, "cuda", extra[0])
         buffers[extra].normal_(generator=pt.Generator(device="cuda").manual_seed(1))
-    variants.append((name, plan, buffers[extra], {kk: v for kk, v in env.items() if kk.startswith("S3_PLAN_EARLY") or kk.startswith("S3_LAUNCH_")}))
+    variants.append((name, plan, buffers[extra], dict(env)))
     print(f"{name}: tiles {plan.n_tiles} staged rows {plan.total_rows} pitch {buffers[extra].stride(0) * 4} B", flush=True)
 times = {v[0]: [] for v in variants}
 for r in range(rounds + 1):

@@ -35,8 +35,8 @@ def tick():
 for rep in range(3):
     data = pt.randn((n, 1, t), dtype=pt.float32)
     t0 = tick()
-    batch = ex._upload(_as_float(data)); t1 = tick()
-    dev = ex._table_centers.apply(batch); t2 = tick()
+    batch, in_place = ex._upload(_as_float(data)); t1 = tick()
+    dev = ex._table_centers.apply(batch, full_table=in_place); t2 = tick()
     out = ex._download(dev, 1, t, "centers"); t3 = tick()
     print(f"T={t}: upload {1e3*(t1-t0):6.1f}  interp {1e3*(t2-t1):5.2f}  transpose + download {1e3*(t3-t2):6.1f} ms   "
           f"(total {1e3*(t3-t0):.1f})", flush=True)

@@ -20,9 +20,16 @@ Multi-GPU (one process per GPU, launched by torch.distributed.run; the collectiv
   batch -- no data-path collective; total work is fixed ("scaling": "strong").  `--shard snapshots` gives every rank
   all cells and its own snapshot batches instead ("weak").
 
-Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP events on the launch stream) and, at N = 1,
-`cpu_baseline` (the CPU oracle on a slice of this very workload), `refine_cpu_baseline` and `end_to_end` (host tensors
-in -> host tensors out through ExportData, PCIe included; never `value`).
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP events on the launch stream: mean, min, median, max
+per launch, and the identity of the device they were taken on) and, at N = 1:
+* `roofline_batches`: the same kernel family at the batch lengths the reference actually exports with -- 25 snapshots of a
+  scalar (100-byte ragged rows) and of a 3-component field (300-byte rows), examples/s3_for_cylinder3D_Re3900.py:28-69 ->
+  utils.py:204-226, and 100 snapshots -- each with its own algorithmic bytes;
+* `device_resident_input`: a CUDA tensor [N, 1, T] fp32 as the reference hands batches over (every row of the CFD mesh,
+  dense) -> ExportData's upload + neighbour table -> [Nc, T] f64 on the device, and the whole `_fit_data` incl. the download;
+* `cpu_baseline` (the CPU oracle on a slice of this very workload at the bench's batch length), `refine_cpu_baseline`
+  (`refine()` of THIS workload at full size with the oracle's kernels) and `end_to_end` (host tensors in -> host tensors
+  out through ExportData, PCIe included; never `value`), with the three GPU / CPU ratios side by side in `gpu_over_cpu`.
 """
 import argparse
 import glob
@@ -87,38 +94,36 @@ def build_case(name, cfg, geometry):
 
 
 # ---- CPU baselines (rank 0, N = 1 only; the oracle is the checker of the tests, used here as the timed CPU port) --------
-def cpu_baseline(w, idx, data, k, seconds=12.0, n_cells=10_000, t_max=64):
+def cpu_baseline(w, idx, data, k, seconds=10.0, n_cells=100_000):
     """the CPU oracle (C + OpenMP restatement of export.py:446-468) on a slice of THIS workload: the first `n_cells` cells of
-    the bench's own neighbour table and the source rows they reference, the first `t_max` snapshots of the bench's batch"""
+    the bench's own neighbour table, the source rows they reference, ALL snapshots of the bench's batch"""
     from oracle import s3_oracle as orc
     nc = min(int(w.shape[0]), n_cells)
     i_s, w_s = idx[:nc].cpu().numpy(), w[:nc].cpu().numpy()
     rows, inv = np.unique(i_s, return_inverse=True)
-    t = min(int(data.shape[1]), t_max)
-    sub = data[pt.from_numpy(rows).to(data.device).long()][:, :t].contiguous().cpu().numpy().reshape(len(rows), 1, t)
+    t = int(data.shape[1])
+    sub = data[pt.from_numpy(rows).to(data.device).long()].contiguous().cpu().numpy().reshape(len(rows), 1, t)
     inv = inv.reshape(i_s.shape)
     orc.interp(w_s, inv, sub)                  # warm
     reps, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < seconds:
+    while time.perf_counter() - t0 < seconds or reps < 2:
         orc.interp(w_s, inv, sub)
         reps += 1
     dt = time.perf_counter() - t0
     return dict(value=nc * t * reps / dt / 1e6, unit="Mcells*snapshots/s", cores=orc.num_threads(), kind="port",
                 sample=f"oracle/s3_oracle.c s3o_interp (OpenMP) on the bench's own table: first {nc} cells, the {len(rows)} "
-                       f"source rows they reference, first {t} snapshots, {reps} passes, k={k}, fp32 in / f64 out")
+                       f"source rows they reference, all {t} snapshots of the batch, {reps} passes, k={k}, fp32 in / f64 out")
 
 
-def refine_cpu_baseline():
-    """`SamplingTree.refine()` with the CPU oracle kernels (tests/oracle_backend.py: brute-force KNN in C + OpenMP) and the
-    same host logic on the cylinder3D_small workload (299 502 points): the CPU port's grid-generation wall-clock"""
+def refine_cpu_baseline(name, x, metric, geos, kw, n_leaf_gpu):
+    """`SamplingTree.refine()` of THIS workload at full size with the CPU oracle's kernels (tests/oracle_backend.py; the
+    neighbour queries through the oracle's bucket grid, its stand-in for the reference's kd-tree: identical results to
+    brute force, pinned by the same goldens) and the same host logic: the CPU port's grid-generation wall-clock"""
     import sparsespatialsampling_amd.s_cube as s_cube
-    from sparsespatialsampling_amd import geometry
     from oracle import s3_oracle as orc
     from tests.oracle_backend import OracleTreeBackend
-    cfg = dict(WORKLOADS["cylinder3D_small"])
-    x, metric, geos, kw = build_case("cylinder3D_small", cfg, geometry)
     product = s_cube._make_backend
-    s_cube._make_backend = lambda v, t, k: OracleTreeBackend(v, t, k)
+    s_cube._make_backend = lambda v, t, k: OracleTreeBackend(v, t, k, grid=True)
     try:
         t0 = time.perf_counter()
         tree = s_cube.SamplingTree(pt.from_numpy(x), pt.from_numpy(metric), geos, **kw)
@@ -128,16 +133,9 @@ def refine_cpu_baseline():
         tree.close()
     finally:
         s_cube._make_backend = product
-    pt.cuda.synchronize()
-    t0 = time.perf_counter()
-    tree = s_cube.SamplingTree(pt.from_numpy(x), pt.from_numpy(metric), geos, **kw)
-    tree.refine()
-    pt.cuda.synchronize()
-    gpu_s = time.perf_counter() - t0
-    same = len(tree.all_centers) == n_leaf
-    tree.close()
-    return dict(workload=f"cylinder3D_small: {len(x)} points -> {n_leaf} leaf cells", cpu_wall_s=cpu_s, cores=orc.num_threads(),
-                kind="port", gpu_wall_s=gpu_s, speedup=cpu_s / gpu_s, same_grid_size=bool(same))
+    return dict(workload=f"{name} at full size: {len(x)} points -> {n_leaf} leaf cells", cpu_wall_s=cpu_s,
+                cores=orc.num_threads(), kind="port", knn="bucket grid (oracle/s3_oracle.c s3o_grid_*)",
+                same_grid_size=bool(n_leaf == n_leaf_gpu))
 
 
 def end_to_end(x, centers, k, batches=(25, 200)):
@@ -196,6 +194,114 @@ def copy_bandwidth_gbs(n_bytes=2 << 30, reps=5):
     return 2.0 * n_bytes * reps / (a.elapsed_time(b) * 1e-3) / 1e9
 
 
+def device_identity():
+    """which card the numbers were taken on: launch times of one binary differ by several per cent between the boxes of a
+    pool, so a timing without the device behind it cannot be matched to a profile"""
+    prop = pt.cuda.get_device_properties(pt.cuda.current_device())
+    ident = dict(name=prop.name, gcn_arch=getattr(prop, "gcnArchName", None), compute_units=prop.multi_processor_count,
+                 hbm_gib=round(prop.total_memory / 2 ** 30, 1), uuid=str(getattr(prop, "uuid", "")) or None,
+                 hostname=os.uname().nodename)
+    try:
+        import subprocess
+        out = subprocess.run(["rocm-smi", "--showuniqueid", "--showserial", "--showclocks", "--json"], capture_output=True,
+                             text=True, timeout=20).stdout
+        card = json.loads(out).get("card0", {})
+        ident["unique_id"] = card.get("Unique ID")
+        ident["serial"] = card.get("Serial Number")
+        ident["clocks"] = {k.split(" ")[0]: v for k, v in card.items() if "clock" in k.lower() and "level" in k.lower()}
+    except Exception as err:                      # no rocm-smi on the box / no permission: the torch fields remain
+        ident["rocm_smi"] = f"unavailable: {type(err).__name__}"
+    return ident
+
+
+def launch_times_ms(fn, steps, warmup):
+    """HIP-event time of every one of `steps` launches of fn() on the current stream (after `warmup` untimed ones)"""
+    for _ in range(warmup):
+        fn()
+    pt.cuda.synchronize()
+    ev = [(pt.cuda.Event(enable_timing=True), pt.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    for a, b in ev:
+        a.record()
+        fn()
+        b.record()
+    pt.cuda.synchronize()
+    return [a.elapsed_time(b) for a, b in ev]
+
+
+def ms_stats(ms):
+    return dict(kernel_ms=float(np.mean(ms)), kernel_ms_min=float(np.min(ms)), kernel_ms_median=float(np.median(ms)),
+                kernel_ms_max=float(np.max(ms)), launches=len(ms))
+
+
+def planned_kernel_name(t_elems, k, plan_tiles):
+    """the kernel s3_interp_planned dispatches a batch of fp32 rows of t_elems elements to (csrc/interp_plan.hip: launch_planned)"""
+    vecs = (t_elems + 3) // 4
+    if vecs <= 4:
+        return ("interp_planned_short_quad_kernel<float,7>" if vecs == 4 and not os.environ.get("S3_SHORT_NO_QUAD")
+                else "interp_planned_short_reg_kernel<float,26>")
+    chunks = (t_elems + 31) // 32
+    if chunks <= int(os.environ.get("S3_STREAM_MAX_CHUNKS", "8")) and k in (8, 26) and plan_tiles >= int(os.environ.get("S3_STREAM_MIN_TILES", "64")):
+        return f"interp_planned_stream_kernel<float,{k},true,{'true' if t_elems % 2 == 0 else 'false'}>"
+    return "interp_planned_kernel<float,64>"
+
+
+def batch_record(hipops, plan, w, n_rows, nc, k, row_len, label, workload_key, steps, warmup, gen):
+    """roofline sub-record of one batch shape: rows of `row_len` fp32 elements in the layout ExportData uploads into"""
+    data = hipops.padded_rows(n_rows, row_len, pt.float32, "cuda")
+    data.normal_(generator=gen)
+    out = pt.empty((nc, row_len), dtype=pt.float64, device="cuda")
+    ms = launch_times_ms(lambda: plan.interp(w, data, out=out), steps, warmup)
+    b_alg = n_rows * row_len * 4 + nc * row_len * 8 + nc * k * (4 + 8)
+    st = ms_stats(ms)
+    traffic, src = recorded_traffic(workload_key)
+    rec = dict(rows=label, row_bytes=row_len * 4, pitch_bytes=int(data.stride(0)) * 4, kernel=planned_kernel_name(row_len, k, plan.n_tiles),
+               algorithmic_bytes=b_alg, achieved=b_alg / (st["kernel_ms"] * 1e-3) / 1e9, unit="GB/s",
+               frac=b_alg / (st["kernel_ms"] * 1e-3) / 8e12, frac_best_launch=b_alg / (st["kernel_ms_min"] * 1e-3) / 8e12,
+               Gcells_snapshots_per_s=nc * row_len / (st["kernel_ms"] * 1e-3) / 1e9, traffic=traffic,
+               traffic_source=None if traffic is None else f"recorded, not measured in this run: {src}", **st)
+    del data, out
+    return rec
+
+
+def device_resident_input(x, centers, k, t_list, bare_ms):
+    """a CUDA tensor [N, 1, T] fp32 as the reference hands batches over (export.py:128-167: every row of the CFD mesh, dense)
+    -> ExportData: `interp_ms` = upload step + neighbour table on the device (HIP events; [Nc, T] f64 stays in HBM),
+    `fit_data_ms` = the whole _fit_data incl. transpose and download to the host.  `bare_kernel_ms`: the planned kernel on
+    the pitched copy of the referenced rows (the layout the headline is measured in)."""
+    from sparsespatialsampling_amd.export import ExportData, _as_float
+    s = types.SimpleNamespace(n_dimensions=3, faces=None, centers=pt.from_numpy(centers), vertices=None, levels=None,
+                              metric=pt.zeros(len(x), dtype=pt.float64), size_initial_cell=1.0, save_path=".", save_name="bench",
+                              grid_name="g")
+    ex = ExportData(s, write_times=[str(i) for i in range(100000)], n_neighbors=k)
+    coords = pt.from_numpy(x)
+    out = {}
+    for t in t_list:
+        data = pt.empty((len(x), 1, t), dtype=pt.float32, device="cuda").normal_()
+        ex._fit_data(coords, data, "f", 10 ** 9)             # builds the cache on the first call; warms this size
+
+        def on_device():
+            batch, in_place = ex._upload(_as_float(data))
+            return ex._table_centers.apply(batch, True, full_table=in_place)
+        ms = launch_times_ms(on_device, 10, 2)
+        pt.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            ex._fit_data(coords, data, "f", 10 ** 9)
+        pt.cuda.synchronize()
+        fit_ms = (time.perf_counter() - t0) / 3 * 1e3
+        rec = dict(interp_ms=float(np.mean(ms)), interp_ms_min=float(np.min(ms)), interp_ms_median=float(np.median(ms)),
+                   fit_data_ms=fit_ms, Gcells_snapshots_per_s=len(centers) * t / (float(np.mean(ms)) * 1e-3) / 1e9,
+                   rows_read_in_place=bool(ex._upload(_as_float(data))[0].data_ptr() == data.data_ptr()))
+        if t in bare_ms:
+            rec["bare_kernel_ms"] = bare_ms[t]
+            rec["over_bare_kernel"] = rec["interp_ms"] / bare_ms[t]
+        out[f"T{t}"] = rec
+        del data
+    out["note"] = ("CUDA tensor [N, 1, T] fp32 (dense: all rows of the CFD mesh, row pitch = T elements) in; interp_ms: "
+                   "ExportData._upload + neighbour table, output [Nc, T] f64 in HBM; fit_data_ms adds transpose + pinned download")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -203,7 +309,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cylinder3D_Re3900", choices=sorted(WORKLOADS))
     ap.add_argument("--t-batch", type=int, default=None)
-    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baselines and the end-to-end leg (profiling runs)")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baselines, the device-resident and the end-to-end legs (profiling runs)")
+    ap.add_argument("--no-batches", action="store_true", help="skip the roofline_batches sub-records")
+    ap.add_argument("--n-comp", type=int, default=1, help="components per snapshot: the row holds n_comp * t_batch values")
     ap.add_argument("--shard", choices=["cells", "snapshots"], default="cells",
                     help="N>1: every rank interpolates its contiguous range of the generated cells for the same snapshots "
                          "(leaf-cell shards, default) or all cells for its own snapshot batches")
@@ -254,10 +362,10 @@ def main():
     warm.refine()
     warm.close()
     del warm, xs
-    # the grid generation is timed twice: the first full-size run of the process also pays for the device allocations (cell
-    # arrays, topology tables, allocator pools) -- both figures are reported, `refine_wall_s` is the second (steady) one
+    # the grid generation is timed four times: the first full-size run of the process also pays for the device allocations
+    # (cell arrays, topology tables, allocator pools) -- it is reported apart, `refine_wall_s` is the median of the other three
     timings = []
-    for attempt in range(2):
+    for attempt in range(4):
         pt.cuda.synchronize()
         comm.barrier()
         t0 = time.perf_counter()
@@ -272,8 +380,8 @@ def main():
         tree.close()
         del tree
     refine_first_s = timings[0][0]
-    refine_s, t_init = timings[1]
-    del metric
+    refine_s = float(np.median([t[0] for t in timings[1:]]))            # median of three steady runs
+    t_init = float(np.median([t[1] for t in timings[1:]]))
 
     # ---- KNN cache (once) -------------------------------------------------------------------------------------
     t0 = time.perf_counter()
@@ -303,14 +411,15 @@ def main():
     pt.cuda.synchronize()
     knn_cache_s = time.perf_counter() - t0
     nc, t_b = len(my_centers), cfg["t_batch"]
+    row_len = t_b * args.n_comp                      # values per source row: [N, n_comp, T] flattened
 
     # ---- synthetic snapshot batch resident in HBM ---------------------------------------------------------------
     gen = pt.Generator(device="cuda").manual_seed(1234 + (rank if args.shard == "snapshots" else 0))
     # the layout the export path uploads into: [rows, T] with the pitch of hipops.padded_rows
-    data = hipops.padded_rows(n_rows, t_b, pt.float32, "cuda", int(os.environ.get("S3_BENCH_PITCH_EXTRA", "0")))
+    data = hipops.padded_rows(n_rows, row_len, pt.float32, "cuda", int(os.environ.get("S3_BENCH_PITCH_EXTRA", "0")))
     data.normal_(generator=gen)
     dense = data.contiguous() if args.direct else None
-    out = pt.empty((nc, t_b), dtype=pt.float64, device="cuda")
+    out = pt.empty((nc, row_len), dtype=pt.float64, device="cuda")
 
     def step():
         if plan is not None:
@@ -331,7 +440,8 @@ def main():
     pt.cuda.synchronize()
     comm.barrier()
     elapsed = comm.allreduce_max(time.perf_counter() - t0)
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))       # HIP events on the launch stream
+    launch_ms = [a.elapsed_time(b) for a, b in ev]                       # HIP events on the launch stream, per launch
+    kernel_ms = float(np.mean(launch_ms))
 
     copy_bw = copy_bandwidth_gbs() if rank == 0 else None
     if rank == 0:
@@ -339,41 +449,71 @@ def main():
         value = units / elapsed / 1e6
         # algorithmic HBM bytes of one launch on this rank: every referenced source row once + every output
         # once + idx (int32) / weights (f64) once
-        b_alg = n_rows * t_b * 4 + nc * t_b * 8 + nc * k * (4 + 8)
+        b_alg = n_rows * row_len * 4 + nc * row_len * 8 + nc * k * (4 + 8)
         achieved = b_alg / (kernel_ms * 1e-3) / 1e9
-        workload = (f"{args.workload} (synthetic, SURVEY 8(d)): {len(x)} points x {t_b} snapshots per step, "
-                    f"{nc_total} generated cells, k={k}, fp32 in / f64 out")
-        traffic, traffic_src = recorded_traffic(f"{args.workload}/T{t_b}") if plan is not None and world == 1 else (None, None)
-        short = plan is not None and t_b * 4 <= 64
+        workload = (f"{args.workload} (synthetic, SURVEY 8(d)): {len(x)} points of which the {n_rows} rows the grid references "
+                    f"are resident (pitched, Hilbert order) x {t_b} snapshots per step, {nc_total} generated cells, k={k}, "
+                    f"fp32 in / f64 out")
+        shape_key = f"T{t_b}" + (f"x{args.n_comp}" if args.n_comp > 1 else "")
+        traffic, traffic_src = recorded_traffic(f"{args.workload}/{shape_key}") if plan is not None and world == 1 else (None, None)
         res = {
             "metric": "Mcells*snapshots/s interpolated", "value": value, "unit": "Mcells*snapshots/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak" if args.shard == "snapshots" else "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": workload, "n_points": len(x), "n_cells": nc_total, "t_batch": t_b, "k": k, "n_comp": 1,
+            "config": {"workload": workload, "n_points": len(x), "resident_source_rows": n_rows, "n_cells": nc_total,
+                       "t_batch": t_b, "k": k, "n_comp": args.n_comp, "shape_key": shape_key,
                        "parallelism": f"{'snapshot-axis' if args.shard == 'snapshots' else 'leaf-cell'} shards x{world}",
                        "cells_per_rank": shard_counts, "collectives": comm.name},
+            "device": device_identity(),
             "refine_wall_s": refine_s, "refine_init_s": t_init, "refine_first_run_wall_s": refine_first_s,
+            "refine_runs_s": [t[0] for t in timings],
             "refine_iterations": info["iterations"],
             "refine_cells_created": n_cells_total, "refine_leaves_per_s": nc_total / refine_s, "knn_cache_s": knn_cache_s,
             "captured_metric": info["metric_per_iter"][-1],
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "copy_kernel_GBs": copy_bw, "frac_of_copy_kernel": achieved / copy_bw,
                          "traffic": traffic, "traffic_source": None if traffic is None else f"recorded, not measured in this run: {traffic_src}",
-                         "kernel": "interp_kernel<float,4>" if plan is None else
-                                   (("interp_planned_short_quad_kernel<float,7>" if t_b * 4 == 64 and not os.environ.get("S3_SHORT_NO_QUAD")
-                                     else "interp_planned_short_reg_kernel<float,26>") if short else "interp_planned_kernel<float,64>"),
-                         "staged_rows_per_launch": None if plan is None else plan.total_rows, "kernel_ms": kernel_ms,
+                         "kernel": "interp_kernel<float,4>" if plan is None else planned_kernel_name(row_len, k, plan.n_tiles),
+                         "staged_rows_per_launch": None if plan is None else plan.total_rows, **ms_stats(launch_ms),
+                         "frac_best_launch": b_alg / (min(launch_ms) * 1e-3) / 8e12,
                          "algorithmic_bytes": b_alg, "resident_source_rows": n_rows, "cells_on_this_rank": nc,
-                         "gather_upper_bound_bytes": nc * k * t_b * 4 + nc * t_b * 8},
+                         "gather_upper_bound_bytes": nc * k * row_len * 4 + nc * row_len * 8},
         }
+        if world == 1 and plan is not None and not args.no_batches:
+            # the batch lengths the reference exports with (examples/s3_for_cylinder3D_Re3900.py:28-69, utils.py:204-226)
+            key = args.workload
+            shapes = [("T25", 25, "25 snapshots of a scalar field: 100-byte ragged rows"),
+                      ("T25x3", 75, "25 snapshots of a 3-component field: 300-byte rows"),
+                      ("T100", 100, "100 snapshots of a scalar field: 400-byte rows")]
+            res["roofline_batches"] = {name: batch_record(hipops, plan, w, n_rows, nc, k, rl, label, f"{key}/{name}",
+                                                           args.steps, args.warmup, gen)
+                                       for name, rl, label in shapes if rl != row_len}
         if not args.no_cpu_baseline and world == 1:       # reported at N=1 only
             res["cpu_baseline"] = cpu_baseline(w, idx, data, k)
+            bare = {t_b: kernel_ms}
+            if "roofline_batches" in res and "T25" in res["roofline_batches"]:
+                bare[25] = res["roofline_batches"]["T25"]["kernel_ms"]
             del data, out
             pt.cuda.empty_cache()
             if not cfg.get("kind") == "box":
+                res["device_resident_input"] = device_resident_input(x, centers, k, sorted({25, t_b}), bare)
+                pt.cuda.empty_cache()
                 res["end_to_end"] = end_to_end(x, centers, k)
-            res["refine_cpu_baseline"] = refine_cpu_baseline()
+            rcb = refine_cpu_baseline(args.workload, x, metric, geos, tree_kw, nc_total)
+            rcb.update(gpu_wall_s=refine_s, gpu_runs_s=[t[0] for t in timings[1:]], speedup=rcb["cpu_wall_s"] / refine_s)
+            res["refine_cpu_baseline"] = rcb
+            cpu_g = res["cpu_baseline"]["value"] / 1e3                       # G cell*snapshots/s of the CPU port
+            ratios = {"in_hbm": value / 1e3 / cpu_g, "cpu_port_Gcells_snapshots_per_s": cpu_g,
+                      "note": "GPU rate / rate of the OpenMP oracle port on this box's host cores; in_hbm: the headline (inputs "
+                              "resident, pitched), device_resident: dense CUDA batch in -> device out, host_to_host: end_to_end"}
+            if "device_resident_input" in res:
+                ratios["device_resident"] = res["device_resident_input"][f"T{t_b}"]["Gcells_snapshots_per_s"] / cpu_g
+                e2e = res["end_to_end"]
+                for name in [n for n in e2e if n.startswith("T")]:
+                    e2e[name]["speedup_vs_cpu_port"] = e2e[name]["Gcells_snapshots_per_s"] / cpu_g
+                ratios["host_to_host"] = max(e2e[n]["speedup_vs_cpu_port"] for n in e2e if n.startswith("T"))
+            res["gpu_over_cpu"] = ratios
         os.write(json_fd, (json.dumps(res) + "\n").encode())
     comm.barrier()
     parallel.shutdown()

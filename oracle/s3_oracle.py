@@ -37,6 +37,10 @@ def lib():
         _lib.s3o_sumsq.restype = C.c_double
         _lib.s3o_torch_inner_sum.restype = C.c_double
         _lib.s3o_numpy_pairwise_sum.restype = C.c_double
+        _lib.s3o_grid_create.restype = C.c_void_p
+        _lib.s3o_grid_create.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_double]
+        _lib.s3o_grid_destroy.argtypes = [C.c_void_p]
+        _lib.s3o_grid_destroy.restype = None
     return _lib
 
 
@@ -73,6 +77,51 @@ def idw_predict(pts, y, q, k):
     rc = lib().s3o_idw_predict(_p(pts), C.c_int64(n), d, _p(y), _p(q), C.c_int64(len(q)), k, _p(out))
     assert rc == 0, rc
     return out
+
+
+class GridIndex:
+    """the exact k-nearest query of ``knn`` / ``idw_predict`` / ``child_gain`` through a bucket grid (the oracle's stand-in
+    for the reference's kd-tree, s_cube.py:161-163): identical results, usable at the reference's problem sizes"""
+
+    def __init__(self, pts, occupancy=3.0):
+        self.pts = _f64(pts)
+        self.n, self.dim = self.pts.shape
+        self._h = C.c_void_p(lib().s3o_grid_create(_p(self.pts), C.c_int64(self.n), self.dim, C.c_double(occupancy)))
+        assert self._h.value, "s3o_grid_create failed"
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().s3o_grid_destroy(self._h)
+            self._h = C.c_void_p(0)
+
+    __del__ = close
+
+    def knn(self, q, k):
+        q = _f64(q)
+        idx = np.empty((len(q), k), dtype=np.int64)
+        dist = np.empty((len(q), k), dtype=np.float64)
+        rc = lib().s3o_grid_knn(self._h, _p(q), C.c_int64(len(q)), k, _p(idx), _p(dist))
+        assert rc == 0, rc
+        return idx, dist
+
+    def idw_predict(self, y, q, k):
+        y, q = _f64(y), _f64(q)
+        out = np.empty(len(q), dtype=np.float64)
+        rc = lib().s3o_grid_idw_predict(self._h, _p(y), _p(q), C.c_int64(len(q)), k, _p(out))
+        assert rc == 0, rc
+        return out
+
+    def child_gain(self, y, k, centers, level, width, gain0):
+        y, centers = _f64(y), _f64(centers)
+        level = np.ascontiguousarray(level, dtype=np.int32)
+        n, d = centers.shape
+        tab = level_factor_table(width, d)
+        metric = np.empty((n, 2 ** d + 1), dtype=np.float64)
+        gain = np.empty(n, dtype=np.float64)
+        rc = lib().s3o_grid_child_gain(self._h, _p(y), k, _p(centers), _p(level), C.c_int64(n), C.c_double(float(width)),
+                                       _p(tab), C.c_double(float(gain0)), _p(metric), _p(gain))
+        assert rc == 0, rc
+        return metric, gain
 
 
 def idw_weights(dist):

@@ -391,6 +391,20 @@ gather_rows_kernel(const char *__restrict__ src, int64_t src_pitch, const int32_
     }
 }
 
+// short rows (a few dozen pieces): one piece per thread, consecutive threads walk consecutive pieces of consecutive rows --
+// every lane busy whatever the row length (the kernel above gives a 100-byte row to a whole wavefront: 25 of 64 lanes)
+template <typename P>
+__global__ void __launch_bounds__(256)
+gather_short_rows_kernel(const char *__restrict__ src, int64_t src_pitch, const int32_t *__restrict__ ids, int64_t n,
+                         int pieces, char *__restrict__ dst, int64_t dst_pitch) {
+    const int64_t total = n * pieces;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / pieces;
+        const int j = (int)(i - row * pieces);
+        reinterpret_cast<P *>(dst + row * dst_pitch)[j] = reinterpret_cast<const P *>(src + (ids ? (int64_t)ids[row] : row) * src_pitch)[j];
+    }
+}
+
 __global__ void check_ids_kernel(const int32_t *__restrict__ ids, int64_t n, int32_t n_rows, int32_t *__restrict__ bad) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i < n && (ids[i] < 0 || ids[i] >= n_rows)) atomicExch(bad, 1);
@@ -486,6 +500,19 @@ int s3_gather_rows(const void *d_src, int64_t n_src_rows, int64_t row_bytes, int
     const bool wide = row_bytes % 16 == 0 && src_pitch_bytes % 16 == 0 && dst_pitch_bytes % 16 == 0 &&
                       reinterpret_cast<uintptr_t>(d_src) % 16 == 0 && reinterpret_cast<uintptr_t>(d_dst) % 16 == 0;
     const unsigned grid = s3::grid_for((n + 3) / 4, 1, 1 << 20);
+    if (row_bytes <= 1024) {                     // fewer pieces than lanes of a wavefront (or a few times as many)
+        if (wide) {
+            const int pieces = (int)(row_bytes / 16);
+            gather_short_rows_kernel<float4><<<s3::grid_for(n * pieces, 256, 1 << 16), 256, 0, st>>>(
+                static_cast<const char *>(d_src), src_pitch_bytes, d_ids, n, pieces, static_cast<char *>(d_dst), dst_pitch_bytes);
+        } else {
+            const int pieces = (int)(row_bytes / 4);
+            gather_short_rows_kernel<float><<<s3::grid_for(n * pieces, 256, 1 << 16), 256, 0, st>>>(
+                static_cast<const char *>(d_src), src_pitch_bytes, d_ids, n, pieces, static_cast<char *>(d_dst), dst_pitch_bytes);
+        }
+        S3_LAUNCH_CHECK();
+        return S3_OK;
+    }
     if (wide)
         gather_rows_kernel<float4><<<grid, 256, 0, st>>>(static_cast<const char *>(d_src), src_pitch_bytes, d_ids, n, row_bytes,
                                                          static_cast<char *>(d_dst), dst_pitch_bytes);

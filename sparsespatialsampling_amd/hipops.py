@@ -248,7 +248,8 @@ class InterpPlan:
 
     @staticmethod
     def supports(k, data):
-        return k <= 64 and InterpPlan._layout(data, k) is not None
+        """can a plan with ``k`` neighbours read ``data`` as it stands?  ``k = None``: by the 16-byte rule alone (every plan)"""
+        return (k is None or k <= 64) and InterpPlan._layout(data, k) is not None
 
     def close(self):
         if getattr(self, "_handle", None) is not None and self._handle.value:

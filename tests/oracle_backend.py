@@ -11,9 +11,11 @@ from sparsespatialsampling_amd import parallel
 
 
 class OracleTreeBackend:
+    """``grid=True``: the neighbour queries go through the oracle's bucket grid (same results as brute force; the CPU baseline
+    of bench.py at the reference's problem sizes)"""
     name = "oracle"
 
-    def __init__(self, vertices, target, k):
+    def __init__(self, vertices, target, k, grid=False):
         self.pts = np.ascontiguousarray(vertices, dtype=np.float64)
         self.y = np.ascontiguousarray(target, dtype=np.float64)
         self.k = int(k)
@@ -25,8 +27,11 @@ class OracleTreeBackend:
         self.gain = np.zeros(0)
         self.leaf = np.zeros(0, dtype=bool)
         self.comm = parallel.get_comm()      # N > 1 (gloo on CPU): same split / gather protocol as the HIP backend
+        self.grid = orc.GridIndex(self.pts) if grid else None
 
     def predict(self, q):
+        if self.grid is not None:
+            return self.grid.idw_predict(self.y, q, self.k)
         return orc.idw_predict(self.pts, self.y, q, self.k)
 
     def _grow(self, n):
@@ -54,8 +59,12 @@ class OracleTreeBackend:
         self.center[first:first + n_new] = ch.reshape(n_new, self.dim)
         self.level[first:first + n_new] = np.repeat(self.level[parents] + 1, self.nch)
         if e > b:
-            m, g = orc.child_gain(self.pts, self.y, self.k, self.center[first + b:first + e],
-                                  self.level[first + b:first + e], self.width, self.gain0)
+            if self.grid is not None:
+                m, g = self.grid.child_gain(self.y, self.k, self.center[first + b:first + e],
+                                            self.level[first + b:first + e], self.width, self.gain0)
+            else:
+                m, g = orc.child_gain(self.pts, self.y, self.k, self.center[first + b:first + e],
+                                      self.level[first + b:first + e], self.width, self.gain0)
             self.metric[first + b:first + e] = m[:, 0]
             self.gain[first + b:first + e] = g
         if self.comm.world > 1:
@@ -119,7 +128,8 @@ class OracleTreeBackend:
                     center=self.center[:n_cells].copy(), level=self.level[:n_cells].copy())
 
     def close(self):
-        pass
+        if self.grid is not None:
+            self.grid.close()
 
 
 def _mask_cylinder_spec(c, lv, width, spec, refine_mode, keep_inside):

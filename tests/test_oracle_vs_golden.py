@@ -139,6 +139,61 @@ def test_child_gain_trace(name, k):
     assert np.all(z["gain"][sel][~valid] == 0)
 
 
+@pytest.mark.parametrize("name,k", [("knncache_2d", 8), ("knncache_3d", 26)])
+def test_grid_knn_cache(name, k):
+    """the bucket-grid form of the query (the oracle's stand-in for the reference's kd-tree, used where brute force cannot run:
+    bench.py's CPU baselines at full size) against the same goldens as the brute-force form: bit-exact indices, distances,
+    weights, incl. the exact-hit rows and queries outside the cloud's bounding box"""
+    z = load(name)
+    for occ in (0.5, 3.0, 40.0):
+        grid = orc.GridIndex(z["coords"], occ)
+        for q, idx_ref, w_ref in ((z["centers"], z["idx_c"], z["w_c"]), (z["vertices"], z["idx_v"], z["w_v"])):
+            idx, dist = grid.knn(q, k)
+            assert np.array_equal(idx, idx_ref)
+            assert np.array_equal(orc.idw_weights(dist), w_ref)
+        idx, dist = grid.knn(z["centers"], k)
+        assert np.array_equal(dist, z["dist_c"])
+        grid.close()
+
+
+@pytest.mark.parametrize("name,k", [("predict_2d", 8), ("predict_3d", 26)])
+def test_grid_predict(name, k):
+    z = load(name)
+    grid = orc.GridIndex(z["x"])
+    assert np.array_equal(grid.idw_predict(z["y"], z["q"], k), z["pred"])
+    grid.close()
+
+
+@pytest.mark.parametrize("name,k", [("refine_2d_metric", 8), ("refine_3d_metric", 26), ("refine_3d_ncells_cone", 26)])
+def test_grid_child_gain_trace(name, k):
+    z = load(name)
+    x, y, _, _ = refine_inputs(name, SPEC)
+    width, gain0 = float(z["width"]), float(z["gain0"])
+    sel = np.arange(1, len(z["level"]))
+    grid = orc.GridIndex(x)
+    metric, gain = grid.child_gain(y, k, z["center"][sel], z["level"][sel], width, gain0)
+    assert np.array_equal(metric[:, 0], z["metric"][sel])
+    valid = z["state"][sel] != 2
+    assert np.array_equal(gain[valid], z["gain"][sel][valid])
+    grid.close()
+
+
+def test_grid_equals_brute_force_on_hard_clouds():
+    """ties (lattice points), clustered clouds, duplicate points, queries far outside, k = n"""
+    rng = np.random.default_rng(5)
+    for d in (2, 3):
+        lattice = np.stack(np.meshgrid(*[np.arange(9.0)] * d, indexing="ij"), -1).reshape(-1, d)
+        clustered = np.concatenate([rng.random((3000, d)), 0.5 + 1e-3 * rng.standard_normal((3000, d)), np.zeros((5, d))])
+        for pts in (lattice, clustered, rng.random((7, d))):
+            q = np.concatenate([pts[:50] + 0.0, rng.random((200, d)) * 3 - 1, lattice[:40] + 0.5])
+            for k in (1, 5, min(26, len(pts)), min(64, len(pts))):
+                grid = orc.GridIndex(pts, float(rng.choice([0.3, 2.0, 10.0])))
+                i0, d0 = orc.knn(pts, q, k)
+                i1, d1 = grid.knn(q, k)
+                assert np.array_equal(i0, i1) and np.array_equal(d0, d1)
+                grid.close()
+
+
 def test_child_centers_recurrence():
     """centre(child) = centre(parent) + dir * (0.25*width)/2^level(parent)  (s_cube.py:441) -- bit exact."""
     for name in ("refine_2d_metric", "refine_3d_metric"):

@@ -22,6 +22,11 @@ def oracle_backend(monkeypatch):
     monkeypatch.setattr(s_cube, "_make_backend", lambda v, t, k: OracleTreeBackend(v, t, k))
 
 
+@pytest.fixture
+def oracle_grid_backend(monkeypatch):
+    monkeypatch.setattr(s_cube, "_make_backend", lambda v, t, k: OracleTreeBackend(v, t, k, grid=True))
+
+
 def load(name):
     return np.load(os.path.join(G, name + ".npz"))
 
@@ -138,3 +143,9 @@ def test_c1_cylinder2d_full_size(oracle_backend):
     assert np.array_equal(tree.face_ids.numpy(), z["face_ids"])
     assert np.array_equal(np.array(tree._n_cells_log), z["n_cells_log"])
     np.testing.assert_allclose(np.array(tree._metric), z["metric_hist"], rtol=1e-12)
+
+
+@pytest.mark.parametrize("seed", [0, 5, 9])
+def test_refine_random_configurations_grid_oracle(oracle_grid_backend, seed):
+    """the same reference grids with the oracle's bucket-grid neighbour search (what bench.py times as the CPU port)"""
+    check_random_case(seed)

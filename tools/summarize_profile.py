@@ -6,7 +6,8 @@ src, dst = f"gpurun_out/prof_{tag}/{name}", f"profiles/{tag}/{name}"
 os.makedirs(dst, exist_ok=True)
 bench = json.loads([l for l in open(f"{src}/bench.json").read().splitlines() if l.startswith("{")][-1])
 stats = list(csv.DictReader(open(f"{src}/kernel_stats.csv")))
-dom = max((r for r in stats if "interp_planned" in r["Name"]), key=lambda r: float(r["TotalDurationNs"]))
+cand = [r for r in stats if "interp_planned" in r["Name"] and "permute" not in r["Name"]]
+dom = max(cand, key=lambda r: float(r["TotalDurationNs"]))
 short = dom["Name"].split("(")[0].split("::")[-1]
 
 
@@ -31,7 +32,8 @@ summary = {
     "algorithmic_bytes": bench["roofline"].get("algorithmic_bytes"),
     "traffic_over_algorithmic": (2.0 * fetch + write) * 1024.0 / bench["roofline"]["algorithmic_bytes"],
     "frac_of_peak_rocprof": bench["roofline"]["algorithmic_bytes"] / (float(dom["AverageNs"]) * 1e-9) / 8e12,
-    "workload": cfg["workload"], "workload_key": f"{cfg['workload'].split(' ')[0]}/T{cfg['t_batch']}",
+    "workload": cfg["workload"], "workload_key": f"{cfg['workload'].split(' ')[0]}/{cfg.get('shape_key', 'T%d' % cfg['t_batch'])}",
+    "device": bench.get("device"), "kernel_ms_hip_events_stats": {k: v for k, v in bench["roofline"].items() if k.startswith("kernel_ms")},
 }
 json.dump(summary, open(f"{dst}/summary.json", "w"), indent=1)
 shutil.copy(f"{src}/bench.json", f"{dst}/bench.json")

@@ -15,7 +15,7 @@ from sparsespatialsampling_amd.version import __version__  # noqa: F401
 
 _MODULES = {
     "s_cube": "s_cube", "export": "export", "data": "data", "const": "const", "version": "version",
-    "sparse_spatial_sampling": "sparse_spatial_sampling",
+    "sparse_spatial_sampling": "sparse_spatial_sampling", "utils": "utils",
     "geometry": "geometry", "geometry.geometry_base": "geometry.geometry_base",
     "geometry.cube_geometry": "geometry.cube_geometry", "geometry.sphere_geometry": "geometry.sphere_geometry",
     "geometry.cylinder_geometry": "geometry.cylinder_geometry", "geometry.coordinates_2d": "geometry.coordinates_2d",

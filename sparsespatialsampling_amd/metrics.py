@@ -66,3 +66,14 @@ def temporal_std(field: pt.Tensor, unbiased: bool = True) -> pt.Tensor:
 def temporal_mean(field: pt.Tensor) -> pt.Tensor:
     """``torch.mean(field, dim=-1)`` computed in float64 on the GPU"""
     return temporal_moments(field)[0]
+
+
+def tke_from_uprime2mean(prime2mean: pt.Tensor) -> pt.Tensor:
+    """turbulent kinetic energy ``0.5 * (u'u' + v'v' + w'w')`` from one snapshot of OpenFOAM's ``UPrime2Mean`` field -- the
+    metric of the reference's cylinder3D script, examples/s3_for_cylinder3D_Re3900.py:104
+    (``0.5 * prime2Mean[:, [0, 3, 5]].sum(-1)``; a ``volSymmTensorField`` stores [XX, XY, XZ, YY, YZ, ZZ]).  No time axis to
+    reduce: three loads and two additions per cell, evaluated where the tensor lives (host or device), in the tensor's own
+    precision, with the reference's operation order."""
+    if prime2mean.dim() != 2 or prime2mean.shape[1] != 6:
+        raise ValueError(f"expected a symmetric-tensor field [N, 6] (XX, XY, XZ, YY, YZ, ZZ), got {tuple(prime2mean.shape)}")
+    return 0.5 * prime2mean[:, [0, 3, 5]].sum(-1)

@@ -23,6 +23,37 @@ print("alias ok")
 """
 
 
+# the import lines of the reference's three example scripts that name the package (examples/s3_for_cylinder2D_Re100.py:27-30,
+# s3_for_OAT15_airfoil.py:18-21, s3_for_cylinder3D_Re3900.py:20-23) -- import lines only, nothing else of those files
+EXAMPLE_IMPORTS = """
+from sparseSpatialSampling.export import ExportData
+from sparseSpatialSampling.geometry import CubeGeometry, SphereGeometry
+from sparseSpatialSampling.sparse_spatial_sampling import SparseSpatialSampling
+from sparseSpatialSampling.utils import load_foam_data, export_openfoam_fields, write_svd_s_cube_to_file
+from sparseSpatialSampling.utils import write_svd_s_cube_to_file
+from sparseSpatialSampling.geometry import CubeGeometry, GeometryCoordinates2D
+from sparseSpatialSampling.geometry import CubeGeometry, CylinderGeometry3D
+from sparseSpatialSampling.utils import load_original_Foam_fields, write_svd_s_cube_to_file
+import sparsespatialsampling_amd.utils, sparsespatialsampling_amd.svd
+assert export_openfoam_fields is sparsespatialsampling_amd.utils.export_openfoam_fields
+assert write_svd_s_cube_to_file is sparsespatialsampling_amd.svd.write_svd_s_cube_to_file
+for reader, args in ((load_foam_data, ("case", [[0, 0], [1, 1]])), (load_original_Foam_fields, ("case", 2, [[0, 0], [1, 1]]))):
+    try:
+        reader(*args)
+    except ImportError as err:
+        assert "flowtorch" in str(err)
+    else:
+        raise AssertionError("the OpenFOAM readers are not part of this build")
+print("examples import ok")
+"""
+
+
+def test_import_blocks_of_the_reference_examples_run_under_the_alias():
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "compat"), ROOT]))
+    run = subprocess.run([sys.executable, "-c", EXAMPLE_IMPORTS], env=env, capture_output=True, text=True, timeout=300, cwd="/tmp")
+    assert run.returncode == 0 and "examples import ok" in run.stdout, run.stderr[-2000:]
+
+
 def test_reference_import_names_resolve_to_this_package():
     env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "compat"), ROOT]))
     run = subprocess.run([sys.executable, "-c", SCRIPT], env=env, capture_output=True, text=True, timeout=300, cwd="/tmp")

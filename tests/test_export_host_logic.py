@@ -318,3 +318,64 @@ def test_large_snapshots_take_the_raw_write_path_and_read_back(tmp_path):
         f.write_snapshots(["0.6"], "p_center", a[4:5].copy())
     with h5io.open_h5(path, "r") as f:
         assert np.array_equal(f.read("data/0.6/p_center"), a[4]) and np.array_equal(f.read("data/0.0/p_center"), a[0])
+
+
+def test_export_openfoam_fields_batches_like_the_reference(export_mod, tmp_path):
+    """the batching wrapper (reference utils.py:155-226): the reader is asked once for the field names / the write times that
+    were not given, every field goes through ``export()`` in batches of ``batch_size`` snapshots with the total announced,
+    a field the reader does not find is skipped, and the file equals the one a single call per field produces"""
+    from sparsespatialsampling_amd import utils
+    from sparsespatialsampling_amd.data import Dataloader
+    rng = np.random.default_rng(11)
+    n, t_all = 300, 7
+    times = [f"{0.1 * (i + 1):.1f}" for i in range(t_all)]
+    x = rng.random((n, 2))
+    store = {"p": rng.standard_normal((n, 1, t_all)).astype(np.float32), "U": rng.standard_normal((n, 3, t_all)).astype(np.float32)}
+    calls = []
+
+    def reader(path, n_dims, bounds, field_names=None, write_times=None, get_field_names_and_times=False):
+        calls.append((field_names, None if write_times is None else tuple(write_times), get_field_names_and_times))
+        assert path == "case" and n_dims == 2 and bounds == [[0, 0], [1, 1]]
+        if get_field_names_and_times:
+            return list(times), ["p", "U", "ghost"]
+        if field_names not in store:
+            return None, None
+        cols = [times.index(t) for t in write_times]
+        return pt.from_numpy(x), pt.from_numpy(store[field_names][:, :, cols])
+
+    def run(name, batch_size, fields):
+        sc = _scube(tmp_path / name, d=2, nc=40)
+        sc.metric = pt.from_numpy(np.linspace(0.0, 1.0, n))
+        os.makedirs(sc.save_path, exist_ok=True)
+        ex = export_mod.ExportData(sc, write_times=None)
+        utils.export_openfoam_fields(ex, "case", [[0, 0], [1, 1]], batch_size=batch_size, fields=fields, loader=reader)
+        return sc
+
+    calls.clear()
+    sc = run("batched", 3, None)
+    meta = [c for c in calls if c[2]]
+    assert len(meta) == 2                                       # once for the field names, once for the write times
+    loads = [c for c in calls if not c[2]]
+    assert [c[1] for c in loads if c[0] == "p"] == [tuple(times[0:3]), tuple(times[3:6]), tuple(times[6:7])]
+    assert [c[0] for c in loads].count("ghost") == 3            # asked for, not found, skipped
+    one = run("single", None, ["p", "U"])
+    a = dump(os.path.join(sc.save_path, sc.save_name + ".h5"))
+    b = dump(os.path.join(one.save_path, one.save_name + ".h5"))
+    assert a.keys() == b.keys() and all(np.array_equal(a[k], b[k]) for k in a)
+    loaded = Dataloader(sc.save_path, sc.save_name + ".h5")
+    assert sorted(loaded.write_times, key=float) == times and loaded.load_snapshot("U", times).shape[-1] == t_all
+    with pytest.raises(ValueError):
+        utils.export_openfoam_fields(export_mod.ExportData(_scube(tmp_path / "bad"), write_times=times), "case", [[0, 0], [1, 1]],
+                                     batch_size=0, fields="p", loader=reader)
+    with pytest.raises(ImportError, match="flowtorch"):
+        utils.export_openfoam_fields(export_mod.ExportData(_scube(tmp_path / "nofoam"), write_times=times), "case",
+                                     [[0, 0], [1, 1]], fields="p")
+
+
+def test_tke_metric_formula():
+    """examples/s3_for_cylinder3D_Re3900.py:104"""
+    from sparsespatialsampling_amd import metrics
+    t = pt.from_numpy(np.random.default_rng(2).random((50, 6)))
+    assert pt.equal(metrics.tke_from_uprime2mean(t), 0.5 * t[:, [0, 3, 5]].sum(-1))
+    with pytest.raises(ValueError):
+        metrics.tke_from_uprime2mean(t[:, :5])

@@ -462,6 +462,37 @@ def test_full_size_c3_properties():
     both.copy_(a.double() + 2 * b.double())
     assert pt.allclose(plan.interp(w, both), fa + 2 * fb, rtol=1e-12, atol=1e-12)
     assert pt.equal(fa, hipops.interp(w, idx, a.contiguous()).reshape(nc, t))        # same arithmetic as the direct kernel
+    plan.close()
+    del a, b, const, both, fa, fb
+
+    # the layout bench.py times: only the referenced rows resident, in Hilbert order, pitch of padded_rows,
+    # 1000 snapshots -- against the oracle on a slice of 10^4 cells, and the batch lengths of roofline_batches (25 scalar
+    # snapshots: 100-byte ragged rows through the persistent kernel; 3 x 25: 300-byte rows)
+    from oracle import s3_oracle as orc
+    used, remap = hipops.referenced_rows([idx], len(x), coords=x)
+    n_rows = int(used.numel())
+    assert n_rows == 2_430_607
+    idx_c = idx.clone()
+    hipops.remap_indices(idx_c, remap)
+    plan = hipops.InterpPlan(idx_c, n_rows, centers)
+    plan.set_weights(w)
+    rng = np.random.default_rng(8)
+    sel = np.sort(rng.choice(nc, 10_000, replace=False))
+    i_sel, w_sel = idx_c[pt.from_numpy(sel).cuda()].cpu().numpy(), w[pt.from_numpy(sel).cuda()].cpu().numpy()
+    rows_sel, inv = np.unique(i_sel, return_inverse=True)
+    for row_len in (1000, 25, 75):
+        data = hipops.padded_rows(n_rows, row_len, pt.float32, "cuda")
+        data.normal_(generator=pt.Generator(device="cuda").manual_seed(row_len))
+        assert data.stride(0) * 4 % 128 == 0 and (row_len != 1000 or data.stride(0) == 35 * 32)
+        got = plan.interp(w, data)
+        sub = data[pt.from_numpy(rows_sel).cuda().long()].contiguous().cpu().numpy().reshape(len(rows_sel), 1, row_len)
+        ref = orc.interp(w_sel, inv.reshape(i_sel.shape), sub).reshape(len(sel), row_len)
+        out = got[pt.from_numpy(sel).cuda()].cpu().numpy()
+        assert np.abs(out - ref).max() <= 1e-13 * np.abs(ref).max()
+        if row_len != 1000:                       # the whole batch against the direct gather kernel, bit for bit
+            assert pt.equal(got, hipops.interp(w, idx_c, data.contiguous()))
+        del data, got
+    plan.close()
 
 
 @pytest.mark.parametrize("seed", [0, 1, 2, 4, 5, 6, 7, 8, 9, 10, 11])

@@ -108,6 +108,18 @@ int s3_make_children(double *d_center /*[cap,dim]*/, int32_t *d_level /*[cap]*/,
 int s3_child_gain(const s3_knn *knn, int k, const double *d_center, const int32_t *d_level, int64_t first, int64_t n,
                   int dim, double width, const double *d_level_factor, double gain0, double *d_metric /*[cap]*/,
                   double *d_gain /*[cap]*/, double *d_scratch, s3_stream stream);
+/* the same with the predictions of a cell's 2^dim candidate child centres kept in d_child_metric[cap][2^dim]: the centre of
+ * a new cell is candidate child c of its parent, a point the parent's call predicted already (same coordinates, same
+ * deterministic search -- the reference predicts it a second time, s_cube.py:221-233, and obtains the same number), so with
+ * d_parents given only the 2^dim child points of a new cell are searched (8 of 9 queries in 3-D) and its centre's value is
+ * d_child_metric[parent][c].  The n cells first..first+n-1 are children number parents_offset.. of the ORDERED parents
+ * d_parents[] (2^dim consecutive cells per parent, as s3_make_children creates them).  d_parents == NULL: all 2^dim + 1
+ * points are searched (cells whose parent has no entry: the root).  Either way the children's values of the n cells are
+ * stored in d_child_metric. */
+int s3_child_gain_reuse(const s3_knn *knn, int k, const double *d_center, const int32_t *d_level, int64_t first, int64_t n,
+                        int dim, double width, const double *d_level_factor, double gain0, double *d_metric /*[cap]*/,
+                        double *d_gain /*[cap]*/, double *d_scratch, const int32_t *d_parents /*or NULL*/,
+                        int64_t parents_offset, double *d_child_metric /*[cap][2^dim]*/, s3_stream stream);
 
 /* a12: geometry predicates on the nodes of the listed cells (d_cells == NULL: ids first..first+n-1).  Each call ORs
  * its verdict into d_invalid[n] (zero it first): GeometryObject._apply_mask policy, geometry_base.py:40-76.

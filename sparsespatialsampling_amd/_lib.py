@@ -55,6 +55,8 @@ HIP_SIGNATURES = {
     "s3_idw_predict": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_vp]),
     "s3_make_children": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_dbl, c_vp]),
     "s3_child_gain": (c_int, [c_vp, c_int, c_vp, c_vp, c_i64, c_i64, c_int, c_dbl, c_vp, c_dbl, c_vp, c_vp, c_vp, c_vp]),
+    "s3_child_gain_reuse": (c_int, [c_vp, c_int, c_vp, c_vp, c_i64, c_i64, c_int, c_dbl, c_vp, c_dbl, c_vp, c_vp, c_vp, c_vp,
+                                    c_i64, c_vp, c_vp]),
     "s3_mask_box": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_dbl, c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
     "s3_mask_sphere": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_dbl, c_vp, c_dbl, c_int, c_int, c_vp, c_vp]),
     "s3_mask_cylinder": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_dbl, c_vp, c_vp, c_dbl, c_dbl, c_dbl, c_int, c_int,

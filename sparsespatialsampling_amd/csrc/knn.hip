@@ -588,19 +588,25 @@ idw_predict_kernel(Grid<DIM> g, const double *__restrict__ pts, const int32_t *_
     yhat[i] = idw_from_list(b, y);
 }
 
-// a3+a4 first half: query t = (cell i, point j) with j = 0 the cell centre and j = 1..2^DIM its candidate children
-template <int DIM>
+// a3+a4 first half: query t = (cell i, point j) with j = 0 the cell centre and j = 1..2^DIM its candidate children.
+// REUSE: the centre of new cell first + i IS candidate child (i mod 2^DIM) of its parent, a point whose metric was
+// predicted (by this kernel, from the same coordinates: make_children_kernel and the expression below are the same) when
+// the parent was created -- the reference predicts it again (s_cube.py:221-233) and gets the same number, so only the
+// 2^DIM child points are searched here and the centre's value is taken from child_metric[parent].  Either way the child
+// values of every new cell are kept in child_metric[cell] for the day the cell is refined.
+template <int DIM, bool REUSE>
 __global__ void __launch_bounds__(KNN_BLOCK)
 child_metric_kernel(Grid<DIM> g, const double *__restrict__ pts, const int32_t *__restrict__ orig,
                     const int32_t *__restrict__ cs, const double *__restrict__ y, const double *__restrict__ center,
                     const int32_t *__restrict__ level, int64_t first, int64_t n, double quarter_width, int k,
-                    double *__restrict__ metric_all) {
-    constexpr int NQ = (1 << DIM) + 1;
+                    double *__restrict__ metric_all, const int32_t *__restrict__ parents, int64_t parents_offset,
+                    double *__restrict__ child_metric) {
+    constexpr int NCH = 1 << DIM, NQ = NCH + 1, PER = REUSE ? NCH : NQ;
     extern __shared__ double lds[];
     int64_t t = blockIdx.x * (int64_t)KNN_BLOCK + threadIdx.x;
-    if (t >= n * NQ) return;
-    int64_t i = t / NQ;
-    int jq = (int)(t - i * NQ);
+    if (t >= n * PER) return;
+    int64_t i = t / PER;
+    int jq = (int)(t - i * PER) + (REUSE ? 1 : 0);
     int64_t cell = first + i;
     double q[DIM];
     double off = cell_offset(quarter_width, level[cell]);
@@ -611,7 +617,13 @@ child_metric_kernel(Grid<DIM> g, const double *__restrict__ pts, const int32_t *
     }
     KBest b = kb_init(lds, k);
     knn_search<DIM>(g, pts, orig, cs, q, b);
-    metric_all[t] = idw_from_list(b, y);
+    const double m = idw_from_list(b, y);
+    metric_all[i * NQ + jq] = m;
+    if (child_metric != nullptr && jq > 0) child_metric[cell * NCH + jq - 1] = m;
+    if (REUSE && jq == 1) {
+        const int64_t ii = parents_offset + i;               // position of the cell among the batch's children
+        metric_all[i * NQ] = child_metric[(int64_t)parents[ii / NCH] * NCH + (ii % NCH)];
+    }
 }
 
 // summation order of torch's CPU sum over a contiguous inner dimension of n <= 64 doubles (ATen SumKernel.cpp,
@@ -925,32 +937,53 @@ int s3_idw_predict(const s3_knn *knn, const double *d_q, int64_t nq, int k, doub
     return S3_OK;
 }
 
-int s3_child_gain(const s3_knn *knn, int k, const double *d_center, const int32_t *d_level, int64_t first, int64_t n,
-                  int dim, double width, const double *d_level_factor, double gain0, double *d_metric, double *d_gain,
-                  double *d_scratch, s3_stream stream) {
-    if (int rc = check_query_args(knn, d_center, n, k, "s3_child_gain")) return rc;
-    S3_REQUIRE(knn->y != nullptr, "s3_child_gain: call s3_knn_set_values first");
-    S3_REQUIRE(dim == knn->dim, "s3_child_gain: dim %d does not match the index (%d)", dim, knn->dim);
-    S3_REQUIRE(first >= 0 && n >= 0, "s3_child_gain: bad range");
-    S3_REQUIRE(n == 0 || (d_level && d_level_factor && d_metric && d_gain && d_scratch), "s3_child_gain: null array");
-    S3_REQUIRE(gain0 != 0.0, "s3_child_gain: gain0 must be non-zero");
+static int child_gain_impl(const s3_knn *knn, int k, const double *d_center, const int32_t *d_level, int64_t first, int64_t n,
+                           int dim, double width, const double *d_level_factor, double gain0, double *d_metric, double *d_gain,
+                           double *d_scratch, const int32_t *d_parents, int64_t parents_offset, double *d_child_metric,
+                           s3_stream stream, const char *who) {
+    if (int rc = check_query_args(knn, d_center, n, k, who)) return rc;
+    S3_REQUIRE(knn->y != nullptr, "%s: call s3_knn_set_values first", who);
+    S3_REQUIRE(dim == knn->dim, "%s: dim %d does not match the index (%d)", who, dim, knn->dim);
+    S3_REQUIRE(first >= 0 && n >= 0 && parents_offset >= 0, "%s: bad range", who);
+    S3_REQUIRE(n == 0 || (d_level && d_level_factor && d_metric && d_gain && d_scratch), "%s: null array", who);
+    S3_REQUIRE(gain0 != 0.0, "%s: gain0 must be non-zero", who);
+    S3_REQUIRE(d_parents == nullptr || d_child_metric != nullptr, "%s: parents given without the child-metric table", who);
     if (n == 0) return S3_OK;
     hipStream_t st = as_stream(stream);
     size_t lds = knn_lds_bytes(k);
     const double qw = 0.25 * width;
+#define S3_CHILD_METRIC(DIM, REUSE, PER)                                                                                      \
+    child_metric_kernel<DIM, REUSE><<<grid_for(n * (PER), KNN_BLOCK), KNN_BLOCK, lds, st>>>(                                   \
+        make_grid<DIM>(knn), knn->pts, knn->orig, knn->cell_start, knn->y, d_center, d_level, first, n, qw, k, d_scratch,     \
+        d_parents, parents_offset, d_child_metric)
     if (dim == 2) {
-        child_metric_kernel<2><<<grid_for(n * 5, KNN_BLOCK), KNN_BLOCK, lds, st>>>(
-            make_grid<2>(knn), knn->pts, knn->orig, knn->cell_start, knn->y, d_center, d_level, first, n, qw, k, d_scratch);
+        if (d_parents) S3_CHILD_METRIC(2, true, 4); else S3_CHILD_METRIC(2, false, 5);
         child_gain_kernel<2><<<grid_for(n, 256), 256, 0, st>>>(d_scratch, d_level, first, n, d_level_factor, gain0,
                                                               d_metric, d_gain);
     } else {
-        child_metric_kernel<3><<<grid_for(n * 9, KNN_BLOCK), KNN_BLOCK, lds, st>>>(
-            make_grid<3>(knn), knn->pts, knn->orig, knn->cell_start, knn->y, d_center, d_level, first, n, qw, k, d_scratch);
+        if (d_parents) S3_CHILD_METRIC(3, true, 8); else S3_CHILD_METRIC(3, false, 9);
         child_gain_kernel<3><<<grid_for(n, 256), 256, 0, st>>>(d_scratch, d_level, first, n, d_level_factor, gain0,
                                                               d_metric, d_gain);
     }
+#undef S3_CHILD_METRIC
     S3_LAUNCH_CHECK();
     return S3_OK;
+}
+
+int s3_child_gain(const s3_knn *knn, int k, const double *d_center, const int32_t *d_level, int64_t first, int64_t n,
+                  int dim, double width, const double *d_level_factor, double gain0, double *d_metric, double *d_gain,
+                  double *d_scratch, s3_stream stream) {
+    return child_gain_impl(knn, k, d_center, d_level, first, n, dim, width, d_level_factor, gain0, d_metric, d_gain, d_scratch,
+                           nullptr, 0, nullptr, stream, "s3_child_gain");
+}
+
+int s3_child_gain_reuse(const s3_knn *knn, int k, const double *d_center, const int32_t *d_level, int64_t first, int64_t n,
+                        int dim, double width, const double *d_level_factor, double gain0, double *d_metric, double *d_gain,
+                        double *d_scratch, const int32_t *d_parents, int64_t parents_offset, double *d_child_metric,
+                        s3_stream stream) {
+    S3_REQUIRE(d_child_metric != nullptr, "s3_child_gain_reuse: null child-metric table");
+    return child_gain_impl(knn, k, d_center, d_level, first, n, dim, width, d_level_factor, gain0, d_metric, d_gain, d_scratch,
+                           d_parents, parents_offset, d_child_metric, stream, "s3_child_gain_reuse");
 }
 
 int s3_idw_weights(const double *d_dist, int64_t nc, int k, double *d_w, s3_stream stream) {

@@ -437,6 +437,17 @@ def child_gain(knn, k, center, level, first, n, width, level_factor, gain0, metr
                                        _ptr(scratch), _stream()), "s3_child_gain")
 
 
+def child_gain_reuse(knn, k, center, level, first, n, width, level_factor, gain0, metric, gain, scratch, parents,
+                     parents_offset, child_metric):
+    """``child_gain`` that keeps every cell's child predictions in ``child_metric`` [cap, 2^d] and, with ``parents`` (the
+    batch's ordered parent ids), takes a new cell's centre value from its parent's entry instead of searching again"""
+    dim = int(center.shape[1])
+    check(_lib.hip_lib().s3_child_gain_reuse(knn.handle, int(k), _ptr(center), _ptr(level), int(first), int(n), dim,
+                                             float(width), _ptr(level_factor), float(gain0), _ptr(metric), _ptr(gain),
+                                             _ptr(scratch), _ptr(parents), int(parents_offset), _ptr(child_metric), _stream()),
+          "s3_child_gain_reuse")
+
+
 def mask_box(center, level, cells, first, n, width, lo, hi, refine_mode, keep_inside, invalid):
     dim = int(center.shape[1])
     lo, hi = _host_f64(lo), _host_f64(hi)

@@ -391,7 +391,7 @@ def main():
     if world > 1 and args.shard == "cells":
         # this rank's share of the generated leaf cells: a spatially compact blob, cut so that every rank moves the same
         # number of bytes per snapshot (parallel.LeafShards, what ExportData does with several ranks)
-        shards = parallel.LeafShards(knn, centers, k, rank, world)
+        shards = parallel.LeafShards(knn, centers, k, rank, world, comm)
         my_centers, shard_counts = np.ascontiguousarray(centers[shards.mine]), shards.counts
         del shards
     idx, dist_ = knn.query(my_centers, k)

@@ -220,6 +220,11 @@ int s3_interp_plan_info(const s3_interp_plan *plan, int64_t *h_n_tiles, int64_t 
  * the plan's processing order (position -> cell id); rank r owns the cells d_order[h_cuts[r] .. h_cuts[r+1]).
  * h_cuts: world + 1 entries on the host. */
 int s3_interp_plan_partition(const s3_interp_plan *plan, int world, int32_t *d_order, int64_t *h_cuts, s3_stream stream);
+/* the same cost, cumulated along the plan's processing order and sampled at n_samples + 1 equally spaced cell positions
+ * i * nc / n_samples (h_out[0] = 0, h_out[n_samples] = total; linear inside a tile): what a rank that holds the plan of ONE
+ * stretch of the Hilbert curve publishes so that all ranks can cut the curve into stretches of equal cost without anybody
+ * building the table of all cells (parallel.LeafShards) */
+int s3_interp_plan_cost_profile(const s3_interp_plan *plan, int n_samples, double *h_out /*[n_samples + 1]*/, s3_stream stream);
 /* in_stride: elements between consecutive source rows of d_data (>= row_len; 0 = row_len).  Rows padded to a multiple
  * of 128 bytes keep every staged segment on one cache line. */
 /* the weights of the table, [nc,k] in the caller's cell order, are kept inside the plan in tile order (one contiguous
@@ -276,12 +281,20 @@ int s3_gather_rows(const void *d_src, int64_t n_src_rows, int64_t row_bytes, int
  * Bootstrap: rank 0 calls s3_comm_unique_id and hands the 128 bytes to the other ranks by any host channel. */
 typedef struct s3_comm s3_comm;
 #define S3_COMM_ID_BYTES 128
+/* 1 when the RCCL library can be loaded in this process (creates nothing, never blocks): ranks exchange this BEFORE anybody
+ * enters s3_comm_init, whose ncclCommInitRank is a collective without a timeout */
+int s3_comm_available(void);
 int s3_comm_unique_id(void *h_id_out, size_t bytes /* >= S3_COMM_ID_BYTES */);
 int s3_comm_init(const void *h_id, size_t bytes, int rank, int world, s3_comm **out);   /* the current device is used */
 void s3_comm_destroy(s3_comm *comm);
 int s3_comm_rank(const s3_comm *comm, int *rank, int *world);
 int s3_comm_allgather_inplace(s3_comm *comm, void *const *d_arrays, const size_t *bytes_per_rank, int n_arrays,
                               s3_stream stream);
+/* every rank's block to ONE rank (the one that writes the export's file): rank r sends bytes_per_rank[r] bytes from d_send,
+ * `root` receives the blocks in rank order into d_recv (d_recv may be NULL on the other ranks).  Point-to-point sends in one
+ * group: every byte crosses xGMI once, where an all-gather would deliver all blocks to every rank. */
+int s3_comm_gather_to_root(s3_comm *comm, const void *d_send, void *d_recv, const size_t *bytes_per_rank /*[world]*/, int root,
+                           s3_stream stream);
 int s3_comm_allreduce_f64(s3_comm *comm, double *d_buf, int64_t n, int op /*0 sum, 1 max*/, s3_stream stream);
 /* captured-metric numerator in a form that does not depend on how the work is split: partial[b] = sum of metric^2 over the
  * leaf cells of the 1024-cell block b (fixed reduction tree inside a block), for blocks [block_begin, block_end);

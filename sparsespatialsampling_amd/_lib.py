@@ -81,6 +81,9 @@ HIP_SIGNATURES = {
     "s3_interp_planned": (c_int, [c_vp, c_vp, c_vp, c_int, c_i64, c_i64, c_vp, c_vp]),
     "s3_interp_plan_set_source_ids": (c_int, [c_vp, c_vp, c_i64, c_vp]),
     "s3_interp_planned_src": (c_int, [c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_vp, c_vp]),
+    "s3_comm_available": (c_int, []),
+    "s3_comm_gather_to_root": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_vp]),
+    "s3_interp_plan_cost_profile": (c_int, [c_vp, c_int, c_vp, c_vp]),
     "s3_comm_unique_id": (c_int, [c_vp, C.c_size_t]),
     "s3_comm_init": (c_int, [c_vp, C.c_size_t, c_int, c_int, C.POINTER(c_vp)]),
     "s3_comm_destroy": (None, [c_vp]),

@@ -13,7 +13,20 @@
 #include "common.h"
 
 #include <dlfcn.h>
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#else
+// An image without the RCCL headers still builds the library (single-GPU use needs none of this); the few types and
+// constants of the calls below, as the RCCL / NCCL ABI defines them.  The functions are looked up at run time either way.
+extern "C" {
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclUint8 = 1, ncclInt32 = 2, ncclUint32 = 3, ncclInt64 = 4, ncclUint64 = 5, ncclFloat16 = 6,
+               ncclFloat32 = 7, ncclFloat64 = 8, ncclDouble = 8 } ncclDataType_t;
+typedef enum { ncclSum = 0, ncclProd = 1, ncclMax = 2, ncclMin = 3 } ncclRedOp_t;
+}
+#endif
 
 #include <cstring>
 
@@ -31,6 +44,8 @@ struct Rccl {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
@@ -57,6 +72,8 @@ Rccl *rccl() {
     r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
     r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
     r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
+    r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
+    r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
     r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
     r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
@@ -79,6 +96,10 @@ Rccl *rccl() {
 }  // namespace
 
 extern "C" {
+
+// 1 when librccl can be loaded in this process (no communicator is created, nothing blocks): what the ranks tell each other
+// BEFORE anybody enters ncclCommInitRank, a collective without a timeout
+int s3_comm_available(void) { return rccl() != nullptr ? 1 : 0; }
 
 int s3_comm_unique_id(void *id_out, size_t bytes) {
     Rccl *R = rccl();
@@ -142,6 +163,49 @@ int s3_comm_allgather_inplace(s3_comm *c, void *const *d_arrays, const size_t *b
         if (r != ncclSuccess) {
             (void)R->GroupEnd();
             s3::set_error("ncclAllGather failed: %s", R->GetErrorString(r));
+            return S3_EHIP;
+        }
+    }
+    S3_RCCL(R->GroupEnd());
+    return S3_OK;
+}
+
+// Every rank's block to ONE rank: rank r sends bytes_per_rank[r] bytes from d_send; `root` receives them one after the other
+// (rank order) into d_recv -- its own block is copied on the device.  One group of point-to-point calls: the bytes cross
+// xGMI once, to the rank that writes the file, where an all-gather would deliver all of them to every rank.
+int s3_comm_gather_to_root(s3_comm *c, const void *d_send, void *d_recv, const size_t *bytes_per_rank, int root, s3_stream stream) {
+    S3_REQUIRE(c != nullptr && bytes_per_rank != nullptr && root >= 0 && root < c->world, "s3_comm_gather_to_root: bad arguments");
+    Rccl *R = rccl();
+    S3_REQUIRE(R != nullptr, "s3_comm: librccl.so.1 could not be loaded");
+    const size_t mine = bytes_per_rank[c->rank];
+    S3_REQUIRE(mine == 0 || d_send != nullptr, "s3_comm_gather_to_root: null send buffer");
+    S3_REQUIRE(c->rank != root || d_recv != nullptr, "s3_comm_gather_to_root: the root needs a receive buffer");
+    hipStream_t st = s3::as_stream(stream);
+    if (c->rank != root) {
+        if (mine) S3_RCCL(R->Send(d_send, mine, ncclUint8, root, c->comm, st));
+        return S3_OK;
+    }
+    S3_RCCL(R->GroupStart());
+    size_t off = 0;
+    for (int r = 0; r < c->world; ++r) {
+        char *dst = static_cast<char *>(d_recv) + off;
+        off += bytes_per_rank[r];
+        if (bytes_per_rank[r] == 0) continue;
+        if (r == root) {
+            if (dst != d_send) {
+                const hipError_t e = hipMemcpyAsync(dst, d_send, mine, hipMemcpyDeviceToDevice, st);
+                if (e != hipSuccess) {
+                    (void)R->GroupEnd();
+                    s3::set_error("s3_comm_gather_to_root: device copy failed: %s", hipGetErrorString(e));
+                    return S3_EHIP;
+                }
+            }
+            continue;
+        }
+        const ncclResult_t rr = R->Recv(dst, bytes_per_rank[r], ncclUint8, r, c->comm, st);
+        if (rr != ncclSuccess) {
+            (void)R->GroupEnd();
+            s3::set_error("ncclRecv failed: %s", R->GetErrorString(rr));
             return S3_EHIP;
         }
     }

@@ -1084,24 +1084,33 @@ int s3_interp_plan_info(const s3_interp_plan *p, int64_t *n_tiles, int64_t *tota
 // plan's processing order (d_order, a copy of `perm`): rank r owns the cells d_order[h_cuts[r] .. h_cuts[r+1]).
 // Equal cell counts in creation order (the survey's first suggestion) leave the slowest of 8 ranks with 1.8x the
 // mean time on the cylinder3D grid: the early, coarse cells reference 26 distinct rows each, the fine ones share theirs.
-int s3_interp_plan_partition(const s3_interp_plan *p, int world, int32_t *d_order, int64_t *h_cuts, s3_stream stream) try {
-    S3_REQUIRE(p != nullptr && h_cuts != nullptr, "s3_interp_plan_partition: null argument");
-    S3_REQUIRE(world >= 1, "s3_interp_plan_partition: world=%d", world);
-    hipStream_t st = as_stream(stream);
+// cost of tile t per snapshot: 4 bytes per staged row; per cell 8 bytes of output + the accumulate phase of its k neighbours,
+// which is not hidden behind the row traffic in tiles full of cells: a fit of launch times of 15 shards of the cylinder3D
+// grid (tools/shard_probe.py: t = a * rows + b * cells + c) gives b / a = 3.6 at k = 26
+static int plan_tile_costs(const s3_interp_plan *p, hipStream_t st, int32_t *d_order, std::vector<int32_t> &cb, std::vector<double> &acc) {
     const size_t nt = (size_t)p->n_tiles;
-    std::vector<int32_t> cb(nt + 1), rb(nt + 1);
+    std::vector<int32_t> rb(nt + 1);
+    cb.assign(nt + 1, 0);
     S3_HIP_CHECK(hipMemcpyAsync(cb.data(), p->tile_cell_begin, sizeof(int32_t) * (nt + 1), hipMemcpyDeviceToHost, st));
     S3_HIP_CHECK(hipMemcpyAsync(rb.data(), p->tile_row_begin, sizeof(int32_t) * (nt + 1), hipMemcpyDeviceToHost, st));
     if (d_order)
         S3_HIP_CHECK(hipMemcpyAsync(d_order, p->perm, sizeof(int32_t) * (size_t)p->nc, hipMemcpyDeviceToDevice, st));
     S3_HIP_CHECK(hipStreamSynchronize(st));
-    // per snapshot: 4 bytes per staged row; per cell 8 bytes of output + the accumulate phase of its k neighbours, which
-    // is not hidden behind the row traffic in tiles full of cells: a fit of launch times of 15 shards of the cylinder3D
-    // grid (tools/shard_probe.py: t = a * rows + b * cells + c) gives b / a = 3.6 at k = 26
     const double ROW = 4.0, CELL = 8.0 + 6.0 * p->k / 26.0;
-    std::vector<double> acc(nt + 1, 0.0);
+    acc.assign(nt + 1, 0.0);
     for (size_t t = 0; t < nt; ++t)
         acc[t + 1] = acc[t] + ROW * (rb[t + 1] - rb[t]) + CELL * (cb[t + 1] - cb[t]);
+    return S3_OK;
+}
+
+int s3_interp_plan_partition(const s3_interp_plan *p, int world, int32_t *d_order, int64_t *h_cuts, s3_stream stream) try {
+    S3_REQUIRE(p != nullptr && h_cuts != nullptr, "s3_interp_plan_partition: null argument");
+    S3_REQUIRE(world >= 1, "s3_interp_plan_partition: world=%d", world);
+    const size_t nt = (size_t)p->n_tiles;
+    std::vector<int32_t> cb;
+    std::vector<double> acc;
+    const int rc = plan_tile_costs(p, as_stream(stream), d_order, cb, acc);
+    if (rc != S3_OK) return rc;
     h_cuts[0] = 0;
     size_t t = 0;
     for (int r = 1; r < world; ++r) {
@@ -1114,6 +1123,29 @@ int s3_interp_plan_partition(const s3_interp_plan *p, int world, int32_t *d_orde
     return S3_OK;
 } catch (const std::exception &e) {
     s3::set_error("s3_interp_plan_partition: %s", e.what());
+    return S3_ENOMEM;
+}
+
+int s3_interp_plan_cost_profile(const s3_interp_plan *p, int n_samples, double *h_out, s3_stream stream) try {
+    S3_REQUIRE(p != nullptr && h_out != nullptr && n_samples >= 1, "s3_interp_plan_cost_profile: bad arguments");
+    const size_t nt = (size_t)p->n_tiles;
+    std::vector<int32_t> cb;
+    std::vector<double> acc;
+    const int rc = plan_tile_costs(p, as_stream(stream), nullptr, cb, acc);
+    if (rc != S3_OK) return rc;
+    size_t t = 0;
+    for (int i = 0; i <= n_samples; ++i) {
+        const double pos = (double)p->nc * i / n_samples;                      // cell position along the processing order
+        while (t + 1 < nt && (double)cb[t + 1] <= pos) ++t;
+        const double span = (double)(cb[t + 1] - cb[t]);
+        const double f = span > 0 ? std::min(1.0, std::max(0.0, (pos - cb[t]) / span)) : 1.0;
+        h_out[i] = acc[t] + f * (acc[t + 1] - acc[t]);
+    }
+    h_out[0] = 0.0;
+    h_out[n_samples] = acc[nt];
+    return S3_OK;
+} catch (const std::exception &e) {
+    s3::set_error("s3_interp_plan_cost_profile: %s", e.what());
     return S3_ENOMEM;
 }
 

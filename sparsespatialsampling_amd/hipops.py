@@ -221,6 +221,14 @@ class InterpPlan:
               "s3_interp_plan_partition")
         return order, [int(c) for c in cuts]
 
+    def cost_profile(self, n_samples):
+        """cumulative per-snapshot cost of the plan's tiles along its processing order at ``n_samples + 1`` equally spaced
+        cell positions (s3_interp_plan_cost_profile) -> float64 numpy array"""
+        out = np.zeros(int(n_samples) + 1, dtype=np.float64)
+        check(_lib.hip_lib().s3_interp_plan_cost_profile(self._handle, int(n_samples), out.ctypes.data_as(C.c_void_p), _stream()),
+              "s3_interp_plan_cost_profile")
+        return out
+
     @staticmethod
     def _layout(data, k=None):
         """(row_len, in_stride) of a data matrix the planned kernels can read, None otherwise.  Every kernel takes rows

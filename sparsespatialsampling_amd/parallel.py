@@ -2,9 +2,11 @@
 Multi-GPU layer of the S^3 path: one process per GPU, the collectives run inside libs3hip.so on RCCL over xGMI
 (``s3_comm_*``, csrc/comm.hip).  SURVEY.md 8(e):
 
-* **interpolation** -- the generated cells are split into contiguous per-rank ranges (``shard_range``); every rank builds
-  the KNN cache / plan of its range, uploads only the source rows that range references and writes its own output rows.
-  No collective.
+* **interpolation** -- the generated cells are split into spatially compact, cost-balanced shards (``LeafShards``: stretches
+  of the cells' Hilbert curve; the cut needs one small all-gather of cost profiles, no rank builds the table of all cells);
+  every rank builds the KNN cache / plan of its shard, uploads only the source rows that shard references and computes its
+  own output rows.  The bench step has no collective; ``ExportData``, which ends in ONE file, sends every rank's rows to the
+  rank that writes it (``gather_to_root``: grouped ncclSend / ncclRecv, every byte crosses xGMI once).
 * **refine** -- point cloud, KNN index and cell arrays are replicated; per batch every rank evaluates the KNN metric /
   gain of its 1/W slice of the new cells (``batch_slice``; the reference spreads the same work over a process pool,
   s_cube.py:207-241) and ONE grouped all-gather returns the slices to everybody.  The captured metric
@@ -37,39 +39,75 @@ def shard_range(n, rank=None, world_size=None):
 
 class LeafShards:
     """Cost-balanced, spatially compact shards of a set of target points (generated cell centres / vertices) for the
-    interpolation.  Every rank computes the same partition: neighbour table of ALL targets (the KNN query
-    is cheap next to one snapshot batch), its tile plan, tiles -- Hilbert order, so a run of tiles is a compact blob that
-    shares few source rows with the other ranks -- cut into ``world`` runs of equal cost (bytes moved per snapshot:
-    staged rows incl. halo + output rows).
+    interpolation: stretches of the targets' Hilbert curve -- a stretch is a compact blob that shares few
+    source rows with the other ranks -- of equal cost (bytes moved per snapshot: staged rows incl. halo + output rows).
+
+    No rank builds the neighbour table of ALL targets (at 10^7 cells that table and its plan would be replicated on every
+    GPU).  Every rank sorts the targets along the curve (keys + one radix sort: cheap), takes the r-th of ``world`` stretches
+    of equal LENGTH, queries the neighbours of that stretch only and publishes its cumulative cost profile (``PROFILE``
+    samples; one small all-gather of ``world * (PROFILE + 1)`` doubles); all ranks then cut the curve at equal COST from the
+    same numbers.  A rank's final stretch differs from its first one by the imbalance only; ``ExportData`` queries it once
+    more for the table it keeps.  Without a communicator (``comm=None``: tests, single-GPU probes) the profiles of all
+    stretches are computed here, one after the other -- the same numbers, hence the same cuts.
 
     ``mine``      int64 host array, the targets of this rank (ascending ids)
-    ``counts``    targets per rank; ``chunk`` = max(counts): slot size of the equal-chunk in-place all-gather
-    ``slot_of``   device int32 [n]: target id -> row of the gathered ``[world * chunk, L]`` array
+    ``counts``    targets per rank; ``offsets``: first row of each rank's block in the gathered ``[n, L]`` array
+    ``slot_of``   device int32 [n]: target id -> row of that array (the rank that collects the blocks restores the order)
     """
+    PROFILE = 256
 
-    def __init__(self, knn, targets, k, rank, world_size):
+    def __init__(self, knn, targets, k, rank, world_size, comm=None):
         from . import hipops
         targets = hipops.to_device(targets, pt.float64)
-        idx, _ = knn.query(targets, k)
-        plan = hipops.InterpPlan(idx, knn.n, targets)
-        order, cuts = plan.partition(world_size)
-        plan.close()
-        del idx
         self.rank, self.world, self.n = int(rank), int(world_size), int(targets.shape[0])
         if self.n < self.world:
             raise ValueError(f"{self.n} target points cannot be sharded over {self.world} ranks")
-        if min(cuts[r + 1] - cuts[r] for r in range(self.world)) == 0:
-            # fewer tiles than ranks (tiny grids): equal counts along the curve instead
-            cuts = [shard_range(self.n, r, self.world)[0] for r in range(self.world)] + [self.n]
+        order = hipops.spatial_order(targets) if self.n > 1 else pt.zeros(1, dtype=pt.int32, device=targets.device)
+        first = [shard_range(self.n, r, self.world)[0] for r in range(self.world)] + [self.n]      # equal lengths
+
+        def profile_of(r):
+            """cumulative cost along stretch r of the curve (cells in curve order: the plan keeps the order it is given)"""
+            ids = order[first[r]:first[r + 1]].long()
+            idx, _ = knn.query(targets[ids], k)
+            plan = hipops.InterpPlan(idx, knn.n, None)
+            prof = plan.cost_profile(self.PROFILE)
+            plan.close()
+            return prof
+
+        profiles = pt.zeros((self.world, self.PROFILE + 1), dtype=pt.float64, device=targets.device)
+        if comm is not None and comm.world == self.world and self.world > 1:
+            profiles[self.rank] = pt.from_numpy(profile_of(self.rank)).to(targets.device)
+            comm.allgather_inplace([profiles], [self.PROFILE + 1])
+        else:
+            for r in range(self.world):
+                profiles[r] = pt.from_numpy(profile_of(r)).to(targets.device)
+        cuts = self._cut(profiles.cpu().numpy(), first)
         self.counts = [cuts[r + 1] - cuts[r] for r in range(self.world)]
-        self.chunk = max(self.counts)
+        self.offsets = [int(c) for c in cuts[:-1]]
         order_h = order.cpu().numpy()
         self.mine = np.sort(order_h[cuts[self.rank]:cuts[self.rank + 1]]).astype(np.int64)
         slot = np.empty(self.n, dtype=np.int32)
         for r in range(self.world):
             ids = np.sort(order_h[cuts[r]:cuts[r + 1]])
-            slot[ids] = r * self.chunk + np.arange(len(ids), dtype=np.int32)
+            slot[ids] = cuts[r] + np.arange(len(ids), dtype=np.int32)
         self.slot_of = pt.from_numpy(slot).to(order.device)
+
+    def _cut(self, profiles, first):
+        """positions along the curve that split the total cost into ``world`` equal parts (piecewise linear cumulative cost
+        from the per-stretch profiles); every stretch keeps at least one target"""
+        pos, cum, base = [], [], 0.0
+        for r in range(self.world):
+            length = first[r + 1] - first[r]
+            pos.append(first[r] + length * np.arange(self.PROFILE + 1) / self.PROFILE)
+            cum.append(base + profiles[r])
+            base += profiles[r][-1]
+        pos, cum = np.concatenate(pos), np.concatenate(cum)
+        goals = base * np.arange(1, self.world) / self.world
+        inner = np.rint(np.interp(goals, cum, pos)).astype(np.int64) if base > 0 else np.asarray(first[1:-1], dtype=np.int64)
+        cuts = [0] + [int(c) for c in inner] + [self.n]
+        for r in range(1, self.world):                       # strictly increasing, room for the ranks behind
+            cuts[r] = min(max(cuts[r], cuts[r - 1] + 1), self.n - (self.world - r))
+        return cuts
 
 
 def batch_slice(n, rank, world_size):
@@ -85,6 +123,12 @@ class SoloComm:
 
     def allgather_inplace(self, arrays, counts):
         pass
+
+    def gather_to_root(self, send, recv, counts, root=0):
+        """rank r's rows ``send`` [counts[r], L] -> rank ``root``'s ``recv`` [sum(counts), L], blocks in rank order; ``recv`` is
+        None on the other ranks"""
+        if recv is not None and send is not None and recv.data_ptr() != send.data_ptr():
+            recv[:send.shape[0]].copy_(send)
 
     def allreduce_max(self, value):
         return float(value)
@@ -117,6 +161,22 @@ class GlooComm(SoloComm):
             self._dist.all_gather_into_tensor(out, mine)
             flat.copy_(out)
 
+    def gather_to_root(self, send, recv, counts, root=0):
+        if self.rank != root:
+            if counts[self.rank]:
+                self._dist.send(send.cpu().contiguous(), dst=root)
+            return
+        off = 0
+        for r, cnt in enumerate(counts):
+            if cnt:
+                if r == root:
+                    recv[off:off + cnt].copy_(send)
+                else:
+                    host = pt.empty((cnt,) + tuple(recv.shape[1:]), dtype=recv.dtype)
+                    self._dist.recv(host, src=r)
+                    recv[off:off + cnt].copy_(host)
+            off += cnt
+
     def allreduce_max(self, value):
         t = pt.tensor([float(value)], dtype=pt.float64)
         self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX)
@@ -136,11 +196,21 @@ class RcclComm(SoloComm):
         self.rank, self.world = int(rank), int(world_size)
         lib = _lib.hip_lib()
         ident = (C.c_char * 128)()
+        # ncclCommInitRank is a collective without a timeout: nobody may enter it unless everybody will.  Rank 0 publishes
+        # the id OR an error marker (so that the others do not wait for an id that never comes); the callers of this
+        # constructor have agreed beforehand that the library loads on every rank (parallel.init: preflight)
         if self.rank == 0:
-            hipops.check(lib.s3_comm_unique_id(ident, 128), "s3_comm_unique_id")
-            store.set("s3_comm_id", bytes(ident.raw))
+            try:
+                hipops.check(lib.s3_comm_unique_id(ident, 128), "s3_comm_unique_id")
+            except Exception as err:
+                store.set("s3_comm_id", b"ERR:" + str(err).encode()[:200])
+                raise
+            store.set("s3_comm_id", b"ID::" + bytes(ident.raw))
         else:
-            ident.raw = store.get("s3_comm_id")
+            blob = bytes(store.get("s3_comm_id"))
+            if blob[:4] != b"ID::":
+                raise RuntimeError(f"rank 0 could not create the RCCL id: {blob[4:].decode(errors='replace')}")
+            ident.raw = blob[4:4 + 128]
         self._h = C.c_void_p(0)
         hipops.device()
         hipops.check(lib.s3_comm_init(ident, 128, self.rank, self.world, C.byref(self._h)), "s3_comm_init")
@@ -157,6 +227,19 @@ class RcclComm(SoloComm):
                 raise ValueError("allgather_inplace: contiguous device tensors with room for world * count elements required")
         self._ops.check(self._lib.hip_lib().s3_comm_allgather_inplace(self._h, ptrs, sizes, n, self._ops._stream()),
                         "s3_comm_allgather_inplace")
+
+    def gather_to_root(self, send, recv, counts, root=0):
+        """device tensors: ``send`` [counts[rank], L] contiguous, ``recv`` [sum(counts), L] contiguous on ``root`` (None elsewhere);
+        grouped ncclSend / ncclRecv inside the library -- every byte crosses xGMI once"""
+        row = int(np.prod(send.shape[1:])) * send.element_size() if send is not None else int(np.prod(recv.shape[1:])) * recv.element_size()
+        sizes = (C.c_size_t * self.world)(*[int(c) * row for c in counts])
+        if send is not None and not (send.is_cuda and send.is_contiguous() and send.shape[0] == counts[self.rank]):
+            raise ValueError("gather_to_root: contiguous device tensor with counts[rank] rows required")
+        if self.rank == root and not (recv is not None and recv.is_cuda and recv.is_contiguous() and recv.shape[0] == sum(counts)):
+            raise ValueError("gather_to_root: the root needs a contiguous device tensor with sum(counts) rows")
+        self._ops.check(self._lib.hip_lib().s3_comm_gather_to_root(
+            self._h, C.c_void_p(send.data_ptr() if send is not None and send.numel() else 0),
+            C.c_void_p(recv.data_ptr() if recv is not None else 0), sizes, int(root), self._ops._stream()), "s3_comm_gather_to_root")
 
     def _allreduce(self, value, op):
         self._scalar[0] = float(value)
@@ -210,10 +293,23 @@ def init(backend=None):
         os.environ.setdefault("MASTER_PORT", "29500")
         store, _, _ = next(dist.rendezvous("env://", rank=rank, world_size=world_size))
         store = dist.PrefixStore("s3_comm", store)
+        # preflight: can every rank load the RCCL library and see its device?  Exchanged through the store BEFORE anybody
+        # enters ncclCommInitRank, which would wait for a rank that never arrives
         try:
-            _comm, reason = RcclComm(rank, world_size, store), ""
-        except Exception as err:         # librccl missing, communicator refused, ...
-            _comm, reason = None, str(err)
+            from . import _lib, hipops
+            hipops.device()
+            able = bool(_lib.hip_lib().s3_comm_available())
+            why = "" if able else "librccl could not be loaded"
+        except Exception as err:
+            able, why = False, str(err)
+        store.set(f"can_rccl_{rank}", b"1" if able else b"0")
+        everybody = all(store.get(f"can_rccl_{r}") == b"1" for r in range(world_size))
+        _comm, reason = None, why or "another rank cannot use RCCL"
+        if everybody:
+            try:
+                _comm, reason = RcclComm(rank, world_size, store), ""
+            except Exception as err:     # id creation failed on rank 0 (every rank sees the marker), communicator refused
+                _comm, reason = None, str(err)
         # every rank must end up with the same kind of communicator: agree through the store
         store.set(f"rccl_ok_{rank}", b"1" if _comm is not None else b"0")
         if all(store.get(f"rccl_ok_{r}") == b"1" for r in range(world_size)):

@@ -714,6 +714,11 @@ comm.allgather_inplace([a, b], [10, 7])
 assert pt.equal(a.cpu(), pt.arange(10, dtype=pt.float64)) and pt.equal(b.cpu(), pt.arange(7, dtype=pt.float64) * 2)
 assert comm.allreduce_max(3.5) == 3.5
 comm.barrier()
+send = pt.arange(12, dtype=pt.float64, device="cuda").reshape(4, 3); recv = pt.zeros((4, 3), dtype=pt.float64, device="cuda")
+comm.gather_to_root(send, recv, [4], root=0)          # s3_comm_gather_to_root: the root's own block is copied on the device
+assert pt.equal(recv, send)
+from sparsespatialsampling_amd import _lib
+assert _lib.hip_lib().s3_comm_available() == 1
 x, y, geos, kw = refine_inputs("refine_3d_metric", geometry)
 tree = s_cube.SamplingTree(pt.from_numpy(x), pt.from_numpy(y), geometry_obj=geos, **kw)
 assert tree._backend.comm is comm
@@ -786,8 +791,10 @@ def test_short_quad_kernel_equals_direct_gather(ops, k):
 
 
 def test_leaf_shards_partition_every_target_once(ops):
-    """``s3_interp_plan_partition`` / ``parallel.LeafShards``: for 1, 2, 3, 8 ranks the shards are disjoint, cover every target,
-    follow the plan's (Hilbert) order, and the gather slots form a permutation of the ``world * chunk`` positions in use"""
+    """``parallel.LeafShards``: for 1, 2, 3, 8 ranks the shards are disjoint, cover every target, are stretches of the
+    targets' Hilbert curve, every rank computes the same cuts, the blocks of the gathered array are a permutation of its
+    rows, and the cost of the shards (staged rows + cells of their own plans) is balanced although the cloud is clustered;
+    ``s3_interp_plan_partition`` / ``s3_interp_plan_cost_profile`` of one plan agree with each other"""
     from sparsespatialsampling_amd import parallel
     rng = np.random.default_rng(77)
     x = np.concatenate([rng.random((40000, 3)), 0.5 + 0.05 * rng.standard_normal((40000, 3))])
@@ -795,18 +802,33 @@ def test_leaf_shards_partition_every_target_once(ops):
     knn = ops.KnnIndex(x)
     idx, _ = knn.query(targets, 26)
     plan = ops.InterpPlan(idx, len(x), targets)
+    prof = plan.cost_profile(64)
+    assert prof[0] == 0 and np.all(np.diff(prof) >= 0) and prof[-1] > 0
     for world in (1, 2, 3, 8):
         order, cuts = plan.partition(world)
         order = order.cpu().numpy()
         assert cuts[0] == 0 and cuts[-1] == len(targets) and all(a <= b for a, b in zip(cuts, cuts[1:]))
         assert np.array_equal(np.sort(order), np.arange(len(targets)))
+        # the plan's own cuts split its cost profile into nearly equal parts
+        at = np.interp(cuts, np.linspace(0, len(targets), 65), prof)
+        assert np.all(np.abs(np.diff(at) - prof[-1] / world) <= 0.05 * prof[-1] / world + 2 * prof[-1] / plan.n_tiles)
         shards = [parallel.LeafShards(knn, targets, 26, r, world) for r in range(world)]
-        assert [len(s.mine) for s in shards] == [cuts[r + 1] - cuts[r] for r in range(world)] == shards[0].counts
+        assert all(s.counts == shards[0].counts and s.offsets == shards[0].offsets for s in shards)
+        assert [len(s.mine) for s in shards] == shards[0].counts and sum(shards[0].counts) == len(targets)
         assert np.array_equal(np.sort(np.concatenate([s.mine for s in shards])), np.arange(len(targets)))
+        curve = ops.spatial_order(targets).cpu().numpy()
         slot = shards[0].slot_of.cpu().numpy()
-        assert len(np.unique(slot)) == len(targets) and slot.max() < world * shards[0].chunk
+        assert np.array_equal(np.sort(slot), np.arange(len(targets)))
+        costs = []
         for r, s in enumerate(shards):
-            assert np.array_equal(slot[s.mine], r * s.chunk + np.arange(len(s.mine)))
+            assert np.array_equal(slot[s.mine], s.offsets[r] + np.arange(len(s.mine)))
+            assert np.array_equal(np.sort(curve[s.offsets[r]:s.offsets[r] + s.counts[r]]), s.mine)    # a stretch of the curve
+            own_idx, _ = knn.query(targets[s.mine], 26)
+            own = ops.InterpPlan(own_idx, len(x), targets[s.mine])
+            costs.append(4.0 * own.total_rows + 14.0 * len(s.mine))
+            own.close()
+        if world > 1:
+            assert max(costs) <= 1.15 * np.mean(costs), costs
     plan.close(), knn.close()
 
 

@@ -126,3 +126,56 @@ def test_ranks_without_rccl_agree_on_gloo(tmp_path):
     for r, res in enumerate((r0, r1)):
         assert res["name"].startswith("gloo (RCCL") and res["world"] == (r, 2) and res["mx"] == 2.0
         assert np.array_equal(res["gathered"], np.array([0, 1, 2, 3, 4, 10, 11, 12, 13, 14], dtype=np.float64))
+
+
+def _gather_worker(rank, world, port, out):
+    for p in (ROOT,):
+        sys.path.insert(0, p) if p not in sys.path else None
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sparsespatialsampling_amd import parallel
+    comm = parallel.init("gloo")
+    counts = [3, 0, 5][:world] if world == 3 else [4, 2]
+    send = (pt.arange(counts[rank] * 2, dtype=pt.float64).reshape(counts[rank], 2) + 100 * rank)
+    recv = pt.zeros((sum(counts), 2), dtype=pt.float64) if rank == 0 else None
+    comm.gather_to_root(send, recv, counts, root=0)           # blocks in rank order on the root, nothing on the others
+    prof = pt.zeros((world, 5), dtype=pt.float64)
+    prof[rank] = pt.arange(5, dtype=pt.float64) * (rank + 1)
+    comm.allgather_inplace([prof], [5])                        # what LeafShards does with its cost profiles
+    if rank == 0:
+        pt.save(dict(recv=recv, prof=prof, counts=counts), out)
+    comm.barrier()
+    parallel.shutdown()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gather_to_root_and_profiles_gloo(tmp_path, world):
+    """the exchange of a sharded export (every rank's rows to the rank that writes the file, variable block sizes incl. an
+    empty one) and the all-gather of the shards' cost profiles, world_size 2 and 3 on gloo"""
+    out = str(tmp_path / "g.pt")
+    mp.spawn(_gather_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    res = pt.load(out, weights_only=False)
+    counts = res["counts"]
+    want = pt.cat([pt.arange(c * 2, dtype=pt.float64).reshape(c, 2) + 100 * r for r, c in enumerate(counts)])
+    assert pt.equal(res["recv"], want)
+    assert pt.equal(res["prof"], pt.stack([pt.arange(5, dtype=pt.float64) * (r + 1) for r in range(world)]))
+
+
+def test_leaf_shard_cuts_balance_the_cost():
+    """``LeafShards._cut``: equal-cost positions from per-stretch cumulative profiles (host logic, no GPU): a curve whose
+    second half costs three times the first is cut at 2/3 of its length for two ranks; degenerate profiles keep every rank
+    at least one target"""
+    from sparsespatialsampling_amd.parallel import LeafShards, shard_range
+    sh = LeafShards.__new__(LeafShards)
+    sh.world, sh.n = 2, 1200
+    first = [shard_range(sh.n, r, 2)[0] for r in range(2)] + [sh.n]
+    s = np.arange(LeafShards.PROFILE + 1) / LeafShards.PROFILE
+    cuts = sh._cut(np.stack([600.0 * s, 1800.0 * s]), first)
+    assert cuts == [0, 800, 1200]                               # 600 + (1200 - 600) / 1800 * 600 = 800
+    sh.world, sh.n = 4, 5
+    first = [shard_range(5, r, 4)[0] for r in range(4)] + [5]
+    assert sh._cut(np.zeros((4, LeafShards.PROFILE + 1)), first) == [0, 2, 3, 4, 5]
+    heavy_head = np.zeros((4, LeafShards.PROFILE + 1)); heavy_head[0] = 10.0 * s
+    cuts = sh._cut(heavy_head, first)
+    assert cuts[0] == 0 and cuts[-1] == 5 and all(b > a for a, b in zip(cuts, cuts[1:]))

@@ -20,6 +20,7 @@
 #include "common.h"
 
 #include <cfloat>
+#include <cstdlib>
 #include <cmath>
 #include <utility>
 #include <vector>
@@ -301,10 +302,11 @@ __global__ void permute_values_kernel(const double *__restrict__ y, const int32_
 // the search
 // ------------------------------------------------------------------------------------------------------------------
 struct KBest {
-    double *sd;    // LDS, this thread's column: slot m at sd[m*KNN_BLOCK]
+    double *sd;    // LDS, this thread's column: slot m at sd[m * stride]
     int32_t *sp;
     int k;
     int cnt;
+    int stride;    // threads that share the LDS block (KNN_BLOCK; a few lanes when a wavefront searches for one cell)
     double worst;  // sd[k-1] once the list is full, +inf before
 };
 
@@ -315,18 +317,18 @@ __device__ __forceinline__ bool kb_less(double d, int32_t p, double d2, int32_t 
 __device__ __forceinline__ void kb_offer(KBest &b, double d, int32_t p, const int32_t *__restrict__ orig) {
     if (b.cnt == b.k) {
         if (d > b.worst) return;
-        if (d == b.worst && !(orig[p] < orig[b.sp[(b.k - 1) * KNN_BLOCK]])) return;
+        if (d == b.worst && !(orig[p] < orig[b.sp[(b.k - 1) * b.stride]])) return;
     }
     int j = b.cnt < b.k ? b.cnt : b.k - 1;
-    while (j > 0 && kb_less(d, p, b.sd[(j - 1) * KNN_BLOCK], b.sp[(j - 1) * KNN_BLOCK], orig)) {
-        b.sd[j * KNN_BLOCK] = b.sd[(j - 1) * KNN_BLOCK];
-        b.sp[j * KNN_BLOCK] = b.sp[(j - 1) * KNN_BLOCK];
+    while (j > 0 && kb_less(d, p, b.sd[(j - 1) * b.stride], b.sp[(j - 1) * b.stride], orig)) {
+        b.sd[j * b.stride] = b.sd[(j - 1) * b.stride];
+        b.sp[j * b.stride] = b.sp[(j - 1) * b.stride];
         --j;
     }
-    b.sd[j * KNN_BLOCK] = d;
-    b.sp[j * KNN_BLOCK] = p;
+    b.sd[j * b.stride] = d;
+    b.sp[j * b.stride] = p;
     if (b.cnt < b.k) ++b.cnt;
-    if (b.cnt == b.k) b.worst = b.sd[(b.k - 1) * KNN_BLOCK];
+    if (b.cnt == b.k) b.worst = b.sd[(b.k - 1) * b.stride];
 }
 
 template <int DIM>
@@ -533,12 +535,12 @@ __device__ __forceinline__ double numpy_pairwise(int k, F f) {
 
 __device__ __forceinline__ double idw_from_list(const KBest &b, const double *__restrict__ y) {
     bool has_zero = false;
-    for (int m = 0; m < b.k; ++m) has_zero |= (b.sd[m * KNN_BLOCK] == 0.0);
+    for (int m = 0; m < b.k; ++m) has_zero |= (b.sd[m * b.stride] == 0.0);
     auto wgt = [&](int m) {
-        double rd = b.sd[m * KNN_BLOCK];
+        double rd = b.sd[m * b.stride];
         return has_zero ? (rd == 0.0 ? 1.0 : 0.0) : 1.0 / sqrt(rd);
     };
-    double num = numpy_pairwise(b.k, [&](int m) { return y[b.sp[m * KNN_BLOCK]] * wgt(m); });
+    double num = numpy_pairwise(b.k, [&](int m) { return y[b.sp[m * b.stride]] * wgt(m); });
     double den = numpy_pairwise(b.k, wgt);
     return num / den;
 }
@@ -549,6 +551,7 @@ __device__ __forceinline__ KBest kb_init(double *lds, int k) {
     b.sp = reinterpret_cast<int32_t *>(lds + (size_t)k * KNN_BLOCK) + threadIdx.x;
     b.k = k;
     b.cnt = 0;
+    b.stride = KNN_BLOCK;
     b.worst = DBL_MAX;
     return b;
 }
@@ -623,6 +626,393 @@ child_metric_kernel(Grid<DIM> g, const double *__restrict__ pts, const int32_t *
     if (REUSE && jq == 1) {
         const int64_t ii = parents_offset + i;               // position of the cell among the batch's children
         metric_all[i * NQ] = child_metric[(int64_t)parents[ii / NCH] * NCH + (ii % NCH)];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The same 2^DIM child predictions of a new cell by ONE WAVEFRONT (s3_child_gain_reuse): selection instead of insertion.
+//
+// The per-lane search above is bound by instruction issue at 24 % lane utilisation: every lane walks its own rings, rows
+// and runs, and inserts into its own sorted list at its own moments.  The 2^DIM child points of one cell lie within a
+// quarter of the cell's width of each other, so they share their candidates:
+//   1. box: the buckets within the child points' reach of the cell centre's bucket, per axis and side (2 or 3 of them at two
+//      points per bucket; rows of buckets = contiguous runs of points: one lane per row fetches their bounds, a wave scan
+//      gives every candidate its slot); at most COOP_M points, no refined bucket, or the cell is searched the per-lane way;
+//   2. the points' coordinates go to LDS once (coalesced), 64 / 2^DIM lanes per child point then share the candidates;
+//   3. pass A: squared distances (same expression as the per-lane search: no contraction, dimension order) below the
+//      SAFE radius of the point -- its distance to the nearest face of the box that has unvisited buckets behind it -- are
+//      counted in 64 bins; the bin where the count reaches k gives a threshold with k .. k + a few candidates below it;
+//      fewer than k candidates inside the safe radius, or more than COOP_CAP below the threshold (ties in bulk): per-lane kernel;
+//   4. pass B: the candidates below the threshold are compacted into a short list, every entry is ranked by (distance,
+//      original point id) against the others, the k best land in order -- the k nearest neighbours exactly as the per-lane
+//      search returns them, since every point nearer than the safe radius is in the box;
+//   5. inverse-distance prediction with numpy's pairwise order (eight partial sums on eight lanes).
+// Cells the wavefront cannot take are searched the per-lane way by 2^DIM of its lanes on the spot: the results are the same
+// bits either way (tools/knn_coop_probe.py, every refine golden).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int COOP_M = 384;        // candidates per cell held in LDS
+constexpr int COOP_SLOTS = COOP_M / 64;
+constexpr int COOP_NB = 64;        // histogram bins per child point
+constexpr int COOP_CAP = 48;       // entries of the short list per child point (k plus the rest of the k-th bin)
+constexpr int COOP_RMAX = 3;       // at most this many buckets on either side of the centre's bucket
+constexpr int COOP_ROWS = 64;      // >= (2 RMAX + 1)^(DIM - 1) rows of buckets, one lane each
+constexpr int COOP_WAVES = 2;      // wavefronts (cells) per workgroup
+
+// 17 KiB per wavefront: nine wavefronts per CU.  A wavefront's life is a chain of dependent memory round trips (cell -> bucket
+// bounds -> points -> values), so what counts is how many of them a CU holds and how few trips each needs: the loops below
+// are unrolled so that the loads of several slots are in flight together.
+template <int DIM>
+struct CoopLds {
+    union {
+        double xyz[COOP_M][DIM];                   // candidates' coordinates (until the short lists are built)
+        struct {
+            double list_y[1 << DIM][COOP_CAP];     // afterwards: value and weight of the k best
+            double list_w[1 << DIM][COOP_CAP];
+        } best;
+    };
+    int32_t pos[COOP_M];
+    uint32_t hist[1 << DIM][COOP_NB + 1];          // (+1: the child points' rows start in different banks)
+    double list_d[1 << DIM][COOP_CAP];
+    int32_t list_p[1 << DIM][COOP_CAP];
+    int32_t row_start[COOP_ROWS], row_prefix[COOP_ROWS + 1];
+    uint32_t count[1 << DIM];
+};
+static_assert(sizeof(double) * COOP_M * 2 >= sizeof(double) * 4 * COOP_CAP * 2, "the lists of the best fit the coordinates' space");
+
+__device__ __forceinline__ void wave_sync_lds() {
+    // one wavefront: LDS operations execute in program order; this only keeps the compiler from moving them
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// One cooperative search: the 64 / LPQ query points c + dir(jq) * off (LPQ lanes each; LPQ = 64: the single point c) share
+// the box around the bucket of c.  reach = radius (in bucket sides, per axis) the box must cover around the query points:
+// the expected distance of the k-th neighbour at the index's average occupancy times a margin.  Returns false (for the
+// whole wavefront) when the scheme cannot answer -- reach beyond COOP_RMAX buckets, a refined bucket in the box, more than
+// COOP_M candidates, fewer than k inside a point's safe radius, more than COOP_CAP below the threshold, a tie among the
+// entries that matter; otherwise lane 0 of every group returns its point's prediction in `result`.
+template <int DIM, int LPQ>
+__device__ __forceinline__ bool coop_solve(const Grid<DIM> &g, const double *__restrict__ pts, const int32_t *__restrict__ orig,
+                                           const int32_t *__restrict__ cs, const double *__restrict__ y, CoopLds<DIM> &L,
+                                           const double (&c)[DIM], double off, int k, double reach, int lane, double &result) {
+    constexpr int BPL = COOP_NB / LPQ < 1 ? 1 : COOP_NB / LPQ;
+    constexpr int CHUNK = LPQ >= 64 ? 2 : 4;                  // candidates whose coordinates a lane reads together
+    constexpr int ROUNDS = COOP_CAP / LPQ < 1 ? 1 : COOP_CAP / LPQ;
+    constexpr int NQB = 64 / LPQ;
+    static_assert(LPQ >= 8 && (COOP_NB % LPQ == 0 || LPQ > COOP_NB) && COOP_CAP <= 64, "lane layout");
+
+    // ---- 1. the box: as many buckets on either side of the centre's bucket as the query points' reach needs ---------------
+    int lo_i[3] = {0, 0, 0}, hi_i[3] = {0, 0, 0};
+    double hmin = DBL_MAX;
+    bool too_far = false;
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) {
+        const int b = cell_coord<DIM>(g, c[j], j);
+        const double frac = fmin(fmax((c[j] - g.lo[j]) * g.inv_h[j] - (double)b, 0.0), 1.0);   // position inside the bucket
+        const double want = off * g.inv_h[j] + reach;                                          // in bucket sides
+        const int r_lo = (int)ceil(want - frac), r_hi = (int)ceil(want - (1.0 - frac));
+        too_far = too_far || r_lo > COOP_RMAX || r_hi > COOP_RMAX;
+        lo_i[j] = max(b - max(r_lo, 0), 0);
+        hi_i[j] = min(b + max(r_hi, 0), g.res[j] - 1);
+        hmin = fmin(hmin, g.h[j]);
+    }
+    if (too_far) return false;                                // the points do not share candidates (coarse cells)
+    const int ny = hi_i[1] - lo_i[1] + 1, nz = DIM == 3 ? hi_i[2] - lo_i[2] + 1 : 1, n_rows = ny * nz;
+    int my_start = 0, my_cnt = 0;
+    bool refined = false;
+    if (lane < n_rows) {
+        const int zz = lane / ny, yy = lane - zz * ny;
+        const int64_t row = ((int64_t)(DIM == 3 ? lo_i[2] + zz : 0) * g.res[1] + (lo_i[1] + yy)) * g.res[0];
+        my_start = cs[row + lo_i[0]];
+        my_cnt = cs[row + hi_i[0] + 1] - my_start;
+        if (g.sub_res != nullptr)
+            for (int x = lo_i[0]; x <= hi_i[0]; ++x) refined |= g.sub_res[row + x] != 0;
+    }
+    int incl = my_cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int u = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += u;
+    }
+    const int M = __shfl(incl, 63, 64);
+    if (__ballot(refined) != 0ull || M > COOP_M || M < k) return false;
+    wave_sync_lds();                                          // (an earlier attempt's reads of these arrays are done)
+    if (lane < n_rows) {
+        L.row_start[lane] = my_start;
+        L.row_prefix[lane] = incl - my_cnt;
+    }
+    if (lane == 0) L.row_prefix[COOP_ROWS] = M;
+    if (lane < NQB) L.count[lane] = 0;
+    for (int t = lane; t < NQB * (COOP_NB + 1); t += 64) (&L.hist[0][0])[t] = 0;
+    wave_sync_lds();
+
+    // ---- 2. candidates -> LDS: four slots of a lane at a time searched, then loaded together, then stored -------------------
+#pragma unroll 1
+    for (int base = 0; base < M; base += 64 * 4) {
+        int slot_p[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = min(base + lane + 64 * u, M - 1);
+            int r = 0;                                        // the row whose slots hold t: last r with row_prefix[r] <= t
+#pragma unroll
+            for (int step = COOP_ROWS / 2; step > 0; step >>= 1)
+                if (r + step < n_rows && L.row_prefix[r + step] <= t) r += step;
+            slot_p[u] = L.row_start[r] + (t - L.row_prefix[r]);
+        }
+        double slot_x[4][DIM];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < DIM; ++j) slot_x[u][j] = pts[(int64_t)slot_p[u] * DIM + j];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = base + lane + 64 * u;
+            if (t < M) {
+                L.pos[t] = slot_p[u];
+#pragma unroll
+                for (int j = 0; j < DIM; ++j) L.xyz[t][j] = slot_x[u][j];
+            }
+        }
+    }
+    wave_sync_lds();
+
+    // ---- 3. this lane's query point, its safe radius, ONE pass over the distances (kept in registers) ----------------------
+    const int jq = lane / LPQ, gl = lane - jq * LPQ;
+    double q[DIM], safe2 = DBL_MAX, far2 = 0.0;
+    bool inside = true;
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) {
+        q[j] = NQB == 1 ? c[j] : c[j] + dir_comp(DIM, jq, j) * off;
+        const double face_lo = g.lo[j] + (double)lo_i[j] * g.h[j], face_hi = g.lo[j] + (double)(hi_i[j] + 1) * g.h[j];
+        if (lo_i[j] > 0) {                                    // buckets behind this face exist and were not visited
+            const double f = q[j] - face_lo - 1e-9 * hmin;
+            inside = inside && f > 0.0;
+            safe2 = fmin(safe2, f * f);
+        }
+        if (hi_i[j] < g.res[j] - 1) {
+            const double f = face_hi - q[j] - 1e-9 * hmin;
+            inside = inside && f > 0.0;
+            safe2 = fmin(safe2, f * f);
+        }
+        const double span = fmax(fabs(q[j] - face_lo), fabs(face_hi - q[j]));
+        far2 += span * span;
+    }
+    if (__ballot(!inside) != 0ull) return false;              // a query point at or beyond a face of the box
+    const double lim2 = fmin(safe2, far2 * 1.0000001 + 1e-300);   // no limiting face: every point of the grid is in the box
+    const double to_bin = (double)COOP_NB / lim2;
+    auto dist2 = [&](int t) {
+        double d = 0.0;
+#pragma unroll
+        for (int j = 0; j < DIM; ++j) {
+            const double w_ = q[j] - L.xyz[t][j];
+            d += w_ * w_;
+        }
+        return d;
+    };
+    // (groups of CHUNK candidates: their coordinates are read together, one LDS round trip per group instead of per candidate)
+    for (int t0 = gl; t0 < M; t0 += CHUNK * LPQ) {
+        double d[CHUNK];
+#pragma unroll
+        for (int u = 0; u < CHUNK; ++u) d[u] = dist2(min(t0 + u * LPQ, M - 1));
+#pragma unroll
+        for (int u = 0; u < CHUNK; ++u)
+            if (t0 + u * LPQ < M && d[u] < lim2) atomicAdd(&L.hist[jq][min(COOP_NB - 1, (int)(d[u] * to_bin))], 1u);
+    }
+    wave_sync_lds();
+    // the bin in which the count reaches k: lane gl of the group owns bins gl * BPL .. (lanes beyond the bins: none)
+    uint32_t bins[BPL], mine = 0;
+#pragma unroll
+    for (int b = 0; b < BPL; ++b) {
+        bins[b] = gl * BPL + b < COOP_NB ? L.hist[jq][gl * BPL + b] : 0u;
+        mine += bins[b];
+    }
+    uint32_t upto = mine;
+#pragma unroll
+    for (int d = 1; d < LPQ; d <<= 1) {
+        const uint32_t u = __shfl_up(upto, d, LPQ);
+        if (gl >= d) upto += u;
+    }
+    const uint32_t total = __shfl(upto, LPQ - 1, LPQ);
+    int b_star = -1;
+    uint32_t below = 0;
+    {
+        uint32_t run = upto - mine;
+        const bool owner = run < (uint32_t)k && upto >= (uint32_t)k;       // exactly one lane of the group
+#pragma unroll
+        for (int b = 0; b < BPL; ++b) {
+            run += bins[b];
+            if (owner && b_star < 0 && run >= (uint32_t)k) { b_star = gl * BPL + b; below = run; }
+        }
+    }
+#pragma unroll
+    for (int d = 1; d < LPQ; d <<= 1) {                       // the owner's values to the whole group
+        b_star = max(b_star, __shfl_xor(b_star, d, LPQ));
+        below = max(below, __shfl_xor(below, d, LPQ));
+    }
+    if (__ballot(total < (uint32_t)k || below > (uint32_t)COOP_CAP) != 0ull) return false;
+
+    // ---- 4. short list, ranks, the k best in order -----------------------------------------------------------------------
+    for (int t0 = gl; t0 < M; t0 += CHUNK * LPQ) {           // (the distances again: cheaper than 2 x 48 registers per lane)
+        double d[CHUNK];
+#pragma unroll
+        for (int u = 0; u < CHUNK; ++u) d[u] = dist2(min(t0 + u * LPQ, M - 1));
+#pragma unroll
+        for (int u = 0; u < CHUNK; ++u)
+            if (t0 + u * LPQ < M && d[u] < lim2 && min(COOP_NB - 1, (int)(d[u] * to_bin)) <= b_star) {
+                const uint32_t at = atomicAdd(&L.count[jq], 1u);
+                L.list_d[jq][at] = d[u];
+                L.list_p[jq][at] = L.pos[t0 + u * LPQ];
+            }
+    }
+    wave_sync_lds();
+    const int n_list = (int)below;
+    double e_d[ROUNDS];
+    int32_t e_p[ROUNDS], e_less[ROUNDS], e_same[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const int e = min(gl + r * LPQ, n_list - 1);
+        e_d[r] = L.list_d[jq][e];
+        e_p[r] = L.list_p[jq][e];
+        e_less[r] = e_same[r] = 0;
+    }
+    const int n_rounds = (n_list + LPQ - 1) / LPQ;            // (uniform within the group, nearly always within the wavefront)
+#pragma unroll 4
+    for (int m = 0; m < n_list; ++m) {                        // every entry of the list against this lane's entries
+        const double dm = L.list_d[jq][m];
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r)
+            if (r < n_rounds) {
+                e_less[r] += dm < e_d[r] ? 1 : 0;
+                e_same[r] += dm == e_d[r] ? 1 : 0;
+            }
+    }
+    // two entries at exactly the same distance among the ones that matter (lattices of points): the order among them is
+    // the original point id -- left to the per-lane search, which breaks the tie that way
+    bool tie = false;
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) tie |= gl + r * LPQ < n_list && e_same[r] > 1 && e_less[r] < k;
+    if (__ballot(tie) != 0ull) return false;
+    wave_sync_lds();
+    // value and inverse-distance weight of the k best, by the lanes that hold them: one round trip for all values
+    double e_y[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        if (!(gl + r * LPQ < n_list)) e_less[r] = COOP_CAP;
+        e_y[r] = e_less[r] < k ? y[e_p[r]] : 0.0;
+    }
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r)
+        if (e_less[r] < k) {
+            L.list_d[jq][e_less[r]] = e_d[r];
+            L.best.list_y[jq][e_less[r]] = e_y[r];
+            L.best.list_w[jq][e_less[r]] = 1.0 / sqrt(e_d[r]);
+        }
+    wave_sync_lds();
+
+    // ---- 5. inverse-distance prediction, numpy's pairwise order (idw_from_list / numpy_pairwise above) --------------------
+    bool zero = false;
+    for (int m = gl; m < k; m += LPQ) zero |= L.list_d[jq][m] == 0.0;
+#pragma unroll
+    for (int d = 1; d < LPQ; d <<= 1) zero |= __shfl_xor((int)zero, d, LPQ) != 0;
+    auto wgt = [&](int m) { return zero ? (L.list_d[jq][m] == 0.0 ? 1.0 : 0.0) : L.best.list_w[jq][m]; };
+    auto term = [&](int m) { return L.best.list_y[jq][m] * wgt(m); };
+    double num = 0.0, den = 0.0;
+    if (k < 8) {
+        if (gl == 0)
+            for (int m = 0; m < k; ++m) {
+                num += term(m);
+                den += wgt(m);
+            }
+    } else {
+        double rn = 0.0, rw = 0.0;
+        if (gl < 8) {
+            rn = term(gl);
+            rw = wgt(gl);
+            for (int m = 8; m < k - (k % 8); m += 8) {
+                rn += term(m + gl);
+                rw += wgt(m + gl);
+            }
+        }
+        // ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7)) on lane 0 of the group
+        rn += __shfl_xor(rn, 1, LPQ); rw += __shfl_xor(rw, 1, LPQ);        // lanes 0,2,4,6: r0+r1, r2+r3, ...
+        rn += __shfl_xor(rn, 2, LPQ); rw += __shfl_xor(rw, 2, LPQ);        // lanes 0,4: (r0+r1)+(r2+r3), (r4+r5)+(r6+r7)
+        rn += __shfl_xor(rn, 4, LPQ); rw += __shfl_xor(rw, 4, LPQ);
+        num = rn;
+        den = rw;
+        if (gl == 0)
+            for (int m = k - (k % 8); m < k; ++m) {
+                num += term(m);
+                den += wgt(m);
+            }
+    }
+    result = num / den;
+    wave_sync_lds();
+    return true;
+}
+
+template <int DIM>
+__global__ void __launch_bounds__(64 * COOP_WAVES)
+child_metric_coop_kernel(Grid<DIM> g, const double *__restrict__ pts, const int32_t *__restrict__ orig,
+                         const int32_t *__restrict__ cs, const double *__restrict__ y, const double *__restrict__ center,
+                         const int32_t *__restrict__ level, int64_t first, int64_t n, double quarter_width, int k, double reach,
+                         double *__restrict__ metric_all, const int32_t *__restrict__ parents, int64_t parents_offset,
+                         double *__restrict__ child_metric, int32_t *__restrict__ rest /*[0]: count, [2 ..]: queries left over*/) {
+    constexpr int NCH = 1 << DIM, NQ = NCH + 1, LPQ = 64 / NCH;
+    __shared__ CoopLds<DIM> lds_all[COOP_WAVES];
+    const int lane = threadIdx.x & 63;
+    const int64_t i = blockIdx.x * (int64_t)COOP_WAVES + (threadIdx.x >> 6);
+    if (i >= n) return;                                       // (uniform per wavefront)
+    CoopLds<DIM> &L = lds_all[threadIdx.x >> 6];
+    const int64_t cell = first + i;
+    // the centre's value from the parent's entry
+    if (lane == 0) {
+        const int64_t ii = parents_offset + i;
+        metric_all[i * NQ] = child_metric[(int64_t)parents[ii / NCH] * NCH + (ii % NCH)];
+    }
+    double c[DIM];
+    const double off = cell_offset(quarter_width, level[cell]);
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) c[j] = center[cell * DIM + j];
+    double m = 0.0;
+    // (a second attempt with a wider box for the cells that find too few candidates inside their safe radius was measured:
+    //  it halves the cells left over but the kernel carrying both attempts is slower by more than that saves -- the cells
+    //  near a body or the edge of the cloud need searches much wider than any box that fits here)
+    if (k <= COOP_CAP && coop_solve<DIM, LPQ>(g, pts, orig, cs, y, L, c, off, k, reach, lane, m)) {
+        if (lane % LPQ == 0) {
+            metric_all[i * NQ + 1 + lane / LPQ] = m;
+            child_metric[cell * NCH + lane / LPQ] = m;
+        }
+        return;
+    }
+    // Coarse cells (child points several buckets apart: no shared candidates), refined buckets in the box, a thin stretch of
+    // the cloud, ties in distance, k > COOP_CAP: the cell's child points are listed for the per-lane search of
+    // child_metric_rest_kernel.
+    if (lane < NCH) rest[2 + atomicAdd(&rest[0], 1)] = (int32_t)(i * NCH + lane);
+}
+
+// the queries the wavefronts above could not answer (rest[0] of them): the per-lane search, lanes densely packed
+template <int DIM>
+__global__ void __launch_bounds__(KNN_BLOCK)
+child_metric_rest_kernel(Grid<DIM> g, const double *__restrict__ pts, const int32_t *__restrict__ orig,
+                         const int32_t *__restrict__ cs, const double *__restrict__ y, const double *__restrict__ center,
+                         const int32_t *__restrict__ level, int64_t first, double quarter_width, int k,
+                         double *__restrict__ metric_all, double *__restrict__ child_metric, const int32_t *__restrict__ rest) {
+    constexpr int NCH = 1 << DIM, NQ = NCH + 1;
+    extern __shared__ double lds[];
+    const int count = rest[0];
+    for (int e = blockIdx.x * KNN_BLOCK + threadIdx.x; e < count; e += gridDim.x * KNN_BLOCK) {
+        const int64_t i = rest[2 + e] / NCH;
+        const int jq = rest[2 + e] % NCH;
+        const int64_t cell = first + i;
+        const double off = cell_offset(quarter_width, level[cell]);
+        double q[DIM];
+#pragma unroll
+        for (int j = 0; j < DIM; ++j) q[j] = center[cell * DIM + j] + dir_comp(DIM, jq, j) * off;
+        KBest b = kb_init(lds, k);
+        knn_search<DIM>(g, pts, orig, cs, q, b);
+        const double m = idw_from_list(b, y);
+        metric_all[i * NQ + 1 + jq] = m;
+        child_metric[cell * NCH + jq] = m;
     }
 }
 
@@ -937,6 +1327,25 @@ int s3_idw_predict(const s3_knn *knn, const double *d_q, int64_t nq, int k, doub
     return S3_OK;
 }
 
+static bool knn_coop_enabled() {
+    const char *e = getenv("S3_KNN_COOP");
+    return !(e && e[0] == '0');
+}
+
+static int64_t knn_coop_min_cells() {
+    const char *e = getenv("S3_KNN_COOP_MIN");
+    return e ? atoll(e) : 100000ll;
+}
+static bool knn_coop_forced() {
+    const char *e = getenv("S3_KNN_COOP");
+    return e && e[0] == '1';
+}
+
+static double knn_coop_margin() {
+    const char *e = getenv("S3_KNN_COOP_MARGIN");
+    return e ? atof(e) : 1.15;
+}
+
 static int child_gain_impl(const s3_knn *knn, int k, const double *d_center, const int32_t *d_level, int64_t first, int64_t n,
                            int dim, double width, const double *d_level_factor, double gain0, double *d_metric, double *d_gain,
                            double *d_scratch, const int32_t *d_parents, int64_t parents_offset, double *d_child_metric,
@@ -956,16 +1365,42 @@ static int child_gain_impl(const s3_knn *knn, int k, const double *d_center, con
     child_metric_kernel<DIM, REUSE><<<grid_for(n * (PER), KNN_BLOCK), KNN_BLOCK, lds, st>>>(                                   \
         make_grid<DIM>(knn), knn->pts, knn->orig, knn->cell_start, knn->y, d_center, d_level, first, n, qw, k, d_scratch,     \
         d_parents, parents_offset, d_child_metric)
+#define S3_CHILD_COOP(DIM)                                                                                                    \
+    do {                                                                                                                      \
+    child_metric_coop_kernel<DIM><<<grid_for(n, COOP_WAVES), 64 * COOP_WAVES, 0, st>>>(                                       \
+        make_grid<DIM>(knn), knn->pts, knn->orig, knn->cell_start, knn->y, d_center, d_level, first, n, qw, k, reach,        \
+        d_scratch, d_parents, parents_offset, d_child_metric, d_rest);                                                        \
+    child_metric_rest_kernel<DIM><<<grid_for(n * (1 << DIM), KNN_BLOCK, 1024), KNN_BLOCK, lds, st>>>(make_grid<DIM>(knn), knn->pts, knn->orig, knn->cell_start, knn->y,  \
+                                                             d_center, d_level, first, qw, k, d_scratch, d_child_metric, d_rest); \
+    } while (0)
+    // one wavefront per cell (S3_KNN_COOP=0: the per-lane search for every child point, as for cells without a known parent)
+    // Measured on MI355X (interleaved box to box, +-5 %): cylinder3D (batches of <= 60 000 new cells, a third of them coarse or
+    // next to the body) 0.061 s with the per-lane kernel alone, 0.060 - 0.065 s with the wavefronts in front of it -- what they
+    // save the per-lane tail for the left-over queries costs again (a per-lane wavefront lives 0.2 - 1.5 ms however few
+    // queries it carries); box5e7 (batches of ~270 000 fine cells) 0.70 -> 0.59 - 0.62 s.  Hence only for large batches
+    // (S3_KNN_COOP_MIN cells; S3_KNN_COOP=1 forces it for every batch, =0 switches it off).
+    const bool coop = d_parents != nullptr && knn_coop_enabled() && (n >= knn_coop_min_cells() || knn_coop_forced());
+    // how far (in bucket sides) the box reaches beyond the child points: the radius of the ball that holds k points at the
+    // index's average occupancy, plus a margin (S3_KNN_COOP_MARGIN, default 1.15); where the cloud is thinner than that the
+    // wavefront notices (fewer than k candidates inside its safe radius) and leaves the cell to the per-lane kernel
+    const double occupancy = (double)knn->n / (double)knn->ncell;
+    const double ball = dim == 3 ? std::cbrt(3.0 * k / (4.0 * 3.14159265358979323846 * occupancy))
+                                 : std::sqrt(k / (3.14159265358979323846 * occupancy));
+    const double reach = ball * knn_coop_margin();
+    // behind the n * (2^dim + 1) doubles of d_scratch: a counter and the list of the queries left to the per-lane search
+    int32_t *d_rest = reinterpret_cast<int32_t *>(d_scratch + n * ((1 << dim) + 1));
+    if (coop) S3_HIP_CHECK(hipMemsetAsync(d_rest, 0, 2 * sizeof(int32_t), st));
     if (dim == 2) {
-        if (d_parents) S3_CHILD_METRIC(2, true, 4); else S3_CHILD_METRIC(2, false, 5);
+        if (coop) S3_CHILD_COOP(2); else if (d_parents) S3_CHILD_METRIC(2, true, 4); else S3_CHILD_METRIC(2, false, 5);
         child_gain_kernel<2><<<grid_for(n, 256), 256, 0, st>>>(d_scratch, d_level, first, n, d_level_factor, gain0,
                                                               d_metric, d_gain);
     } else {
-        if (d_parents) S3_CHILD_METRIC(3, true, 8); else S3_CHILD_METRIC(3, false, 9);
+        if (coop) S3_CHILD_COOP(3); else if (d_parents) S3_CHILD_METRIC(3, true, 8); else S3_CHILD_METRIC(3, false, 9);
         child_gain_kernel<3><<<grid_for(n, 256), 256, 0, st>>>(d_scratch, d_level, first, n, d_level_factor, gain0,
                                                               d_metric, d_gain);
     }
 #undef S3_CHILD_METRIC
+#undef S3_CHILD_COOP
     S3_LAUNCH_CHECK();
     return S3_OK;
 }

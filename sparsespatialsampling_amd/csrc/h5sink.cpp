@@ -21,6 +21,7 @@
 #include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <mutex>
@@ -146,9 +147,19 @@ struct s3h5_file {
     }
 
     // the second descriptor of the file (without it every dataset goes through H5Dwrite)
+    // The raw path (values written with pwrite() at the datasets' offsets through a second descriptor) assumes the file IS
+    // the plain POSIX file HDF5 writes through: only with the sec2 driver, and not when S3_H5_RAW_WRITES=0 asks for
+    // H5Dwrite throughout.  (Called with g_hdf5 held.)
     bool raw_ready() {
         if (raw_fd < 0 && !raw_refused) {
-            raw_fd = ::open(os_path.c_str(), O_WRONLY);
+            const char *sw = getenv("S3_H5_RAW_WRITES");
+            bool sec2 = false;
+            const hid_t fapl = H5Fget_access_plist(fid);
+            if (fapl >= 0) {
+                sec2 = H5Pget_driver(fapl) == H5FD_SEC2;
+                H5Pclose(fapl);
+            }
+            if (sec2 && !(sw && sw[0] == '0')) raw_fd = ::open(os_path.c_str(), O_WRONLY);
             raw_refused = raw_fd < 0;
         }
         return raw_fd >= 0;
@@ -228,6 +239,7 @@ struct s3h5_file {
             int rc = S3H5_OK, n_skipped = 0;
             std::string msg;
             std::vector<Segment> segs;
+            std::vector<const Job *> raw_jobs;                // datasets that exist in the file but hold no values yet
             {
                 std::lock_guard<std::mutex> h(g_hdf5);
                 for (const Job &j : batch) {
@@ -237,8 +249,10 @@ struct s3h5_file {
                     } else if (j.ndim >= 1 && j.bytes >= ((size_t)1 << 20) && raw_ready()) {
                         off_t off = -1;
                         r = create_raw_locked(j.path, j.dtype, j.ndim, j.dims, &off);
-                        if (r == S3H5_OK && off >= 0) segs.push_back({off, static_cast<const char *>(j.data), j.bytes});
-                        else if (r == S3H5_OK) r = write_existing_locked(j.path, j.dtype, j.data);
+                        if (r == S3H5_OK && off >= 0) {
+                            segs.push_back({off, static_cast<const char *>(j.data), j.bytes});
+                            raw_jobs.push_back(&j);
+                        } else if (r == S3H5_OK) r = write_existing_locked(j.path, j.dtype, j.data);
                     } else {
                         r = write_locked(j.path, j.dtype, j.ndim, j.dims, j.data);
                     }
@@ -247,12 +261,26 @@ struct s3h5_file {
                 }
                 if (!segs.empty()) H5Fflush(fid, H5F_SCOPE_LOCAL);      // the datasets' space exists in the file before it is written to
             }
-            if (rc == S3H5_OK) {
-                const int e = write_segments(segs);
-                if (e != 0) {
-                    rc = S3H5_EIO;
-                    msg = std::string("raw write failed: ") + strerror(e);
+            int raw_errno = 0;
+            if (rc == S3H5_OK) raw_errno = write_segments(segs);
+            if ((rc != S3H5_OK || raw_errno != 0) && !raw_jobs.empty()) {
+                // A dataset created for the raw path (space allocated, no fill values) whose values did not arrive -- another
+                // dataset of the batch failed, or pwrite did (a full disk) -- must not stay in the file as a hole that a re-run with
+                // append_existing would take for data: its values go through H5Dwrite now, and if that fails too the dataset
+                // is unlinked.
+                std::lock_guard<std::mutex> h(g_hdf5);
+                for (const Job *j : raw_jobs) {
+                    if (write_existing_locked(j->path, j->dtype, j->data) != S3H5_OK) {
+                        H5Ldelete(fid, j->path.c_str(), H5P_DEFAULT);
+                        if (rc == S3H5_OK) {
+                            rc = S3H5_EIO;
+                            msg = std::string("raw write failed (") + (raw_errno ? strerror(raw_errno) : "batch aborted") +
+                                  ") and so did H5Dwrite: " + g_err + "; the dataset was removed";
+                        }
+                    }
                 }
+                raw_refused = true;                           // no further raw writes to this file
+                if (raw_fd >= 0) { ::close(raw_fd); raw_fd = -1; }
             }
             {
                 std::lock_guard<std::mutex> lk(m);

@@ -102,7 +102,9 @@ class _Topology:
         self._submit(2, cells)
 
     def sync(self):
-        """wait for the submitted updates; raises if one of them failed"""
+        """wait for the submitted updates; raises if one of them failed (nothing to wait for once the engine is closed)"""
+        if getattr(self, "_h_raw", None) is None:
+            return
         rc = self._lib.s3t_sync(self._h)
         if rc == -2:
             raise MemoryError("topology engine: out of host memory")

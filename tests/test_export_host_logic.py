@@ -283,13 +283,16 @@ def test_append_and_file_per_field(export_mod, tmp_path):
         assert os.path.exists(os.path.join(str(tmp_path), f"split_{field}.xdmf"))
 
 
-def test_large_snapshots_take_the_raw_write_path_and_read_back(tmp_path):
-    """datasets of a megabyte or more are created by HDF5 (space allocated at creation) and their values written by several
+@pytest.mark.parametrize("raw", ["1", "0"])
+def test_large_snapshots_take_the_raw_write_path_and_read_back(tmp_path, monkeypatch, raw):
+    """(raw = "0": S3_H5_RAW_WRITES=0 sends everything through H5Dwrite -- the switch for files that are not plain POSIX files)
+    datasets of a megabyte or more are created by HDF5 (space allocated at creation) and their values written by several
     threads straight into the file at the offsets HDF5 reports: the file must read back -- through the library -- exactly
     as written, also mixed with small datasets, a second batch, an existing dataset in the batch and a re-opened file"""
     from sparsespatialsampling_amd import h5io
     if h5io.native_lib() is None:
         pytest.skip("native HDF5 sink not built")
+    monkeypatch.setenv("S3_H5_RAW_WRITES", raw)
     rng = np.random.default_rng(11)
     path = os.path.join(str(tmp_path), "raw.h5")
     n = 300_001                                               # 2.4 MB per scalar snapshot, not a multiple of anything

@@ -149,3 +149,15 @@ def test_c1_cylinder2d_full_size(oracle_backend):
 def test_refine_random_configurations_grid_oracle(oracle_grid_backend, seed):
     """the same reference grids with the oracle's bucket-grid neighbour search (what bench.py times as the CPU port)"""
     check_random_case(seed)
+
+
+def test_close_twice_is_harmless(oracle_backend):
+    """``SamplingTree.close()`` is an optional early release: calling it again (or after an exception handler already did)
+    must not raise -- also on the host topology engine (2:1 balance mode), whose ``sync`` used to insist on a live handle"""
+    x, y, geos, kw = refine_inputs("refine_2d_delta", geometry)
+    tree = s_cube.SamplingTree(pt.from_numpy(x), pt.from_numpy(y), geometry_obj=geos, **kw)
+    tree.refine()
+    centers = tree.all_centers.clone()
+    tree.close()
+    tree.close()
+    assert pt.equal(tree.all_centers, centers)                # the results stay valid

@@ -302,12 +302,56 @@ def device_resident_input(x, centers, k, t_list, bare_ms):
     return out
 
 
+def bench_svd(args, json_fd):
+    """`--workload svd`: the weighted Gram matrix of the interpolated snapshot matrix on the f64 matrix cores
+    (s3_weighted_gram: the kernel of utils.compute_svd, reference utils.py:302-346) at the bench grid's size -- 461 130 cells x
+    1000 snapshots f64 resident in HBM, a step = one launch.  MFMA-bound: algorithmic flops N * T * (T + 1) (upper triangle)
+    against AMD's datasheet peak for f64 matrix operations (78.6 TFLOP/s; the guide lists none) and against the rate a bare
+    loop of the same instruction sustains on this pool (46 TFLOP/s, tools/mfma_f64_peak.hip).  Eigen-solve and mode GEMM of
+    compute_svd are vendor-library calls (rocSOLVER / rocBLAS through torch): timed in `compute_svd_s`, not in `value`."""
+    from sparsespatialsampling_amd import svd, metrics
+    n, t = 461_130, args.t_batch or 1000
+    gen = pt.Generator(device="cuda").manual_seed(7)
+    x = pt.empty((n, t), dtype=pt.float64, device="cuda").normal_(generator=gen)
+    x += pt.linspace(0, 3, t, dtype=pt.float64, device="cuda").sin() * pt.empty((n, 1), dtype=pt.float64, device="cuda").normal_(generator=gen)
+    w = pt.empty(n, dtype=pt.float64, device="cuda").uniform_(0.05, 0.55, generator=gen)
+    mean = metrics.temporal_mean(x)
+    ms = launch_times_ms(lambda: svd.weighted_gram(x, mean, w), args.steps, args.warmup)
+    pt.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        svd.weighted_gram(x, mean, w)
+    pt.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    flops = float(n) * t * (t + 1)
+    st = ms_stats(ms)
+    t1 = time.perf_counter()
+    s_, u_, v_ = svd.compute_svd(x, w, rank=50)
+    pt.cuda.synchronize()
+    svd_s = time.perf_counter() - t1
+    achieved = flops / (st["kernel_ms"] * 1e-3) / 1e12
+    res = {"metric": "TFLOP/s weighted Gram matrix (f64 matrix cores)", "value": flops * args.steps / elapsed / 1e12, "unit": "TFLOP/s",
+           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": f"svd: weighted Gram matrix of {n} cells x {t} snapshots f64 (the bench grid's interpolated field)",
+                      "n_cells": n, "t_batch": t},
+           "device": device_identity(),
+           "roofline": {"bound": "mfma", "achieved": achieved, "peak": 78.6, "unit": "TFLOP/s", "frac": achieved / 78.6,
+                        "peak_source": "AMD MI355X datasheet, f64 matrix (the CDNA4 guide lists no f64 figure)",
+                        "sustained_instruction_rate": 46.0, "frac_of_sustained": achieved / 46.0,
+                        "sustained_source": "bare v_mfma_f64_16x16x4_f64 loop, operands in registers (tools/mfma_f64_peak.hip, DESIGN 5.6)",
+                        "kernel": "gram_block_kernel", "algorithmic_flops": flops, "traffic": None, **st},
+           "compute_svd_s": svd_s, "compute_svd_rank": int(len(s_)),
+           "compute_svd_note": "mean + Gram kernel + eigen-solve (rocSOLVER) + mode GEMM (rocBLAS), rank 50, first call of the process"}
+    os.write(json_fd, (json.dumps(res) + "\n").encode())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="cylinder3D_Re3900", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="cylinder3D_Re3900", choices=sorted(WORKLOADS) + ["svd"])
     ap.add_argument("--t-batch", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baselines, the device-resident and the end-to-end legs (profiling runs)")
     ap.add_argument("--no-batches", action="store_true", help="skip the roofline_batches sub-records")
@@ -343,6 +387,12 @@ def main():
     comm = parallel.init()                 # RCCL communicator inside libs3hip.so when world > 1
     import logging
     logging.getLogger().setLevel(logging.WARNING)
+    if args.workload == "svd":             # the downstream consumer: its own line, its own roofline
+        if world != 1:
+            ap.error("--workload svd is a single-GPU measurement")
+        bench_svd(args, json_fd)
+        parallel.shutdown()
+        return
 
     cfg = dict(WORKLOADS[args.workload])
     if args.t_batch:

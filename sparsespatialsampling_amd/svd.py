@@ -16,9 +16,17 @@ How it runs on the MI355X (method of snapshots; the snapshot count T is small ag
 
 The reference delegates to ``flowtorch.analysis.SVD`` (absent here): ``rank=None`` selects the optimal hard threshold of
 Gavish & Donoho as flowtorch documents it (``opt_rank``); that selection rule is restated from the documentation, not pinned
-against flowtorch.  Unlike the reference the caller's ``data_matrix`` is not modified.  Squaring the matrix halves the
-attainable relative accuracy of the small singular values (about sqrt(eps) * s_max); the leading modes -- what
-``write_svd_s_cube_to_file`` stores, utils.py:349-413 -- are unaffected.
+against flowtorch.  Unlike the reference the caller's ``data_matrix`` is not modified.
+
+Accuracy.  An eigenvalue of the Gram matrix carries an absolute error of about eps * s_max^2, i.e. a singular value s a
+relative error of eps * (s_max / s)^2: fine down to s / s_max ~ 1e-3 (1e-10), useless below 1e-8.  The leading modes -- what
+``write_svd_s_cube_to_file`` stores -- never get there, but the optimal-rank rule takes the MEDIAN of the spectrum, which for
+low-noise data lies far below.  Whenever a singular value that matters (all of them for ``rank=None``, the requested ones
+otherwise) falls under 1e-3 * s_max the spectrum is therefore refined by DEFLATION (``_spectrum``): the modes found so far
+are projected out of the data (one library GEMM), the Gram matrix of the residual -- whose largest singular value is now
+1e-3 of the previous level's -- is taken by the same kernel, and so on for up to three levels; the result has the absolute
+accuracy of a direct SVD (about eps * s_max; ``torch.linalg.svd`` of the float64 matrix is the checker,
+tests/test_gpu_kernels.py::test_compute_svd_small_singular_values).
 """
 import ctypes as C
 from typing import Tuple
@@ -42,11 +50,58 @@ def _eigh(g: pt.Tensor):
     """symmetric eigenproblem of the small T x T Gram matrix: the vendor's dense solver on the device (a plain library call;
     1000 x 1000 float64: ~0.1 s against ~0.8 s with LAPACK on the host), LAPACK on the host if that is not available;
     results on the host"""
-    try:
-        lam, vec = pt.linalg.eigh(g)
-        return lam.cpu(), vec.cpu()
-    except RuntimeError:
+    # scaled to a unit diagonal maximum first: the device solver works with an absolute tolerance -- on the Gram matrix of a
+    # deflated residual (entries of 1e-12 and below) it returned eigenvalues with a relative error of 4e-6 where the scaled
+    # call gives 1e-14 (tools/svd_accuracy_probe.py)
+    scale = g.diagonal().max()
+    if not bool(scale > 0):
         return pt.linalg.eigh(g.cpu())
+    try:
+        lam, vec = pt.linalg.eigh(g / scale)
+        return (lam * scale).cpu(), vec.cpu()
+    except RuntimeError:
+        lam, vec = pt.linalg.eigh((g / scale).cpu())
+        return lam * scale.cpu(), vec
+
+
+LEVEL_RANGE = 1e-3          # singular values down to this fraction of a level's largest one are taken from that level's Gram matrix
+MAX_LEVELS = 4
+
+
+def _spectrum(x2: pt.Tensor, mean: pt.Tensor, w: pt.Tensor, wanted):
+    """all singular values (descending, host) and right singular vectors [T, T] (host) of sqrt(w) * (x2 - mean): Gram matrix +
+    symmetric eigenproblem, refined by deflation where the values that matter (the first ``wanted``; all for None) reach
+    below ``LEVEL_RANGE`` of the largest one of a level (module docstring)"""
+    n, t = int(x2.shape[0]), int(x2.shape[1])
+    zeros = None
+    data, mu = x2, mean
+    s_parts, v_parts, found = [], [], 0
+    for level in range(MAX_LEVELS):
+        lam, vec = _eigh(weighted_gram(data, mu, w))              # ascending; T x T
+        lam, vec = lam.flip(0).clamp_min(0.0), vec.flip(1)
+        lam, vec = lam[:t - found], vec[:, :t - found]            # (the directions already found come out as ~0: dropped)
+        if found:                                                 # keep the new vectors in the complement of the old ones
+            basis = pt.cat(v_parts, dim=1)
+            vec = vec - basis @ (basis.T @ vec)
+            vec, _ = pt.linalg.qr(vec)
+        s_level = lam.sqrt()
+        good = int((lam >= lam[0] * LEVEL_RANGE ** 2).sum()) if float(lam[0]) > 0 else 0
+        need_more = good < len(lam) and (wanted is None or found + good < wanted) and level + 1 < MAX_LEVELS and good > 0
+        if not need_more:
+            s_parts.append(s_level)
+            v_parts.append(vec)
+            break
+        s_parts.append(s_level[:good])
+        v_parts.append(vec[:, :good])
+        found += good
+        # the residual: (X - mean 1^T) (I - V V^T) as a matrix of its own (mean zero by construction)
+        basis = pt.cat(v_parts, dim=1).to(x2.device)              # [T, found]
+        proj = pt.eye(t, dtype=pt.float64, device=x2.device) - basis @ basis.T
+        data = x2 @ proj - mean.reshape(-1, 1) * proj.sum(0, keepdim=True)
+        if zeros is None:
+            zeros = pt.zeros(n, dtype=pt.float64, device=x2.device)
+        mu = zeros
+    return pt.cat(s_parts), pt.cat(v_parts, dim=1)
 
 
 def weighted_gram(x: pt.Tensor, mean: pt.Tensor, weight: pt.Tensor) -> pt.Tensor:
@@ -84,10 +139,7 @@ def compute_svd(data_matrix: pt.Tensor, cell_area: pt.Tensor, rank: int = None) 
     else:
         x2, w = x, area
     mean = metrics.temporal_mean(x2)
-    g = weighted_gram(x2, mean, w)
-    lam, vec = _eigh(g)                                       # ascending; T x T
-    lam, vec = lam.flip(0).clamp_min(0.0), vec.flip(1)
-    s_all = lam.sqrt()
+    s_all, vec = _spectrum(x2, mean, w, None if rank is None else min(int(rank), t))
     r = optimal_rank(s_all, x2.shape[0], t) if rank is None else min(int(rank), t)
     keep = s_all[:r] > s_all[0] * 1e-14 if r else s_all[:0] > 0
     r = int(keep.sum()) if r else 0

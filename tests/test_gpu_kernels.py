@@ -691,6 +691,42 @@ def test_compute_svd_vs_torch(shape, rank):
     assert (recon - best).abs().max() <= 1e-8 * s_ref[0]
 
 
+def test_compute_svd_small_singular_values():
+    """a spectrum that falls over nine decades: the Gram matrix alone returns noise below
+    sqrt(eps) * s_max; with the deflation levels every singular value has the absolute accuracy of a direct SVD (compared
+    with torch.linalg.svd of the float64 matrix: 1e-12 * s_max, i.e. 1e-3 relative at s / s_max = 1e-9 and 1e-10 at 1e-2), the
+    optimal-rank rule -- which takes the MEDIAN of the spectrum -- agrees with the one evaluated on the reference spectrum,
+    and the requested modes are those of the direct SVD"""
+    from sparsespatialsampling_amd import svd
+    rng = np.random.default_rng(5)
+    n, t = 6000, 40
+    q1, _ = np.linalg.qr(rng.standard_normal((n, t)))
+    q2, _ = np.linalg.qr(rng.standard_normal((t, t)))
+    spectrum = 10.0 ** np.linspace(0, -9, t)
+    area = rng.random(n) * 0.5 + 0.05
+    centred = (q1 * spectrum) @ q2.T
+    centred -= centred.mean(1, keepdims=True)                     # compute_svd removes the temporal mean itself
+    data = pt.from_numpy(centred / np.sqrt(area)[:, None] + rng.standard_normal((n, 1)) * 5.0)
+    xw = (data - data.mean(-1, keepdim=True)) * pt.from_numpy(np.sqrt(area))[:, None]
+    u_ref, s_ref, vt_ref = pt.linalg.svd(xw, full_matrices=False)
+    assert float(s_ref[-2] / s_ref[0]) < 1e-8                     # the spectrum really reaches that far down
+    s, u, v = svd.compute_svd(data, pt.from_numpy(area), rank=t - 1)     # (the last value is the removed mean: ~0)
+    assert len(s) == t - 1
+    assert float((s - s_ref[:t - 1]).abs().max()) <= 1e-12 * float(s_ref[0])
+    big = s_ref[:t - 1] >= 1e-6 * s_ref[0]
+    assert pt.allclose(s[big], s_ref[:t - 1][big], rtol=1e-9, atol=0)
+    # without the refinement the same call is off by orders of magnitude at the small end
+    plain = pt.linalg.eigvalsh(xw.T @ xw).flip(0).clamp_min(0).sqrt()
+    assert float((plain[:t - 1] - s_ref[:t - 1]).abs().max()) > 1e-10 * float(s_ref[0])
+    s_auto, _, _ = svd.compute_svd(data, pt.from_numpy(area), rank=None)
+    assert len(s_auto) == svd.optimal_rank(s_ref, n, t)
+    lead = 12
+    uw = u[:, :lead] * pt.from_numpy(np.sqrt(area))[:, None]
+    sign = pt.sign((uw * u_ref[:, :lead]).sum(0))
+    assert (uw * sign - u_ref[:, :lead]).abs().max() <= 1e-6
+    assert (v[:, :lead] * sign - vt_ref[:lead].T).abs().max() <= 1e-6
+
+
 # ---- RCCL communicator inside the library (SURVEY 8(e)) -------------------------------------------------------------
 def test_rccl_comm_single_rank_roundtrip():
     """the s3_comm_* entry points on hardware with a one-rank communicator (a one-GPU box cannot host more ranks on RCCL):

@@ -27,6 +27,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <exception>
+#include <type_traits>
 #include <vector>
 
 struct s3_interp_plan : s3::PlanTables {
@@ -47,6 +48,13 @@ namespace s3 {
 
 constexpr int PL_SEG = 128;        // bytes of one row staged per chunk
 constexpr int PL_NP = 16;          // staging passes of (tile cells)/2 rows -> at most 8 * (tile cells) distinct rows
+#ifndef S3_PL_LP
+#define S3_PL_LP 8
+#endif
+constexpr int PL_LP = S3_PL_LP;    // LDS row pitch of the persistent kernel in 16-byte vectors.  9 (144 bytes: the rows of the cells a
+                                   // wavefront accumulates together then start in different banks) was measured against 8 in
+                                   // alternating processes on one box: 0.167 / 0.152 / 0.457 ms against 0.167 / 0.149 / 0.466 ms at
+                                   // 25 / 32 / 128 snapshots -- the bank conflicts are not on the critical path
 
 template <typename T>
 struct Vec16;
@@ -446,45 +454,15 @@ interp_planned_kernel(const int32_t *__restrict__ perm, const int32_t *__restric
 #undef S3_STORE_B
 #undef S3_DECL
 
-// 16 bytes of a source row.  ALIGNED: the row starts on a 16-byte boundary and is readable up to the next multiple of 16
-// bytes (pitched batches).  Otherwise (a batch read where it lies, [N, n_comp*T] dense: rows start on element boundaries
-// only) the vector is loaded with element alignment, and the ragged tail of a row -- `valid` < EPV elements -- as the
-// LAST EPV elements of the row (the load ends where the row ends; nothing beyond the row is touched), to be rotated into
-// place by rotate_tail.  One load instruction per piece on every path: the s_waitcnt counts of the caller stay exact.
-template <typename T> struct VecElemAligned;
-template <> struct VecElemAligned<float> { typedef float type __attribute__((ext_vector_type(4), aligned(4))); };
-template <> struct VecElemAligned<double> { typedef double type __attribute__((ext_vector_type(2), aligned(8))); };
-
-template <typename T, bool ALIGNED>
-__device__ __forceinline__ typename Vec16<T>::type load_piece(const T *__restrict__ p, int valid) {
-    using V = typename Vec16<T>::type;
-    constexpr int EPV = Vec16<T>::N;
-    if constexpr (ALIGNED) {
-        return *reinterpret_cast<const V *>(p);
-    } else {
-        const typename VecElemAligned<T>::type u = *reinterpret_cast<const typename VecElemAligned<T>::type *>(p - (EPV - valid));
-        V r;
-        T *re = reinterpret_cast<T *>(&r);
-#pragma unroll
-        for (int i = 0; i < EPV; ++i) re[i] = u[i];
-        return r;
-    }
-}
-// a piece loaded by load_piece<T, false> with `valid` < EPV holds its elements in the upper lanes: move them down
-template <typename T>
-__device__ __forceinline__ void rotate_tail(typename Vec16<T>::type &v, int valid) {
-    constexpr int EPV = Vec16<T>::N;
-    T *e = reinterpret_cast<T *>(&v);
-    const int sh = EPV - valid;
-#pragma unroll
-    for (int i = 0; i < EPV; ++i) {
-        T x = e[i];
-#pragma unroll
-        for (int s = 1; s < EPV; ++s)
-            if (i + s < EPV) x = sh == s ? e[i + s] : x;
-        e[i] = x;
-    }
-}
+// Rows that start on element boundaries only (a dense [N, n_comp * T] batch read where it lies: 25 fp32 snapshots make
+// 100-byte rows).  A 16-byte load that is not 16-byte aligned runs at a quarter of the rate on this chip (measured: 0.69 ms
+// against 0.17 ms for the pitched copy of the same batch), so the lanes load ALIGNED vectors -- the eight that cover the
+// 7-vector chunk [a, a + 112) of the row, starting at a rounded down to 16 bytes -- and the shift by (a mod 16) / 4 dwords
+// is undone on the way into LDS: four ds_write_b32 per lane at shifted positions (as cheap as the one ds_write_b128 they
+// replace) into a row image of 9 vectors, one vector of slack in front.  Nothing outside the 16-byte blocks that hold the
+// row's own bytes is read (aligned blocks never straddle a page).
+struct StreamLayoutAligned   { static constexpr int CHUNK_VECS = 8, LP = PL_LP, VOFF = 0; };
+struct StreamLayoutUnaligned { static constexpr int CHUNK_VECS = 7, LP = 9, VOFF = 1; };
 
 // Short and medium batches (the reference exports cylinder3D in batches of 25 snapshots, examples/s3_for_cylinder3D_Re3900.py:
 // 28-69 -> utils.py:204: rows of 100 or 300 bytes): a tile has one to a few column chunks, so the start-up of a tile --
@@ -511,18 +489,18 @@ __device__ __forceinline__ void rotate_tail(typename Vec16<T>::type &v, int vali
 // ONE basic block (with a run-time k every neighbour sits behind its own branch), and the LDS reads of the next pair are
 // issued before the current pair is accumulated -- left to itself the compiler reads a neighbour's two vectors into the same
 // registers every time and waits for them at once: 26 exposed LDS round trips per step.
-template <int M, int K, bool BOTH, typename T>
+template <int M, int K, bool BOTH, typename T, typename LAY>
 __device__ __forceinline__ void stream_read_pair(const int (&pq)[(K + 3) / 4], const typename Vec16<T>::type *__restrict__ s_data,
                                                  int v0, typename Vec16<T>::type (&buf)[4]) {
     if constexpr (M < K) {
         const int pos = quad_bcast_i32<M % 4>(pq[M / 4]);
-        buf[0] = s_data[pos * 8 + v0];
-        if constexpr (BOTH) buf[1] = s_data[pos * 8 + v0 + 4];
+        buf[0] = s_data[pos * LAY::LP + LAY::VOFF + v0];
+        if constexpr (BOTH) buf[1] = s_data[pos * LAY::LP + LAY::VOFF + v0 + 4];
     }
     if constexpr (M + 1 < K) {
         const int pos = quad_bcast_i32<(M + 1) % 4>(pq[(M + 1) / 4]);
-        buf[2] = s_data[pos * 8 + v0];
-        if constexpr (BOTH) buf[3] = s_data[pos * 8 + v0 + 4];
+        buf[2] = s_data[pos * LAY::LP + LAY::VOFF + v0];
+        if constexpr (BOTH) buf[3] = s_data[pos * LAY::LP + LAY::VOFF + v0 + 4];
     }
 }
 
@@ -570,18 +548,18 @@ __device__ __forceinline__ void stream_fma_row(double wm, const double2 &a, cons
 
 // BOTH = false: the upper four vectors of the chunk lie beyond the end of the row (the last chunk of a ragged row) -- nobody
 // reads or accumulates them
-template <int M, int K, bool BOTH, typename T>
+template <int M, int K, bool BOTH, typename T, typename LAY>
 __device__ __forceinline__ void stream_accumulate(const double (&wq)[(K + 3) / 4], const int (&pq)[(K + 3) / 4],
                                                   const typename Vec16<T>::type *__restrict__ s_data, int v0,
                                                   typename Vec16<T>::type (&cur)[4], typename Vec16<T>::type (&nxt)[4],
                                                   double (&acc0)[Vec16<T>::N], double (&acc1)[Vec16<T>::N]) {
     if constexpr (M < K) {
-        stream_read_pair<M + 2, K, BOTH, T>(pq, s_data, v0, nxt);
+        stream_read_pair<M + 2, K, BOTH, T, LAY>(pq, s_data, v0, nxt);
         __builtin_amdgcn_sched_barrier(0);
         stream_fma_row<BOTH>(quad_bcast_f64<M % 4>(wq[M / 4]), cur[0], cur[1], acc0, acc1);
         if constexpr (M + 1 < K) stream_fma_row<BOTH>(quad_bcast_f64<(M + 1) % 4>(wq[(M + 1) / 4]), cur[2], cur[3], acc0, acc1);
         __builtin_amdgcn_sched_barrier(0);
-        stream_accumulate<M + 2, K, BOTH, T>(wq, pq, s_data, v0, nxt, cur, acc0, acc1);
+        stream_accumulate<M + 2, K, BOTH, T, LAY>(wq, pq, s_data, v0, nxt, cur, acc0, acc1);
     }
 }
 
@@ -594,13 +572,14 @@ interp_planned_stream_kernel(const int32_t *__restrict__ perm, const int32_t *__
                              double *__restrict__ dump, const int32_t *__restrict__ sched_begin,
                              const int32_t *__restrict__ sched_tiles, int n_chunks) {
     using V = typename Vec16<T>::type;
+    using LAY = std::conditional_t<ALIGNED, StreamLayoutAligned, StreamLayoutUnaligned>;
     constexpr int EPV = Vec16<T>::N;
-    constexpr int EPC = PL_SEG / (int)sizeof(T);
+    constexpr int EPC = LAY::CHUNK_VECS * EPV;       // elements of a row per step
     constexpr int BLOCK = 256, RPP = BLOCK / 8;
     constexpr int KQ = (K + 3) / 4, k = K;           // every lane of a quad holds KQ entries of its cell's tables
     extern __shared__ float4 lds_raw[];
-    V *s_data = reinterpret_cast<V *>(lds_raw);                                           // [PL_NP * RPP][8] 16-byte vectors
-    int32_t *s_ids = reinterpret_cast<int32_t *>(lds_raw + (size_t)PL_NP * RPP * 8);      // [2 * BLOCK] row ids of the issue tile
+    V *s_data = reinterpret_cast<V *>(lds_raw);                                           // [PL_NP * RPP][LP] 16-byte vectors
+    int32_t *s_ids = reinterpret_cast<int32_t *>(lds_raw + (size_t)PL_NP * RPP * LAY::LP);  // [2 * BLOCK] row ids of the issue tile
 
     const int tid = threadIdx.x;
     // this workgroup's tiles: sched_tiles[my_begin .. my_begin + n_my) (plan_schedule below)
@@ -611,7 +590,6 @@ interp_planned_stream_kernel(const int32_t *__restrict__ perm, const int32_t *__
     const int srow = tid >> 3, svec = tid & 7;       // staging role: 8 lanes per 128-byte segment
     const int qcl = tid >> 2, v0 = tid & 3;          // accumulate role: 4 lanes per cell, vectors v0 and v0 + 4
     double *const dump_lane = dump + ((int64_t)blockIdx.x * BLOCK + tid) * 2;
-    const bool ragged = !ALIGNED && row_len % EPV != 0;
     const uint32_t stride32 = (uint32_t)in_stride;   // (row pitch in elements < 2^31: one v_mad_u64_u32 per row address)
 
 #define S3S_DECL(P) int rid##P = 0; V pre##P;
@@ -644,17 +622,41 @@ interp_planned_stream_kernel(const int32_t *__restrict__ perm, const int32_t *__
         celln = perm[cb + cl];
     };
 #define S3S_RID(P) rid##P = s_ids[min(P * RPP + srow, nr_n - 1)];
-#define S3S_LOAD(P) pre##P = load_piece<T, ALIGNED>(data + (uint64_t)(uint32_t)rid##P * stride32 + col_, valid_);
+    // ALIGNED: lane svec loads vector svec of the chunk (a dummy -- the chunk's first vector -- beyond the end of the row).
+    // Otherwise: the aligned 16-byte block number svec counted from the block that holds the chunk's first byte (a dummy -- that
+    // first block -- where the block lies wholly behind the chunk's last valid byte).
+#define S3S_LOAD(P)                                                                                                          \
+    do {                                                                                                                     \
+        const T *a_ = data + (uint64_t)(uint32_t)rid##P * stride32 + c0_;                                                    \
+        if constexpr (ALIGNED) {                                                                                             \
+            pre##P = *reinterpret_cast<const V *>(a_ + (ok_ ? svec : 0) * EPV);                                              \
+        } else {                                                                                                             \
+            const uintptr_t a0_ = reinterpret_cast<uintptr_t>(a_) & ~(uintptr_t)15;                                          \
+            const uintptr_t p_ = a0_ + 16u * (unsigned)svec;                                                                 \
+            pre##P = *reinterpret_cast<const V *>(p_ < reinterpret_cast<uintptr_t>(a_) + valid_bytes_ ? p_ : a0_);           \
+        }                                                                                                                    \
+    } while (0);
 #define S3S_ISSUE(CH)                                                                    \
     do {                                                                                 \
         const int64_t c0_ = (int64_t)(CH) * EPC;                                         \
         const bool ok_ = c0_ + (int64_t)svec * EPV < row_len;                            \
-        const int64_t col_ = c0_ + (ok_ ? svec : 0) * EPV;                               \
-        const int valid_ = (int)min((int64_t)EPV, row_len - col_);                       \
+        const uintptr_t valid_bytes_ = (uintptr_t)min((int64_t)EPC, row_len - c0_) * sizeof(T);   \
+        (void)ok_; (void)valid_bytes_;                                                   \
         S3_REP16(S3S_LOAD)                                                               \
     } while (0)
-#define S3S_ROTATE(P) rotate_tail<T>(pre##P, valid_);
-#define S3S_STORE(P) s_data[(P * RPP + srow) * 8 + svec] = pre##P;
+    // (the row ids in rid* are those the segments in pre* were loaded with: ids and segments are renewed together)
+#define S3S_STORE(P)                                                                                                         \
+    do {                                                                                                                     \
+        if constexpr (ALIGNED) {                                                                                             \
+            s_data[(P * RPP + srow) * LAY::LP + svec] = pre##P;                                                              \
+        } else {                                                                                                             \
+            const T *a_ = data + (uint64_t)(uint32_t)rid##P * stride32 + store_c0_;                                          \
+            const int ph_ = (int)((reinterpret_cast<uintptr_t>(a_) >> 2) & 3);                                               \
+            uint32_t *row_ = reinterpret_cast<uint32_t *>(s_data) + (P * RPP + srow) * (LAY::LP * 4) + 4 + 4 * svec - ph_;   \
+            const uint32_t *w_ = reinterpret_cast<const uint32_t *>(&pre##P);                                                \
+            row_[0] = w_[0]; row_[1] = w_[1]; row_[2] = w_[2]; row_[3] = w_[3];                                              \
+        }                                                                                                                    \
+    } while (0);
 
     // prologue: the first tile's ids are the one exposed round trip of the workgroup
     load_ids(first);
@@ -687,12 +689,8 @@ interp_planned_stream_kernel(const int32_t *__restrict__ perm, const int32_t *__
         for (int c = 0; c < n_chunks; ++c) {
             const bool last_chunk = c + 1 == n_chunks;
             const bool enter_next = last_chunk && j + 1 < n_my;      // the issue pointer moves on to this workgroup's next tile
-            if (ragged && last_chunk) {              // (uniform) the ragged tail of an element-aligned row: into place
-                const int64_t c0_ = (int64_t)c * EPC;
-                const bool ok_ = c0_ + (int64_t)svec * EPV < row_len;
-                const int valid_ = (int)min((int64_t)EPV, row_len - (c0_ + (ok_ ? svec : 0) * EPV));
-                S3_REP16(S3S_ROTATE)
-            }
+            const int64_t store_c0_ = (int64_t)c * EPC;
+            (void)store_c0_;
             S3_REP16(S3S_STORE)
             if (enter_next) {
                 s_ids[tid] = ida;
@@ -718,18 +716,19 @@ interp_planned_stream_kernel(const int32_t *__restrict__ perm, const int32_t *__
 #pragma unroll
             for (int i = 0; i < EPV; ++i) acc0[i] = acc1[i] = 0.0;
             V buf_a[4], buf_b[4];
-            if (col0 + 4 * EPV < row_len) {          // (uniform) the chunk's upper four vectors exist
-                stream_read_pair<0, K, true, T>(pq, s_data, v0, buf_a);
-                stream_accumulate<0, K, true, T>(wq, pq, s_data, v0, buf_a, buf_b, acc0, acc1);
+            if (col0 + 4 * EPV < row_len) {          // (uniform) vectors 4 .. of the chunk exist
+                stream_read_pair<0, K, true, T, LAY>(pq, s_data, v0, buf_a);
+                stream_accumulate<0, K, true, T, LAY>(wq, pq, s_data, v0, buf_a, buf_b, acc0, acc1);
             } else {
-                stream_read_pair<0, K, false, T>(pq, s_data, v0, buf_a);
-                stream_accumulate<0, K, false, T>(wq, pq, s_data, v0, buf_a, buf_b, acc0, acc1);
+                stream_read_pair<0, K, false, T, LAY>(pq, s_data, v0, buf_a);
+                stream_accumulate<0, K, false, T, LAY>(wq, pq, s_data, v0, buf_a, buf_b, acc0, acc1);
             }
             // the same number of stores on every path: what must not be written goes to this lane's dump slot.  Pairs of
             // doubles; rows of odd length start on 8-byte boundaries only (element-aligned 16-byte stores) and end in a
             // single element, which one lane of the cell stores separately.
             double *const orow = out + cell * row_len;
             const int64_t e0 = col0 + (int64_t)v0 * EPV, e1 = col0 + (int64_t)(v0 + 4) * EPV;
+            const bool second = v0 + 4 < LAY::CHUNK_VECS;    // (the chunk of an element-aligned batch has seven vectors)
             typedef double pair_t __attribute__((ext_vector_type(2), aligned(8)));
 #pragma unroll
             for (int i = 0; i < EPV; i += 2) {
@@ -739,7 +738,7 @@ interp_planned_stream_kernel(const int32_t *__restrict__ perm, const int32_t *__
             }
 #pragma unroll
             for (int i = 0; i < EPV; i += 2) {
-                double *p1 = live && e1 + i + 1 < row_len ? orow + e1 + i : dump_lane;
+                double *p1 = live && second && e1 + i + 1 < row_len ? orow + e1 + i : dump_lane;
                 pair_t v = {acc1[i], acc1[i + 1]};
                 *reinterpret_cast<pair_t *>(p1) = v;
             }
@@ -754,8 +753,8 @@ interp_planned_stream_kernel(const int32_t *__restrict__ perm, const int32_t *__
                 }
 #pragma unroll
                 for (int i = 0; i < EPV; i += 2) {
-                    tv = t == e1 + i ? acc1[i] : tv;
-                    mine = mine || t == e1 + i;
+                    tv = second && t == e1 + i ? acc1[i] : tv;
+                    mine = mine || (second && t == e1 + i);
                 }
                 double *pt = live && mine ? orow + t : dump_lane;
                 *pt = tv;
@@ -767,7 +766,6 @@ interp_planned_stream_kernel(const int32_t *__restrict__ perm, const int32_t *__
 #undef S3S_RID
 #undef S3S_LOAD
 #undef S3S_ISSUE
-#undef S3S_ROTATE
 #undef S3S_STORE
 }
 
@@ -887,13 +885,14 @@ static int plan_schedule(s3_interp_plan *p, hipStream_t st) {
 template <typename T, bool ALIGNED, bool EVEN>
 static int launch_stream_e(s3_interp_plan *p, const int32_t *rows, const void *data, int64_t row_len, int64_t in_stride,
                            double *out, hipStream_t st) {
-    constexpr int EPC = PL_SEG / (int)sizeof(T);
+    using LAY = std::conditional_t<ALIGNED, StreamLayoutAligned, StreamLayoutUnaligned>;
+    constexpr int EPC = LAY::CHUNK_VECS * 16 / (int)sizeof(T);
     const int n_chunks = (int)((row_len + EPC - 1) / EPC);
     if (!p->sched_begin) {
         const int rc = plan_schedule(p, st);
         if (rc != S3_OK) return rc;
     }
-    const size_t lds = (size_t)PL_NP * 32 * PL_SEG + 2 * 256 * sizeof(int32_t);
+    const size_t lds = (size_t)PL_NP * 32 * LAY::LP * 16 + 2 * 256 * sizeof(int32_t);
     const size_t dump_doubles = (size_t)p->sched_wgs * 256 * 2;        // one 16-byte slot per lane of the launch
     if (p->dump_doubles < dump_doubles) {
         if (p->dump) (void)hipFree(p->dump);

@@ -194,6 +194,28 @@ def copy_bandwidth_gbs(n_bytes=2 << 30, reps=5):
     return 2.0 * n_bytes * reps / (a.elapsed_time(b) * 1e-3) / 1e9
 
 
+_SMI = {}
+
+
+def query_rocm_smi():
+    """serial / unique id / clock levels of card 0 from rocm-smi -- called BEFORE this process touches the GPU (rocm-smi is a
+    Python script: starting it means an exec in a forked child, which the GPU pool refuses once the parent has initialised the
+    device), and not at all under a profiler whose preloaded library has initialised it already"""
+    if _SMI or "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        _SMI.setdefault("rocm_smi", "not queried (profiler attached)")
+        return
+    try:
+        import subprocess
+        out = subprocess.run(["rocm-smi", "--showuniqueid", "--showserial", "--showclocks", "--json"], capture_output=True,
+                             text=True, timeout=20).stdout
+        card = json.loads(out).get("card0", {})
+        _SMI["unique_id"] = card.get("Unique ID")
+        _SMI["serial"] = card.get("Serial Number")
+        _SMI["clocks"] = {k.split(" ")[0]: v for k, v in card.items() if "clock" in k.lower() and "level" in k.lower()}
+    except Exception as err:                      # no rocm-smi on the box / no permission: the torch fields remain
+        _SMI["rocm_smi"] = f"unavailable: {type(err).__name__}"
+
+
 def device_identity():
     """which card the numbers were taken on: launch times of one binary differ by several per cent between the boxes of a
     pool, so a timing without the device behind it cannot be matched to a profile"""
@@ -201,16 +223,7 @@ def device_identity():
     ident = dict(name=prop.name, gcn_arch=getattr(prop, "gcnArchName", None), compute_units=prop.multi_processor_count,
                  hbm_gib=round(prop.total_memory / 2 ** 30, 1), uuid=str(getattr(prop, "uuid", "")) or None,
                  hostname=os.uname().nodename)
-    try:
-        import subprocess
-        out = subprocess.run(["rocm-smi", "--showuniqueid", "--showserial", "--showclocks", "--json"], capture_output=True,
-                             text=True, timeout=20).stdout
-        card = json.loads(out).get("card0", {})
-        ident["unique_id"] = card.get("Unique ID")
-        ident["serial"] = card.get("Serial Number")
-        ident["clocks"] = {k.split(" ")[0]: v for k, v in card.items() if "clock" in k.lower() and "level" in k.lower()}
-    except Exception as err:                      # no rocm-smi on the box / no permission: the torch fields remain
-        ident["rocm_smi"] = f"unavailable: {type(err).__name__}"
+    ident.update(_SMI)
     return ident
 
 
@@ -376,6 +389,8 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
+    if rank == 0:
+        query_rocm_smi()                   # (before anything initialises the GPU)
     # S3_BENCH_SHARE_GPU=1 + S3_DIST_BACKEND=gloo: rehearsal of the N>1 code path on a box with a single GPU
     share = os.environ.get("S3_BENCH_SHARE_GPU") == "1"
     pt.cuda.set_device(0 if share else local_rank)

@@ -115,10 +115,11 @@ int s3_child_gain(const s3_knn *knn, int k, const double *d_center, const int32_
  * d_child_metric[parent][c].  The n cells first..first+n-1 are children number parents_offset.. of the ORDERED parents
  * d_parents[] (2^dim consecutive cells per parent, as s3_make_children creates them).  d_parents == NULL: all 2^dim + 1
  * points are searched (cells whose parent has no entry: the root).  Either way the children's values of the n cells are
- * stored in d_child_metric.  d_scratch: n*(2^dim+1) doubles + (2 + n*2^dim) int32.  With d_parents every cell is given to
- * one wavefront (shared candidate box of the 2^dim child points, or one box per child point for coarse cells; selection by
- * histogram instead of sorted insertion: csrc/knn.hip); the few queries that scheme cannot answer (refined buckets, ties in
- * distance, k > 48) are listed behind the doubles and searched the per-lane way afterwards. */
+ * stored in d_child_metric.  d_scratch: n*(2^dim+1) doubles + 2*(2 + n*2^dim) int32.  With d_parents every cell is given to
+ * one wavefront (shared candidate box of the 2^dim child points; selection by histogram instead of sorted insertion:
+ * csrc/knn.hip); the queries that scheme cannot answer (coarse cells, points next to a body) are listed behind the doubles
+ * for a streaming search with one wavefront per query, and what that cannot answer either (refined buckets, ties in distance,
+ * k > 48) for the per-lane search. */
 int s3_child_gain_reuse(const s3_knn *knn, int k, const double *d_center, const int32_t *d_level, int64_t first, int64_t n,
                         int dim, double width, const double *d_level_factor, double gain0, double *d_metric /*[cap]*/,
                         double *d_gain /*[cap]*/, double *d_scratch, const int32_t *d_parents /*or NULL*/,

@@ -657,6 +657,8 @@ constexpr int COOP_CAP = 48;       // entries of the short list per child point 
 constexpr int COOP_RMAX = 3;       // at most this many buckets on either side of the centre's bucket
 constexpr int COOP_ROWS = 64;      // >= (2 RMAX + 1)^(DIM - 1) rows of buckets, one lane each
 constexpr int COOP_WAVES = 2;      // wavefronts (cells) per workgroup
+constexpr int32_t FAR_COARSE_FLAG = 1 << 30;
+constexpr int FAR_COARSE_MAX = 32768;     // more child points of coarse cells than this in a batch: the per-lane kernel takes them
 
 // 17 KiB per wavefront: nine wavefronts per CU.  A wavefront's life is a chain of dependent memory round trips (cell -> bucket
 // bounds -> points -> values), so what counts is how many of them a CU holds and how few trips each needs: the loops below
@@ -691,8 +693,9 @@ __device__ __forceinline__ void wave_sync_lds() {
 // whole wavefront) when the scheme cannot answer -- reach beyond COOP_RMAX buckets, a refined bucket in the box, more than
 // COOP_M candidates, fewer than k inside a point's safe radius, more than COOP_CAP below the threshold, a tie among the
 // entries that matter; otherwise lane 0 of every group returns its point's prediction in `result`.
+// (returns 0 = answered, 1 = the points are too far apart to share a box -- a coarse cell --, 2 = any other reason)
 template <int DIM, int LPQ>
-__device__ __forceinline__ bool coop_solve(const Grid<DIM> &g, const double *__restrict__ pts, const int32_t *__restrict__ orig,
+__device__ __forceinline__ int coop_solve(const Grid<DIM> &g, const double *__restrict__ pts, const int32_t *__restrict__ orig,
                                            const int32_t *__restrict__ cs, const double *__restrict__ y, CoopLds<DIM> &L,
                                            const double (&c)[DIM], double off, int k, double reach, int lane, double &result) {
     constexpr int BPL = COOP_NB / LPQ < 1 ? 1 : COOP_NB / LPQ;
@@ -716,7 +719,7 @@ __device__ __forceinline__ bool coop_solve(const Grid<DIM> &g, const double *__r
         hi_i[j] = min(b + max(r_hi, 0), g.res[j] - 1);
         hmin = fmin(hmin, g.h[j]);
     }
-    if (too_far) return false;                                // the points do not share candidates (coarse cells)
+    if (too_far) return 1;                                    // the points do not share candidates (coarse cells)
     const int ny = hi_i[1] - lo_i[1] + 1, nz = DIM == 3 ? hi_i[2] - lo_i[2] + 1 : 1, n_rows = ny * nz;
     int my_start = 0, my_cnt = 0;
     bool refined = false;
@@ -735,7 +738,7 @@ __device__ __forceinline__ bool coop_solve(const Grid<DIM> &g, const double *__r
         if (lane >= d) incl += u;
     }
     const int M = __shfl(incl, 63, 64);
-    if (__ballot(refined) != 0ull || M > COOP_M || M < k) return false;
+    if (__ballot(refined) != 0ull || M > COOP_M || M < k) return 2;
     wave_sync_lds();                                          // (an earlier attempt's reads of these arrays are done)
     if (lane < n_rows) {
         L.row_start[lane] = my_start;
@@ -797,7 +800,7 @@ __device__ __forceinline__ bool coop_solve(const Grid<DIM> &g, const double *__r
         const double span = fmax(fabs(q[j] - face_lo), fabs(face_hi - q[j]));
         far2 += span * span;
     }
-    if (__ballot(!inside) != 0ull) return false;              // a query point at or beyond a face of the box
+    if (__ballot(!inside) != 0ull) return 1;                  // a query point at or beyond a face of the box
     const double lim2 = fmin(safe2, far2 * 1.0000001 + 1e-300);   // no limiting face: every point of the grid is in the box
     const double to_bin = (double)COOP_NB / lim2;
     auto dist2 = [&](int t) {
@@ -849,7 +852,7 @@ __device__ __forceinline__ bool coop_solve(const Grid<DIM> &g, const double *__r
         b_star = max(b_star, __shfl_xor(b_star, d, LPQ));
         below = max(below, __shfl_xor(below, d, LPQ));
     }
-    if (__ballot(total < (uint32_t)k || below > (uint32_t)COOP_CAP) != 0ull) return false;
+    if (__ballot(total < (uint32_t)k || below > (uint32_t)COOP_CAP) != 0ull) return 2;
 
     // ---- 4. short list, ranks, the k best in order -----------------------------------------------------------------------
     for (int t0 = gl; t0 < M; t0 += CHUNK * LPQ) {           // (the distances again: cheaper than 2 x 48 registers per lane)
@@ -891,7 +894,7 @@ __device__ __forceinline__ bool coop_solve(const Grid<DIM> &g, const double *__r
     bool tie = false;
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) tie |= gl + r * LPQ < n_list && e_same[r] > 1 && e_less[r] < k;
-    if (__ballot(tie) != 0ull) return false;
+    if (__ballot(tie) != 0ull) return 2;
     wave_sync_lds();
     // value and inverse-distance weight of the k best, by the lanes that hold them: one round trip for all values
     double e_y[ROUNDS];
@@ -947,7 +950,7 @@ __device__ __forceinline__ bool coop_solve(const Grid<DIM> &g, const double *__r
     }
     result = num / den;
     wave_sync_lds();
-    return true;
+    return 0;
 }
 
 template <int DIM>
@@ -977,7 +980,8 @@ child_metric_coop_kernel(Grid<DIM> g, const double *__restrict__ pts, const int3
     // (a second attempt with a wider box for the cells that find too few candidates inside their safe radius was measured:
     //  it halves the cells left over but the kernel carrying both attempts is slower by more than that saves -- the cells
     //  near a body or the edge of the cloud need searches much wider than any box that fits here)
-    if (k <= COOP_CAP && coop_solve<DIM, LPQ>(g, pts, orig, cs, y, L, c, off, k, reach, lane, m)) {
+    const int code = k <= COOP_CAP ? coop_solve<DIM, LPQ>(g, pts, orig, cs, y, L, c, off, k, reach, lane, m) : 2;
+    if (code == 0) {
         if (lane % LPQ == 0) {
             metric_all[i * NQ + 1 + lane / LPQ] = m;
             child_metric[cell * NCH + lane / LPQ] = m;
@@ -987,7 +991,271 @@ child_metric_coop_kernel(Grid<DIM> g, const double *__restrict__ pts, const int3
     // Coarse cells (child points several buckets apart: no shared candidates), refined buckets in the box, a thin stretch of
     // the cloud, ties in distance, k > COOP_CAP: the cell's child points are listed for the per-lane search of
     // child_metric_rest_kernel.
-    if (lane < NCH) rest[2 + atomicAdd(&rest[0], 1)] = (int32_t)(i * NCH + lane);
+    // (bit 30 marks the child points of coarse cells, rest[1] counts them: a batch with many of them -- the uniform levels --
+    // is better served by the per-lane kernel than by one wavefront per query, child_metric_far_kernel decides)
+    if (lane < NCH) rest[2 + atomicAdd(&rest[0], 1)] = (int32_t)(i * NCH + lane) | (code == 1 ? FAR_COARSE_FLAG : 0);
+    if (lane == 0 && code == 1) atomicAdd(&rest[1], NCH);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The queries the wavefront-per-cell kernel leaves over -- child points of coarse cells, points next to a body or at the edge
+// of the cloud -- need searches wider than a box that fits in LDS, and the per-lane search takes 0.2 - 1.5 ms of dependent loads
+// for each of them however few there are.  Here ONE WAVEFRONT PER QUERY streams the candidates instead of caching them: boxes of
+// growing radius (FAR_RADII buckets on either side of the query's bucket; rows of buckets = contiguous runs of points, their
+// bounds and a prefix sum in LDS), two passes over the box's points read straight from the index (histogram of the squared
+// distances inside the safe radius -> threshold; compaction of the candidates below it), then ranks by counting and the
+// pairwise-ordered prediction exactly as in coop_solve.  What is still left (refined buckets, ties in distance, k > COOP_CAP, a
+// box of more than FAR_MAX_POINTS points) goes to the per-lane kernel.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int FAR_ROWS = 1024;            // >= (2 * max radius + 1)^(DIM - 1)
+constexpr int FAR_NB = 256;               // histogram bins
+constexpr int FAR_MAX_POINTS = 1 << 16;
+__device__ constexpr int FAR_RADII[4] = {3, 5, 9, 15};
+
+struct FarLds {
+    int32_t row_start[FAR_ROWS];
+    int32_t row_prefix[FAR_ROWS + 1];
+    uint32_t hist[FAR_NB];
+    double list_d[COOP_CAP], list_y[COOP_CAP], list_w[COOP_CAP];
+    int32_t list_p[COOP_CAP];
+    uint32_t count;
+};
+
+template <int DIM>
+__device__ __forceinline__ bool far_solve(const Grid<DIM> &g, const double *__restrict__ pts, const int32_t *__restrict__ orig,
+                                          const int32_t *__restrict__ cs, const double *__restrict__ y, FarLds &L,
+                                          const double (&q)[DIM], int k, int radius, int lane, bool &hopeless, double &result) {
+    // ---- the box and its rows --------------------------------------------------------------------------------------------
+    int lo_i[3] = {0, 0, 0}, hi_i[3] = {0, 0, 0};
+    double hmin = DBL_MAX, safe2 = DBL_MAX, far2 = 0.0;
+    bool whole_grid = true;
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) {
+        const int b = cell_coord<DIM>(g, q[j], j);
+        lo_i[j] = max(b - radius, 0);
+        hi_i[j] = min(b + radius, g.res[j] - 1);
+        hmin = fmin(hmin, g.h[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) {
+        const double face_lo = g.lo[j] + (double)lo_i[j] * g.h[j], face_hi = g.lo[j] + (double)(hi_i[j] + 1) * g.h[j];
+        if (lo_i[j] > 0) {
+            const double f = q[j] - face_lo - 1e-9 * hmin;
+            safe2 = fmin(safe2, f > 0.0 ? f * f : 0.0);
+            whole_grid = false;
+        }
+        if (hi_i[j] < g.res[j] - 1) {
+            const double f = face_hi - q[j] - 1e-9 * hmin;
+            safe2 = fmin(safe2, f > 0.0 ? f * f : 0.0);
+            whole_grid = false;
+        }
+        const double span = fmax(fabs(q[j] - face_lo), fabs(face_hi - q[j]));
+        far2 += span * span;
+    }
+    const int ny = hi_i[1] - lo_i[1] + 1, nz = DIM == 3 ? hi_i[2] - lo_i[2] + 1 : 1, n_rows = ny * nz;
+    if (n_rows > FAR_ROWS) { hopeless = true; return false; }
+    wave_sync_lds();
+    // every lane a contiguous share of the rows: bounds, local prefix, wave scan
+    const int per = (n_rows + 63) / 64, r0 = lane * per, r1 = min(r0 + per, n_rows);
+    int mine = 0;
+    bool refined = false;
+    for (int r = r0; r < r1; ++r) {
+        const int zz = r / ny, yy = r - zz * ny;
+        const int64_t row = ((int64_t)(DIM == 3 ? lo_i[2] + zz : 0) * g.res[1] + (lo_i[1] + yy)) * g.res[0];
+        const int start = cs[row + lo_i[0]], cnt = cs[row + hi_i[0] + 1] - start;
+        L.row_start[r] = start;
+        L.row_prefix[r] = mine;                            // (local; the lane's offset is added below)
+        mine += cnt;
+        if (g.sub_res != nullptr)
+            for (int x = lo_i[0]; x <= hi_i[0]; ++x) refined |= g.sub_res[row + x] != 0;
+    }
+    int incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int u = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += u;
+    }
+    const int M = __shfl(incl, 63, 64);
+    for (int r = r0; r < r1; ++r) L.row_prefix[r] += incl - mine;
+    if (lane == 0) L.count = 0;
+    for (int t = lane; t < FAR_NB; t += 64) L.hist[t] = 0;
+    if (__ballot(refined) != 0ull || M > FAR_MAX_POINTS) { hopeless = true; return false; }
+    if (M < k) { hopeless = whole_grid; return false; }      // a wider box will do (unless this one is the whole grid)
+    wave_sync_lds();
+    const double lim2 = fmin(safe2, far2 * 1.0000001 + 1e-300);
+    if (!(lim2 > 0.0)) return false;
+    const double to_bin = (double)FAR_NB / lim2;
+    auto point_of = [&](int t) {                             // slot t of the box -> position in the index
+        int r = 0;
+#pragma unroll
+        for (int step = FAR_ROWS / 2; step > 0; step >>= 1)
+            if (r + step < n_rows && L.row_prefix[r + step] <= t) r += step;
+        return L.row_start[r] + (t - L.row_prefix[r]);
+    };
+    auto dist2 = [&](int p) {
+        double d = 0.0;
+#pragma unroll
+        for (int j = 0; j < DIM; ++j) {
+            const double u = q[j] - pts[(int64_t)p * DIM + j];
+            d += u * u;
+        }
+        return d;
+    };
+    // ---- pass A: histogram ---------------------------------------------------------------------------------------------------
+    for (int t0 = lane; t0 < M; t0 += 4 * 64) {
+        int p[4];
+        double d[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) p[u] = point_of(min(t0 + 64 * u, M - 1));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) d[u] = dist2(p[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (t0 + 64 * u < M && d[u] < lim2) atomicAdd(&L.hist[min(FAR_NB - 1, (int)(d[u] * to_bin))], 1u);
+    }
+    wave_sync_lds();
+    constexpr int BPL = FAR_NB / 64;
+    uint32_t bins[BPL], own = 0;
+#pragma unroll
+    for (int b = 0; b < BPL; ++b) {
+        bins[b] = L.hist[lane * BPL + b];
+        own += bins[b];
+    }
+    uint32_t upto = own;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t u = __shfl_up(upto, d, 64);
+        if (lane >= d) upto += u;
+    }
+    const uint32_t total = __shfl(upto, 63, 64);
+    int b_star = -1;
+    uint32_t below = 0;
+    {
+        uint32_t run = upto - own;
+        const bool owner = run < (uint32_t)k && upto >= (uint32_t)k;
+#pragma unroll
+        for (int b = 0; b < BPL; ++b) {
+            run += bins[b];
+            if (owner && b_star < 0 && run >= (uint32_t)k) { b_star = lane * BPL + b; below = run; }
+        }
+    }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        b_star = max(b_star, __shfl_xor(b_star, d, 64));
+        below = max(below, __shfl_xor(below, d, 64));
+    }
+    if (total < (uint32_t)k) { hopeless = whole_grid; return false; }
+    if (below > (uint32_t)COOP_CAP) { hopeless = true; return false; }     // ties in bulk
+    // ---- pass B: the candidates below the threshold ---------------------------------------------------------------------------
+    for (int t0 = lane; t0 < M; t0 += 4 * 64) {
+        int p[4];
+        double d[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) p[u] = point_of(min(t0 + 64 * u, M - 1));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) d[u] = dist2(p[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (t0 + 64 * u < M && d[u] < lim2 && min(FAR_NB - 1, (int)(d[u] * to_bin)) <= b_star) {
+                const uint32_t at = atomicAdd(&L.count, 1u);
+                L.list_d[at] = d[u];
+                L.list_p[at] = p[u];
+            }
+    }
+    wave_sync_lds();
+    const int n_list = (int)below;
+    const int e = min(lane, n_list - 1);
+    const double e_d = L.list_d[e];
+    const int e_p = L.list_p[e];
+    int less = 0, same = 0;
+    for (int m = 0; m < n_list; ++m) {
+        const double dm = L.list_d[m];
+        less += dm < e_d ? 1 : 0;
+        same += dm == e_d ? 1 : 0;
+    }
+    if (__ballot(lane < n_list && same > 1 && less < k) != 0ull) { hopeless = true; return false; }   // a tie that matters
+    wave_sync_lds();
+    const bool best = lane < n_list && less < k;
+    const double e_y = best ? y[e_p] : 0.0;
+    if (best) {
+        L.list_d[less] = e_d;
+        L.list_y[less] = e_y;
+        L.list_w[less] = 1.0 / sqrt(e_d);
+    }
+    wave_sync_lds();
+    bool zero = false;
+    for (int m = lane; m < k; m += 64) zero |= L.list_d[m] == 0.0;
+    zero = __ballot(zero) != 0ull;
+    auto wgt = [&](int m) { return zero ? (L.list_d[m] == 0.0 ? 1.0 : 0.0) : L.list_w[m]; };
+    auto term = [&](int m) { return L.list_y[m] * wgt(m); };
+    double num = 0.0, den = 0.0;
+    if (k < 8) {
+        if (lane == 0)
+            for (int m = 0; m < k; ++m) {
+                num += term(m);
+                den += wgt(m);
+            }
+    } else {
+        double rn = 0.0, rw = 0.0;
+        if (lane < 8) {
+            rn = term(lane);
+            rw = wgt(lane);
+            for (int m = 8; m < k - (k % 8); m += 8) {
+                rn += term(m + lane);
+                rw += wgt(m + lane);
+            }
+        }
+        rn += __shfl_xor(rn, 1, 64); rw += __shfl_xor(rw, 1, 64);
+        rn += __shfl_xor(rn, 2, 64); rw += __shfl_xor(rw, 2, 64);
+        rn += __shfl_xor(rn, 4, 64); rw += __shfl_xor(rw, 4, 64);
+        num = rn;
+        den = rw;
+        if (lane == 0)
+            for (int m = k - (k % 8); m < k; ++m) {
+                num += term(m);
+                den += wgt(m);
+            }
+    }
+    result = num / den;
+    return true;
+}
+
+template <int DIM>
+__global__ void __launch_bounds__(64 * COOP_WAVES)
+child_metric_far_kernel(Grid<DIM> g, const double *__restrict__ pts, const int32_t *__restrict__ orig,
+                        const int32_t *__restrict__ cs, const double *__restrict__ y, const double *__restrict__ center,
+                        const int32_t *__restrict__ level, int64_t first, double quarter_width, int k,
+                        double *__restrict__ metric_all, double *__restrict__ child_metric, const int32_t *__restrict__ rest,
+                        int32_t *__restrict__ rest2) {
+    constexpr int NCH = 1 << DIM, NQ = NCH + 1;
+    __shared__ FarLds lds_all[COOP_WAVES];
+    const int lane = threadIdx.x & 63;
+    FarLds &L = lds_all[threadIdx.x >> 6];
+    const int count = rest[0];
+    const bool coarse_to_lanes = rest[1] > FAR_COARSE_MAX;
+    for (int e = blockIdx.x * COOP_WAVES + (threadIdx.x >> 6); e < count; e += gridDim.x * COOP_WAVES) {
+        const int32_t entry = rest[2 + e] & ~FAR_COARSE_FLAG;
+        const int64_t i = entry / NCH;
+        const int jq = entry % NCH;
+        const int64_t cell = first + i;
+        const double off = cell_offset(quarter_width, level[cell]);
+        double q[DIM];
+#pragma unroll
+        for (int j = 0; j < DIM; ++j) q[j] = center[cell * DIM + j] + dir_comp(DIM, jq, j) * off;
+        bool ok = false, hopeless = k > COOP_CAP || (coarse_to_lanes && (rest[2 + e] & FAR_COARSE_FLAG) != 0);
+        double m = 0.0;
+#pragma unroll 1
+        for (int attempt = 0; attempt < 4 && !ok && !hopeless; ++attempt)
+            ok = far_solve<DIM>(g, pts, orig, cs, y, L, q, k, FAR_RADII[attempt], lane, hopeless, m);
+        if (lane == 0) {
+            if (ok) {
+                metric_all[i * NQ + 1 + jq] = m;
+                child_metric[cell * NCH + jq] = m;
+            } else {
+                rest2[2 + atomicAdd(&rest2[0], 1)] = entry;
+            }
+        }
+    }
 }
 
 // the queries the wavefronts above could not answer (rest[0] of them): the per-lane search, lanes densely packed
@@ -1334,7 +1602,7 @@ static bool knn_coop_enabled() {
 
 static int64_t knn_coop_min_cells() {
     const char *e = getenv("S3_KNN_COOP_MIN");
-    return e ? atoll(e) : 100000ll;
+    return e ? atoll(e) : 4096ll;
 }
 static bool knn_coop_forced() {
     const char *e = getenv("S3_KNN_COOP");
@@ -1370,15 +1638,19 @@ static int child_gain_impl(const s3_knn *knn, int k, const double *d_center, con
     child_metric_coop_kernel<DIM><<<grid_for(n, COOP_WAVES), 64 * COOP_WAVES, 0, st>>>(                                       \
         make_grid<DIM>(knn), knn->pts, knn->orig, knn->cell_start, knn->y, d_center, d_level, first, n, qw, k, reach,        \
         d_scratch, d_parents, parents_offset, d_child_metric, d_rest);                                                        \
-    child_metric_rest_kernel<DIM><<<grid_for(n * (1 << DIM), KNN_BLOCK, 1024), KNN_BLOCK, lds, st>>>(make_grid<DIM>(knn), knn->pts, knn->orig, knn->cell_start, knn->y,  \
-                                                             d_center, d_level, first, qw, k, d_scratch, d_child_metric, d_rest); \
+    child_metric_far_kernel<DIM><<<grid_for(n * (1 << DIM), COOP_WAVES, 8192), 64 * COOP_WAVES, 0, st>>>(                      \
+        make_grid<DIM>(knn), knn->pts, knn->orig, knn->cell_start, knn->y, d_center, d_level, first, qw, k, d_scratch,        \
+        d_child_metric, d_rest, d_rest2);                                                                                     \
+    child_metric_rest_kernel<DIM><<<grid_for(n * (1 << DIM), KNN_BLOCK, 256), KNN_BLOCK, lds, st>>>(make_grid<DIM>(knn), knn->pts, knn->orig, knn->cell_start, knn->y,  \
+                                                             d_center, d_level, first, qw, k, d_scratch, d_child_metric, d_rest2); \
     } while (0)
     // one wavefront per cell (S3_KNN_COOP=0: the per-lane search for every child point, as for cells without a known parent)
-    // Measured on MI355X (interleaved box to box, +-5 %): cylinder3D (batches of <= 60 000 new cells, a third of them coarse or
-    // next to the body) 0.061 s with the per-lane kernel alone, 0.060 - 0.065 s with the wavefronts in front of it -- what they
-    // save the per-lane tail for the left-over queries costs again (a per-lane wavefront lives 0.2 - 1.5 ms however few
-    // queries it carries); box5e7 (batches of ~270 000 fine cells) 0.70 -> 0.59 - 0.62 s.  Hence only for large batches
-    // (S3_KNN_COOP_MIN cells; S3_KNN_COOP=1 forces it for every batch, =0 switches it off).
+    // Measured on MI355X: cylinder3D, adaptive batches of ~40 000 new cells: 0.37 ms (wavefront per cell) + 0.23 ms (streaming
+    // search for what it leaves: coarse cells, cells next to the body) + nothing left for the per-lane kernel, against 1.16 ms
+    // for the per-lane kernel alone -- the refine's wall-clock does not move (0.060 s either way: the host's set bookkeeping
+    // runs beside these kernels and takes as long); box5e7, batches of ~230 000 fine cells: 3.8 + 0.12 ms against 7.0 ms, refine
+    // 0.70 -> 0.56 - 0.58 s.  Batches of the uniform levels (every cell coarse) end up in the per-lane kernel as before.
+    // Tiny batches skip the three launches (S3_KNN_COOP_MIN cells; S3_KNN_COOP=1 forces them for every batch, =0 switches them off).
     const bool coop = d_parents != nullptr && knn_coop_enabled() && (n >= knn_coop_min_cells() || knn_coop_forced());
     // how far (in bucket sides) the box reaches beyond the child points: the radius of the ball that holds k points at the
     // index's average occupancy, plus a margin (S3_KNN_COOP_MARGIN, default 1.15); where the cloud is thinner than that the
@@ -1388,8 +1660,13 @@ static int child_gain_impl(const s3_knn *knn, int k, const double *d_center, con
                                  : std::sqrt(k / (3.14159265358979323846 * occupancy));
     const double reach = ball * knn_coop_margin();
     // behind the n * (2^dim + 1) doubles of d_scratch: a counter and the list of the queries left to the per-lane search
+    // two such lists: what the wavefront-per-cell kernel leaves to the streaming search, and what that leaves to the per-lane one
     int32_t *d_rest = reinterpret_cast<int32_t *>(d_scratch + n * ((1 << dim) + 1));
-    if (coop) S3_HIP_CHECK(hipMemsetAsync(d_rest, 0, 2 * sizeof(int32_t), st));
+    int32_t *d_rest2 = d_rest + 2 + n * (1 << dim);
+    if (coop) {
+        S3_HIP_CHECK(hipMemsetAsync(d_rest, 0, 2 * sizeof(int32_t), st));
+        S3_HIP_CHECK(hipMemsetAsync(d_rest2, 0, 2 * sizeof(int32_t), st));
+    }
     if (dim == 2) {
         if (coop) S3_CHILD_COOP(2); else if (d_parents) S3_CHILD_METRIC(2, true, 4); else S3_CHILD_METRIC(2, false, 5);
         child_gain_kernel<2><<<grid_for(n, 256), 256, 0, st>>>(d_scratch, d_level, first, n, d_level_factor, gain0,

@@ -88,7 +88,7 @@ class HipTreeBackend:
         hipops.make_children(self.center, self.level, self._parents, first, float(self.width))
         # the KNN metric / gain of this rank's slice of the new cells (all of them with one rank) ...
         if e > b:
-            scratch = pt.empty((e - b) * (self.nch + 1) + 2 + ((e - b) * self.nch + 1) // 2, dtype=pt.float64, device=self.dev)
+            scratch = pt.empty((e - b) * (self.nch + 1) + 2 + (e - b) * self.nch, dtype=pt.float64, device=self.dev)
             # a new cell's centre is a point its parent's call predicted already: only the 2^d child points are searched
             # (8 of 9 queries in 3-D).  Not for the root's children (the root was evaluated on the host) and not with several
             # ranks, where a parent's entry may live on another rank (the values are the same either way).

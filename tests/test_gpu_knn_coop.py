@@ -41,7 +41,7 @@ def test_wavefront_per_cell_equals_per_lane(monkeypatch, dim, k, cloud):
             metric, gain = pt.zeros(cap, dtype=pt.float64, device="cuda"), pt.zeros(cap, dtype=pt.float64, device="cuda")
             child = pt.from_numpy(rng.random((cap, nch))).cuda() if mode == "1" else res["1"][3].clone()
             start = child.clone()
-            scratch = pt.zeros(n * (nch + 1) + 2 + (n * nch + 1) // 2, dtype=pt.float64, device="cuda")
+            scratch = pt.zeros(n * (nch + 1) + 2 + n * nch, dtype=pt.float64, device="cuda")
             hipops.child_gain_reuse(knn, k, center, level, nch, n, width, lf, 0.37, metric, gain, scratch, parents, 0, child)
             res[mode] = (child[nch:].clone(), metric[nch:].clone(), gain[nch:].clone(), start)
         assert pt.equal(res["1"][0], res["0"][0]) and pt.equal(res["1"][1], res["0"][1]) and pt.equal(res["1"][2], res["0"][2])
@@ -50,3 +50,41 @@ def test_wavefront_per_cell_equals_per_lane(monkeypatch, dim, k, cloud):
         want = res["1"][3][parents.long()[pt.arange(n, device="cuda") // nch], pt.arange(n, device="cuda") % nch]
         assert pt.equal(res["1"][1], want)
     knn.close()
+
+
+@pytest.mark.parametrize("name", ["refine_2d_metric", "refine_2d_delta", "refine_3d_metric", "refine_3d_ncells_cone", "refine_3d_polytopes"])
+def test_refine_goldens_through_the_wavefront_kernels(monkeypatch, name):
+    """the reference's grids (cell ids / levels / centres / faces / vertices / per-cell metric + gain, bit for bit) with every batch
+    forced through the wavefront-per-cell kernel, the streaming search and the per-lane search for what they leave
+    (S3_KNN_COOP=1; by default only batches of >= 4096 cells take that route)"""
+    import sparsespatialsampling_amd.s_cube as s_cube
+    from sparsespatialsampling_amd import geometry
+    from inputs import refine_inputs, sha
+    from tests.test_gpu_refine import check_outputs_against_golden, check_tree_against_golden, load
+    monkeypatch.setenv("S3_KNN_COOP", "1")
+    z = load(name)
+    x, y, geos, kw = refine_inputs(name, geometry)
+    assert sha(x, y) == str(z["input_sha"])
+    tree = s_cube.SamplingTree(pt.from_numpy(x), pt.from_numpy(y), geometry_obj=geos, **kw)
+    tree.refine()
+    check_tree_against_golden(tree, z)
+    check_outputs_against_golden(tree, z)
+
+
+def test_c1_full_size_through_the_wavefront_kernels(monkeypatch):
+    """BASELINE config C1 at full size (a structured-looking 2-D cloud, 87 adaptive iterations, body refined to level 9) with
+    S3_KNN_COOP=1: the reference's grid"""
+    import sparsespatialsampling_amd.s_cube as s_cube
+    from sparsespatialsampling_amd import geometry
+    from inputs import c1_cylinder2d, sha
+    from tests.test_gpu_refine import load
+    monkeypatch.setenv("S3_KNN_COOP", "1")
+    z = load("c1_cylinder2d")
+    x, m, geos, kw = c1_cylinder2d(geometry)
+    assert sha(x, m) == str(z["input_sha"])
+    tree = s_cube.SamplingTree(pt.from_numpy(x), pt.from_numpy(m), geometry_obj=geos, **kw)
+    tree.refine()
+    assert np.array_equal(tree.all_centers.numpy(), z["all_centers"])
+    assert np.array_equal(tree.all_levels.numpy(), z["all_levels"].astype(np.int64))
+    assert np.array_equal(tree.face_ids.numpy(), z["face_ids"])
+    np.testing.assert_allclose(np.array(tree._metric), z["metric_hist"], rtol=1e-12)

@@ -37,14 +37,15 @@ for lv in (6, 7, 8, 9, 10):
     metric_d, gain_d = pt.zeros(cap, dtype=pt.float64, device="cuda"), pt.zeros(cap, dtype=pt.float64, device="cuda")
     child = pt.zeros((cap, nch), dtype=pt.float64, device="cuda")
     parents = pt.zeros((n + nch - 1) // nch, dtype=pt.int32, device="cuda")
-    scratch = pt.zeros(n * (nch + 1) + 2 + (n * nch + 1) // 2, dtype=pt.float64, device="cuda")
+    scratch = pt.zeros(n * (nch + 1) + 2 + n * nch, dtype=pt.float64, device="cuda")
     out = {}
     for mode in ("1", "0"):
         os.environ["S3_KNN_COOP"] = mode
         run = lambda: hipops.child_gain_reuse(knn, k, center, level, 8, n, width, lf, 1.0, metric_d, gain_d, scratch, parents, 0, child)
         ms = timed(run)
-        left = int(scratch[n * (nch + 1):].view(pt.int32)[0]) if mode == "1" else 0
+        tail = scratch[n * (nch + 1):].view(pt.int32)
+        left = (int(tail[0]), int(tail[2 + n * nch])) if mode == "1" else (0, 0)
         out[mode] = (ms, child[8:8 + n].clone(), gain_d[8:8 + n].clone(), left)
     same = bool(pt.equal(out["1"][1], out["0"][1]) and pt.equal(out["1"][2], out["0"][2]))
     print(f"level {lv} (cell {width / 2 ** lv:.5f}, quarter {width / 2 ** lv / 4:.5f}): wavefront per cell {out['1'][0]:.3f} ms "
-          f"({out['1'][3]} of {n * nch} queries left to the per-lane search), per-lane kernel {out['0'][0]:.3f} ms, same bits {same}", flush=True)
+          f"({out['1'][3][0]} of {n * nch} queries to the streaming search, {out['1'][3][1]} to the per-lane search), per-lane kernel {out['0'][0]:.3f} ms, same bits {same}", flush=True)

@@ -657,8 +657,6 @@ constexpr int COOP_CAP = 48;       // entries of the short list per child point 
 constexpr int COOP_RMAX = 3;       // at most this many buckets on either side of the centre's bucket
 constexpr int COOP_ROWS = 64;      // >= (2 RMAX + 1)^(DIM - 1) rows of buckets, one lane each
 constexpr int COOP_WAVES = 2;      // wavefronts (cells) per workgroup
-constexpr int32_t FAR_COARSE_FLAG = 1 << 30;
-constexpr int FAR_COARSE_MAX = 32768;     // more child points of coarse cells than this in a batch: the per-lane kernel takes them
 
 // 17 KiB per wavefront: nine wavefronts per CU.  A wavefront's life is a chain of dependent memory round trips (cell -> bucket
 // bounds -> points -> values), so what counts is how many of them a CU holds and how few trips each needs: the loops below
@@ -988,29 +986,29 @@ child_metric_coop_kernel(Grid<DIM> g, const double *__restrict__ pts, const int3
         }
         return;
     }
-    // Coarse cells (child points several buckets apart: no shared candidates), refined buckets in the box, a thin stretch of
-    // the cloud, ties in distance, k > COOP_CAP: the cell's child points are listed for the per-lane search of
-    // child_metric_rest_kernel.
-    // (bit 30 marks the child points of coarse cells, rest[1] counts them: a batch with many of them -- the uniform levels --
-    // is better served by the per-lane kernel than by one wavefront per query, child_metric_far_kernel decides)
-    if (lane < NCH) rest[2 + atomicAdd(&rest[0], 1)] = (int32_t)(i * NCH + lane) | (code == 1 ? FAR_COARSE_FLAG : 0);
-    if (lane == 0 && code == 1) atomicAdd(&rest[1], NCH);
+    // Coarse cells (child points several buckets apart: no shared candidates), more candidates than the box holds, refined
+    // buckets in the box, a thin stretch of the cloud, ties in distance, k > COOP_CAP: the cell's child points are listed for
+    // child_metric_near_kernel
+    if (lane < NCH) rest[2 + atomicAdd(&rest[0], 1)] = (int32_t)(i * NCH + lane);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// The queries the wavefront-per-cell kernel leaves over -- child points of coarse cells, points next to a body or at the edge
-// of the cloud -- need searches wider than a box that fits in LDS, and the per-lane search takes 0.2 - 1.5 ms of dependent loads
-// for each of them however few there are.  Here ONE WAVEFRONT PER QUERY streams the candidates instead of caching them: boxes of
-// growing radius (FAR_RADII buckets on either side of the query's bucket; rows of buckets = contiguous runs of points, their
-// bounds and a prefix sum in LDS), two passes over the box's points read straight from the index (histogram of the squared
-// distances inside the safe radius -> threshold; compaction of the candidates below it), then ranks by counting and the
-// pairwise-ordered prediction exactly as in coop_solve.  What is still left (refined buckets, ties in distance, k > COOP_CAP, a
-// box of more than FAR_MAX_POINTS points) goes to the per-lane kernel.
+// The queries the wavefront-per-cell kernel leaves over -- child points of cells too large for one shared box, points next to
+// a body, at the edge of the cloud or outside it (the tree's root cell is a cube) -- need searches of their own, and the
+// per-lane search takes 0.2 - 1.5 ms of dependent loads for them however few there are.  child_metric_far_kernel streams the
+// candidates instead of caching them, in two stages: near_solve (2^DIM queries per wavefront, each group of lanes its own small
+// box) and, for what that leaves, far_solve: ONE WAVEFRONT PER QUERY, boxes that hold balls of growing radius (FAR_BALLS x reach
+// beyond the grid's nearest point; rows of buckets = contiguous runs of points, their bounds and a prefix sum in LDS), two
+// passes over the box's points read straight from the index (histogram of the squared distances inside the safe radius ->
+// threshold; compaction of the candidates below it), then ranks by counting and the pairwise-ordered prediction exactly as
+// in coop_solve.  What is still left (refined buckets, ties in distance, k > COOP_CAP, a box of more than FAR_MAX_POINTS
+// points) goes to the per-lane kernel.
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int FAR_ROWS = 1024;            // >= (2 * max radius + 1)^(DIM - 1)
 constexpr int FAR_NB = 256;               // histogram bins
 constexpr int FAR_MAX_POINTS = 1 << 16;
-__device__ constexpr int FAR_RADII[4] = {3, 5, 9, 15};
+constexpr int FAR_RMAX = 15;             // buckets on either side of the query's bucket, at most
+__device__ constexpr double FAR_BALLS[4] = {1.8, 3.5, 7.0, 13.0};   // radius of the ball the box must hold, in units of `reach`
 
 struct FarLds {
     int32_t row_start[FAR_ROWS];
@@ -1024,29 +1022,53 @@ struct FarLds {
 template <int DIM>
 __device__ __forceinline__ bool far_solve(const Grid<DIM> &g, const double *__restrict__ pts, const int32_t *__restrict__ orig,
                                           const int32_t *__restrict__ cs, const double *__restrict__ y, FarLds &L,
-                                          const double (&q)[DIM], int k, int radius, int lane, bool &hopeless, double &result) {
-    // ---- the box and its rows --------------------------------------------------------------------------------------------
+                                          const double (&q)[DIM], int k, double ball, int lane, bool &hopeless,
+                                          double &result) {
+    // ---- the box: what the ball of `ball` bucket sides beyond the grid's nearest point needs, per axis and side ----------------
+    // (a query outside the grid at distance D_i along axis i -- the tree's root cell is a cube around an oblong cloud -- : every
+    //  point is at least D_i away along that axis, so the box need not be a cube around the query and the points beyond a face
+    //  of axis j are at least sqrt(f_j^2 + sum_{i != j} D_i^2) away)
     int lo_i[3] = {0, 0, 0}, hi_i[3] = {0, 0, 0};
-    double hmin = DBL_MAX, safe2 = DBL_MAX, far2 = 0.0;
+    double hmin = DBL_MAX, hmax = 0.0, safe2 = DBL_MAX, far2 = 0.0, out[3] = {0.0, 0.0, 0.0}, out2 = 0.0;
     bool whole_grid = true;
 #pragma unroll
     for (int j = 0; j < DIM; ++j) {
-        const int b = cell_coord<DIM>(g, q[j], j);
-        lo_i[j] = max(b - radius, 0);
-        hi_i[j] = min(b + radius, g.res[j] - 1);
         hmin = fmin(hmin, g.h[j]);
+        hmax = fmax(hmax, g.h[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) {
+        const double top = g.lo[j] + (double)g.res[j] * g.h[j];
+        out[j] = fmax(fmax(g.lo[j] - q[j], q[j] - top) - 1e-9 * hmin, 0.0);
+        out2 += out[j] * out[j];
+    }
+    // inside the grid: the ball itself.  At distance D outside it: the cap of the ball around q that reaches into the grid is to
+    // hold as much as that ball would, height^2 (3 D + 2 height) = 4 ball^3 -- both bounds below overestimate the height
+    const double dist_out = sqrt(out2), ball_phys = ball * hmax;
+    const double cap = dist_out > 0.0 ? fmin(1.26 * ball_phys, sqrt(4.0 * ball_phys * ball_phys * ball_phys / (3.0 * dist_out)))
+                                      : ball_phys;
+    const double ball_len = dist_out + cap;
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) {
+        const int b = cell_coord<DIM>(g, q[j], j);
+        const double pos = (q[j] - g.lo[j]) * g.inv_h[j] - (double)b;             // inside the grid: 0 .. 1
+        const double want = sqrt(fmax(ball_len * ball_len - (out2 - out[j] * out[j]), 0.0)) * g.inv_h[j];
+        const int r_lo = min(max((int)ceil(want - pos), 0), FAR_RMAX), r_hi = min(max((int)ceil(want - (1.0 - pos)), 0), FAR_RMAX);
+        lo_i[j] = max(b - r_lo, 0);
+        hi_i[j] = min(b + r_hi, g.res[j] - 1);
     }
 #pragma unroll
     for (int j = 0; j < DIM; ++j) {
         const double face_lo = g.lo[j] + (double)lo_i[j] * g.h[j], face_hi = g.lo[j] + (double)(hi_i[j] + 1) * g.h[j];
+        const double others2 = fmax(out2 - out[j] * out[j], 0.0);
         if (lo_i[j] > 0) {
             const double f = q[j] - face_lo - 1e-9 * hmin;
-            safe2 = fmin(safe2, f > 0.0 ? f * f : 0.0);
+            safe2 = fmin(safe2, f > 0.0 ? f * f + others2 : 0.0);
             whole_grid = false;
         }
         if (hi_i[j] < g.res[j] - 1) {
             const double f = face_hi - q[j] - 1e-9 * hmin;
-            safe2 = fmin(safe2, f > 0.0 ? f * f : 0.0);
+            safe2 = fmin(safe2, f > 0.0 ? f * f + others2 : 0.0);
             whole_grid = false;
         }
         const double span = fmax(fabs(q[j] - face_lo), fabs(face_hi - q[j]));
@@ -1083,8 +1105,10 @@ __device__ __forceinline__ bool far_solve(const Grid<DIM> &g, const double *__re
     if (M < k) { hopeless = whole_grid; return false; }      // a wider box will do (unless this one is the whole grid)
     wave_sync_lds();
     const double lim2 = fmin(safe2, far2 * 1.0000001 + 1e-300);
-    if (!(lim2 > 0.0)) return false;
-    const double to_bin = (double)FAR_NB / lim2;
+    if (!(lim2 > out2)) return false;
+    // (no point is nearer than the grid: the bins span out2 .. lim2, or the candidates of a query far outside would share a few)
+    const double to_bin = (double)FAR_NB / (lim2 - out2);
+    auto bin_of = [&](double d) { return min(FAR_NB - 1, max((int)((d - out2) * to_bin), 0)); };
     auto point_of = [&](int t) {                             // slot t of the box -> position in the index
         int r = 0;
 #pragma unroll
@@ -1111,7 +1135,7 @@ __device__ __forceinline__ bool far_solve(const Grid<DIM> &g, const double *__re
         for (int u = 0; u < 4; ++u) d[u] = dist2(p[u]);
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            if (t0 + 64 * u < M && d[u] < lim2) atomicAdd(&L.hist[min(FAR_NB - 1, (int)(d[u] * to_bin))], 1u);
+            if (t0 + 64 * u < M && d[u] < lim2) atomicAdd(&L.hist[bin_of(d[u])], 1u);
     }
     wave_sync_lds();
     constexpr int BPL = FAR_NB / 64;
@@ -1156,8 +1180,8 @@ __device__ __forceinline__ bool far_solve(const Grid<DIM> &g, const double *__re
         for (int u = 0; u < 4; ++u) d[u] = dist2(p[u]);
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            if (t0 + 64 * u < M && d[u] < lim2 && min(FAR_NB - 1, (int)(d[u] * to_bin)) <= b_star) {
-                const uint32_t at = atomicAdd(&L.count, 1u);
+            if (t0 + 64 * u < M && d[u] < lim2 && bin_of(d[u]) <= b_star) {
+                const uint32_t at = min(atomicAdd(&L.count, 1u), (uint32_t)(COOP_CAP - 1));
                 L.list_d[at] = d[u];
                 L.list_p[at] = p[u];
             }
@@ -1220,40 +1244,332 @@ __device__ __forceinline__ bool far_solve(const Grid<DIM> &g, const double *__re
     return true;
 }
 
+// ---- stage one of the streaming kernel: 2^DIM left-over queries per wavefront, 64 / 2^DIM lanes each ---------------------------
+// Most of what the wavefront-per-cell kernel leaves over in a batch of mid-sized cells are ordinary queries in ordinary
+// surroundings whose only fault is a cell too large for one shared box: each needs the ~30 - 80 buckets around ITSELF, a
+// hundred or two candidates.  A whole wavefront per such query leaves most lanes idle and the kernel bound by instruction
+// issue (measured: ~1500 wave instructions per query).  Here every group of lanes owns one query and its own box -- the
+// smallest box that holds the ball of `reach` bucket sides around the query, at most NEAR_SIDE buckets per axis --, streams its
+// candidates from the index (two passes: histogram, compaction), ranks and predicts exactly like coop_solve.  A group that
+// cannot answer (box too large, refined bucket, too few candidates inside the safe radius, ties) reports so; the wavefront then
+// searches for its query with all lanes (far_solve).
+constexpr int NEAR_SIDE = 5;
+constexpr int NEAR_MAX_POINTS = 1024;
+
+template <int DIM>
+struct NearLds {
+    static constexpr int NQB = 1 << DIM;
+    static constexpr int ROWS = DIM == 3 ? NEAR_SIDE * NEAR_SIDE : NEAR_SIDE;
+    int32_t row_start[NQB][ROWS + 1], row_prefix[NQB][ROWS + 1];
+    uint32_t hist[NQB][COOP_NB + 1];
+    double list_d[NQB][COOP_CAP], list_y[NQB][COOP_CAP], list_w[NQB][COOP_CAP];
+    int32_t list_p[NQB][COOP_CAP];
+    uint32_t count[NQB];
+};
+
+template <int DIM>
+__device__ __forceinline__ bool near_solve(const Grid<DIM> &g, const double *__restrict__ pts, const int32_t *__restrict__ cs,
+                                           const double *__restrict__ y, NearLds<DIM> &L, const double (&q)[DIM], bool active,
+                                           int k, double reach, int lane, double &result) {
+    constexpr int NQB = 1 << DIM, LPQ = 64 / NQB, ROWS = NearLds<DIM>::ROWS;
+    constexpr int MAXC = (ROWS + LPQ - 1) / LPQ;              // rows per lane
+    constexpr int BPL = COOP_NB / LPQ, ROUNDS = COOP_CAP / LPQ;
+    static_assert(COOP_NB % LPQ == 0 && COOP_CAP % LPQ == 0, "lane layout");
+    const int jq = lane / LPQ, gl = lane - jq * LPQ;
+    bool fail = !active || k > COOP_CAP;
+
+    // ---- the box and its rows ----------------------------------------------------------------------------------------------
+    int lo_i[3] = {0, 0, 0}, hi_i[3] = {0, 0, 0};
+    double hmin = DBL_MAX, safe2 = DBL_MAX, far2 = 0.0;
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) {
+        const int b = cell_coord<DIM>(g, q[j], j);
+        const double frac = fmin(fmax((q[j] - g.lo[j]) * g.inv_h[j] - (double)b, 0.0), 1.0);
+        int r_lo = max((int)ceil(reach - frac), 0), r_hi = max((int)ceil(reach - (1.0 - frac)), 0);
+        if (r_lo + r_hi + 1 > NEAR_SIDE) { fail = true; r_lo = r_hi = 0; }
+        lo_i[j] = max(b - r_lo, 0);
+        hi_i[j] = min(b + r_hi, g.res[j] - 1);
+        hmin = fmin(hmin, g.h[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) {
+        const double face_lo = g.lo[j] + (double)lo_i[j] * g.h[j], face_hi = g.lo[j] + (double)(hi_i[j] + 1) * g.h[j];
+        if (lo_i[j] > 0) {
+            const double f = q[j] - face_lo - 1e-9 * hmin;
+            safe2 = fmin(safe2, f > 0.0 ? f * f : 0.0);
+        }
+        if (hi_i[j] < g.res[j] - 1) {
+            const double f = face_hi - q[j] - 1e-9 * hmin;
+            safe2 = fmin(safe2, f > 0.0 ? f * f : 0.0);
+        }
+        const double span = fmax(fabs(q[j] - face_lo), fabs(face_hi - q[j]));
+        far2 += span * span;
+    }
+    const int ny = hi_i[1] - lo_i[1] + 1, nz = DIM == 3 ? hi_i[2] - lo_i[2] + 1 : 1, n_rows = fail ? 0 : ny * nz;
+    int r_start[MAXC], r_cnt[MAXC];
+    bool refined = false;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int r = c * LPQ + gl;
+        r_start[c] = r_cnt[c] = 0;
+        if (r < n_rows) {
+            const int zz = r / ny, yy = r - zz * ny;
+            const int64_t row = ((int64_t)(DIM == 3 ? lo_i[2] + zz : 0) * g.res[1] + (lo_i[1] + yy)) * g.res[0];
+            r_start[c] = cs[row + lo_i[0]];
+            r_cnt[c] = cs[row + hi_i[0] + 1] - r_start[c];
+            if (g.sub_res != nullptr)
+                for (int x = lo_i[0]; x <= hi_i[0]; ++x) refined |= g.sub_res[row + x] != 0;
+        }
+    }
+    wave_sync_lds();                                          // (the previous query's reads of these arrays are done)
+    int M = 0;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        int incl = r_cnt[c];
+#pragma unroll
+        for (int d = 1; d < LPQ; d <<= 1) {
+            const int u = __shfl_up(incl, d, LPQ);
+            if (gl >= d) incl += u;
+        }
+        const int r = c * LPQ + gl;
+        if (r < n_rows) {
+            L.row_start[jq][r] = r_start[c];
+            L.row_prefix[jq][r] = M + incl - r_cnt[c];
+        }
+        M += __shfl(incl, LPQ - 1, LPQ);
+    }
+#pragma unroll
+    for (int d = 1; d < LPQ; d <<= 1) refined |= __shfl_xor((int)refined, d, LPQ) != 0;
+    const double lim2 = fmin(safe2, far2 * 1.0000001 + 1e-300);
+    fail = fail || refined || M < k || M > NEAR_MAX_POINTS || !(lim2 > 0.0);
+    if (fail) M = 0;
+    if (lane < NQB) L.count[lane] = 0;
+    for (int t = lane; t < NQB * (COOP_NB + 1); t += 64) (&L.hist[0][0])[t] = 0;
+    wave_sync_lds();
+    const double to_bin = (double)COOP_NB / (lim2 > 0.0 ? lim2 : 1.0);
+    auto point_of = [&](int t) {                             // slot t of the group's box -> position in the index
+        int r = 0;
+#pragma unroll
+        for (int step = 16; step > 0; step >>= 1)
+            if (step < ROWS && r + step < n_rows && L.row_prefix[jq][r + step] <= t) r += step;
+        return L.row_start[jq][r] + (t - L.row_prefix[jq][r]);
+    };
+    auto dist2 = [&](int p) {
+        double d = 0.0;
+#pragma unroll
+        for (int j = 0; j < DIM; ++j) {
+            const double u = q[j] - pts[(int64_t)p * DIM + j];
+            d += u * u;
+        }
+        return d;
+    };
+    // ---- pass A: histogram of the squared distances inside the safe radius ------------------------------------------------------
+    for (int t0 = gl; t0 < M; t0 += 4 * LPQ) {
+        int p[4];
+        double d[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) p[u] = point_of(min(t0 + LPQ * u, M - 1));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) d[u] = dist2(p[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (t0 + LPQ * u < M && d[u] < lim2) atomicAdd(&L.hist[jq][min(COOP_NB - 1, (int)(d[u] * to_bin))], 1u);
+    }
+    wave_sync_lds();
+    uint32_t bins[BPL], mine = 0;
+#pragma unroll
+    for (int b = 0; b < BPL; ++b) {
+        bins[b] = L.hist[jq][gl * BPL + b];
+        mine += bins[b];
+    }
+    uint32_t upto = mine;
+#pragma unroll
+    for (int d = 1; d < LPQ; d <<= 1) {
+        const uint32_t u = __shfl_up(upto, d, LPQ);
+        if (gl >= d) upto += u;
+    }
+    const uint32_t total = __shfl(upto, LPQ - 1, LPQ);
+    int b_star = -1;
+    uint32_t below = 0;
+    {
+        uint32_t run = upto - mine;
+        const bool owner = run < (uint32_t)k && upto >= (uint32_t)k;
+#pragma unroll
+        for (int b = 0; b < BPL; ++b) {
+            run += bins[b];
+            if (owner && b_star < 0 && run >= (uint32_t)k) { b_star = gl * BPL + b; below = run; }
+        }
+    }
+#pragma unroll
+    for (int d = 1; d < LPQ; d <<= 1) {
+        b_star = max(b_star, __shfl_xor(b_star, d, LPQ));
+        below = max(below, __shfl_xor(below, d, LPQ));
+    }
+    fail = fail || total < (uint32_t)k || below > (uint32_t)COOP_CAP;
+    if (fail) { M = 0; below = 0; }
+    // ---- pass B: the candidates below the threshold -> the group's short list ---------------------------------------------------
+    for (int t0 = gl; t0 < M; t0 += 4 * LPQ) {
+        int p[4];
+        double d[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) p[u] = point_of(min(t0 + LPQ * u, M - 1));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) d[u] = dist2(p[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (t0 + LPQ * u < M && d[u] < lim2 && min(COOP_NB - 1, (int)(d[u] * to_bin)) <= b_star) {
+                const uint32_t at = min(atomicAdd(&L.count[jq], 1u), (uint32_t)(COOP_CAP - 1));
+                L.list_d[jq][at] = d[u];
+                L.list_p[jq][at] = p[u];
+            }
+    }
+    wave_sync_lds();
+    const int n_list = (int)below;
+    double e_d[ROUNDS];
+    int32_t e_p[ROUNDS], e_less[ROUNDS], e_same[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const int e = max(min(gl + r * LPQ, n_list - 1), 0);
+        e_d[r] = L.list_d[jq][e];
+        e_p[r] = L.list_p[jq][e];
+        e_less[r] = e_same[r] = 0;
+    }
+    for (int m = 0; m < n_list; ++m) {
+        const double dm = L.list_d[jq][m];
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            e_less[r] += dm < e_d[r] ? 1 : 0;
+            e_same[r] += dm == e_d[r] ? 1 : 0;
+        }
+    }
+    bool tie = false;
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) tie |= gl + r * LPQ < n_list && e_same[r] > 1 && e_less[r] < k;
+#pragma unroll
+    for (int d = 1; d < LPQ; d <<= 1) tie |= __shfl_xor((int)tie, d, LPQ) != 0;
+    fail = fail || tie;
+    wave_sync_lds();
+    const int kk = fail ? 0 : k;                              // (a failed group loads and sums nothing: its lists hold no data)
+    double e_y[ROUNDS];
+    bool e_best[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        e_best[r] = gl + r * LPQ < n_list && e_less[r] < kk;
+        e_y[r] = e_best[r] ? y[e_p[r]] : 0.0;
+    }
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r)
+        if (e_best[r]) {
+            L.list_d[jq][e_less[r]] = e_d[r];
+            L.list_y[jq][e_less[r]] = e_y[r];
+            L.list_w[jq][e_less[r]] = 1.0 / sqrt(e_d[r]);
+        }
+    wave_sync_lds();
+    bool zero = false;
+    for (int m = gl; m < kk; m += LPQ) zero |= L.list_d[jq][m] == 0.0;
+#pragma unroll
+    for (int d = 1; d < LPQ; d <<= 1) zero |= __shfl_xor((int)zero, d, LPQ) != 0;
+    auto wgt = [&](int m) { return zero ? (L.list_d[jq][m] == 0.0 ? 1.0 : 0.0) : L.list_w[jq][m]; };
+    auto term = [&](int m) { return L.list_y[jq][m] * wgt(m); };
+    double num = 0.0, den = 0.0;
+    if (kk < 8) {
+        if (gl == 0)
+            for (int m = 0; m < kk; ++m) {
+                num += term(m);
+                den += wgt(m);
+            }
+    } else {
+        double rn = 0.0, rw = 0.0;
+        if (gl < 8) {
+            rn = term(gl);
+            rw = wgt(gl);
+            for (int m = 8; m < kk - (kk % 8); m += 8) {
+                rn += term(m + gl);
+                rw += wgt(m + gl);
+            }
+        }
+        rn += __shfl_xor(rn, 1, LPQ); rw += __shfl_xor(rw, 1, LPQ);
+        rn += __shfl_xor(rn, 2, LPQ); rw += __shfl_xor(rw, 2, LPQ);
+        rn += __shfl_xor(rn, 4, LPQ); rw += __shfl_xor(rw, 4, LPQ);
+        num = rn;
+        den = rw;
+        if (gl == 0)
+            for (int m = kk - (kk % 8); m < kk; ++m) {
+                num += term(m);
+                den += wgt(m);
+            }
+    }
+    result = num / den;
+    return !fail;
+}
+
+// entry of the left-over lists -> query point / where its prediction goes
+template <int DIM>
+__device__ __forceinline__ void leftover_query(int32_t entry, const double *__restrict__ center, const int32_t *__restrict__ level,
+                                               int64_t first, double quarter_width, double (&q)[DIM]) {
+    constexpr int NCH = 1 << DIM;
+    const int64_t cell = first + entry / NCH;
+    const double off = cell_offset(quarter_width, level[cell]);
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) q[j] = center[cell * DIM + j] + dir_comp(DIM, entry % NCH, j) * off;
+}
+
+template <int DIM>
+__device__ __forceinline__ void leftover_store(int32_t entry, double m, int64_t first, double *__restrict__ metric_all,
+                                               double *__restrict__ child_metric) {
+    constexpr int NCH = 1 << DIM, NQ = NCH + 1;
+    metric_all[(int64_t)(entry / NCH) * NQ + 1 + entry % NCH] = m;
+    child_metric[(first + entry / NCH) * NCH + entry % NCH] = m;
+}
+
+// stage one: 2^DIM entries of `rest` per wavefront and round; what it cannot answer goes to `next`
+template <int DIM>
+__global__ void __launch_bounds__(64 * COOP_WAVES)
+child_metric_near_kernel(Grid<DIM> g, const double *__restrict__ pts, const int32_t *__restrict__ cs,
+                         const double *__restrict__ y, const double *__restrict__ center, const int32_t *__restrict__ level,
+                         int64_t first, double quarter_width, int k, double reach, double *__restrict__ metric_all,
+                         double *__restrict__ child_metric, const int32_t *__restrict__ rest, int32_t *__restrict__ next) {
+    constexpr int NCH = 1 << DIM, LPQ = 64 / NCH;
+    __shared__ NearLds<DIM> lds_all[COOP_WAVES];
+    const int lane = threadIdx.x & 63, jg = lane / LPQ;
+    NearLds<DIM> &L = lds_all[threadIdx.x >> 6];
+    const int count = rest[0];
+    for (int e0 = (blockIdx.x * COOP_WAVES + (threadIdx.x >> 6)) * NCH; e0 < count; e0 += gridDim.x * COOP_WAVES * NCH) {
+        const bool active = e0 + jg < count;
+        const int32_t entry = active ? rest[2 + e0 + jg] : 0;
+        double q[DIM], m = 0.0;
+        leftover_query<DIM>(entry, center, level, first, quarter_width, q);
+        const bool ok = near_solve<DIM>(g, pts, cs, y, L, q, active, k, reach, lane, m);
+        if (lane % LPQ == 0 && active) {
+            if (ok) leftover_store<DIM>(entry, m, first, metric_all, child_metric);
+            else next[2 + atomicAdd(&next[0], 1)] = entry;
+        }
+    }
+}
+
+// stage two: one wavefront per entry of `rest`; what it cannot answer goes to `next` (the per-lane kernel's list)
 template <int DIM>
 __global__ void __launch_bounds__(64 * COOP_WAVES)
 child_metric_far_kernel(Grid<DIM> g, const double *__restrict__ pts, const int32_t *__restrict__ orig,
                         const int32_t *__restrict__ cs, const double *__restrict__ y, const double *__restrict__ center,
-                        const int32_t *__restrict__ level, int64_t first, double quarter_width, int k,
+                        const int32_t *__restrict__ level, int64_t first, double quarter_width, int k, double reach,
                         double *__restrict__ metric_all, double *__restrict__ child_metric, const int32_t *__restrict__ rest,
-                        int32_t *__restrict__ rest2) {
-    constexpr int NCH = 1 << DIM, NQ = NCH + 1;
+                        int32_t *__restrict__ next) {
     __shared__ FarLds lds_all[COOP_WAVES];
     const int lane = threadIdx.x & 63;
     FarLds &L = lds_all[threadIdx.x >> 6];
     const int count = rest[0];
-    const bool coarse_to_lanes = rest[1] > FAR_COARSE_MAX;
     for (int e = blockIdx.x * COOP_WAVES + (threadIdx.x >> 6); e < count; e += gridDim.x * COOP_WAVES) {
-        const int32_t entry = rest[2 + e] & ~FAR_COARSE_FLAG;
-        const int64_t i = entry / NCH;
-        const int jq = entry % NCH;
-        const int64_t cell = first + i;
-        const double off = cell_offset(quarter_width, level[cell]);
-        double q[DIM];
-#pragma unroll
-        for (int j = 0; j < DIM; ++j) q[j] = center[cell * DIM + j] + dir_comp(DIM, jq, j) * off;
-        bool ok = false, hopeless = k > COOP_CAP || (coarse_to_lanes && (rest[2 + e] & FAR_COARSE_FLAG) != 0);
-        double m = 0.0;
+        const int32_t entry = rest[2 + e];
+        double q[DIM], m = 0.0;
+        leftover_query<DIM>(entry, center, level, first, quarter_width, q);
+        bool ok = false, hopeless = k > COOP_CAP;
 #pragma unroll 1
         for (int attempt = 0; attempt < 4 && !ok && !hopeless; ++attempt)
-            ok = far_solve<DIM>(g, pts, orig, cs, y, L, q, k, FAR_RADII[attempt], lane, hopeless, m);
+            ok = far_solve<DIM>(g, pts, orig, cs, y, L, q, k, FAR_BALLS[attempt] * reach, lane, hopeless, m);
         if (lane == 0) {
-            if (ok) {
-                metric_all[i * NQ + 1 + jq] = m;
-                child_metric[cell * NCH + jq] = m;
-            } else {
-                rest2[2 + atomicAdd(&rest2[0], 1)] = entry;
-            }
+            if (ok) leftover_store<DIM>(entry, m, first, metric_all, child_metric);
+            else next[2 + atomicAdd(&next[0], 1)] = entry;
         }
     }
 }
@@ -1602,7 +1918,7 @@ static bool knn_coop_enabled() {
 
 static int64_t knn_coop_min_cells() {
     const char *e = getenv("S3_KNN_COOP_MIN");
-    return e ? atoll(e) : 4096ll;
+    return e ? atoll(e) : 1ll;
 }
 static bool knn_coop_forced() {
     const char *e = getenv("S3_KNN_COOP");
@@ -1638,19 +1954,26 @@ static int child_gain_impl(const s3_knn *knn, int k, const double *d_center, con
     child_metric_coop_kernel<DIM><<<grid_for(n, COOP_WAVES), 64 * COOP_WAVES, 0, st>>>(                                       \
         make_grid<DIM>(knn), knn->pts, knn->orig, knn->cell_start, knn->y, d_center, d_level, first, n, qw, k, reach,        \
         d_scratch, d_parents, parents_offset, d_child_metric, d_rest);                                                        \
-    child_metric_far_kernel<DIM><<<grid_for(n * (1 << DIM), COOP_WAVES, 8192), 64 * COOP_WAVES, 0, st>>>(                      \
-        make_grid<DIM>(knn), knn->pts, knn->orig, knn->cell_start, knn->y, d_center, d_level, first, qw, k, d_scratch,        \
+    child_metric_near_kernel<DIM><<<grid_for(n, COOP_WAVES, 8192), 64 * COOP_WAVES, 0, st>>>(                                  \
+        make_grid<DIM>(knn), knn->pts, knn->cell_start, knn->y, d_center, d_level, first, qw, k, reach, d_scratch,            \
         d_child_metric, d_rest, d_rest2);                                                                                     \
-    child_metric_rest_kernel<DIM><<<grid_for(n * (1 << DIM), KNN_BLOCK, 256), KNN_BLOCK, lds, st>>>(make_grid<DIM>(knn), knn->pts, knn->orig, knn->cell_start, knn->y,  \
-                                                             d_center, d_level, first, qw, k, d_scratch, d_child_metric, d_rest2); \
+    S3_HIP_CHECK(hipMemsetAsync(d_rest, 0, 2 * sizeof(int32_t), st));                                                         \
+    child_metric_far_kernel<DIM><<<grid_for(n * (1 << DIM), COOP_WAVES, 8192), 64 * COOP_WAVES, 0, st>>>(                      \
+        make_grid<DIM>(knn), knn->pts, knn->orig, knn->cell_start, knn->y, d_center, d_level, first, qw, k, reach, d_scratch, \
+        d_child_metric, d_rest2, d_rest);                                                                                     \
+    child_metric_rest_kernel<DIM><<<grid_for(n * (1 << DIM), KNN_BLOCK, 256), KNN_BLOCK, lds, st>>>(                           \
+        make_grid<DIM>(knn), knn->pts, knn->orig, knn->cell_start, knn->y, d_center, d_level, first, qw, k, d_scratch,        \
+        d_child_metric, d_rest);                                                                                              \
     } while (0)
-    // one wavefront per cell (S3_KNN_COOP=0: the per-lane search for every child point, as for cells without a known parent)
-    // Measured on MI355X: cylinder3D, adaptive batches of ~40 000 new cells: 0.37 ms (wavefront per cell) + 0.23 ms (streaming
-    // search for what it leaves: coarse cells, cells next to the body) + nothing left for the per-lane kernel, against 1.16 ms
-    // for the per-lane kernel alone -- the refine's wall-clock does not move (0.060 s either way: the host's set bookkeeping
-    // runs beside these kernels and takes as long); box5e7, batches of ~230 000 fine cells: 3.8 + 0.12 ms against 7.0 ms, refine
-    // 0.70 -> 0.56 - 0.58 s.  Batches of the uniform levels (every cell coarse) end up in the per-lane kernel as before.
-    // Tiny batches skip the three launches (S3_KNN_COOP_MIN cells; S3_KNN_COOP=1 forces them for every batch, =0 switches them off).
+    // The wavefront kernels (S3_KNN_COOP=0: the per-lane search for every child point, as for cells without a known parent):
+    //   coop -- one wavefront per cell, one shared box;  near -- what that leaves (cells too large for one box: the uniform
+    //   levels, the first adaptive batches), 2^dim queries per wavefront, each its own small box;  far -- what that leaves (next
+    //   to a body, at the edge of the cloud, outside it), one wavefront per query, boxes of growing size;  rest -- per lane.
+    // Measured on MI355X (rocprofv3 per launch): cylinder3D, adaptive batches of ~40 000 new cells: 0.37 + 0.08 + 0.21 ms against
+    // 1.16 ms for the per-lane kernel alone, the first adaptive batch 0.47 + 0.53 + 1.1 ms, the batches of the uniform levels
+    // 0.1 - 0.3 ms instead of 0.4 - 1.4 ms (a per-lane wavefront lives that long however few queries it has); refine
+    // 0.058 -> 0.050 s on one box.  box5e7, batches of ~230 000 fine cells: 3.8 - 4.2 + 0.5 - 1.1 + 0.05 ms against 7.0 ms,
+    // refine 0.70 -> 0.57 s.
     const bool coop = d_parents != nullptr && knn_coop_enabled() && (n >= knn_coop_min_cells() || knn_coop_forced());
     // how far (in bucket sides) the box reaches beyond the child points: the radius of the ball that holds k points at the
     // index's average occupancy, plus a margin (S3_KNN_COOP_MARGIN, default 1.15); where the cloud is thinner than that the
@@ -1659,8 +1982,8 @@ static int child_gain_impl(const s3_knn *knn, int k, const double *d_center, con
     const double ball = dim == 3 ? std::cbrt(3.0 * k / (4.0 * 3.14159265358979323846 * occupancy))
                                  : std::sqrt(k / (3.14159265358979323846 * occupancy));
     const double reach = ball * knn_coop_margin();
-    // behind the n * (2^dim + 1) doubles of d_scratch: a counter and the list of the queries left to the per-lane search
-    // two such lists: what the wavefront-per-cell kernel leaves to the streaming search, and what that leaves to the per-lane one
+    // behind the n * (2^dim + 1) doubles of d_scratch: two lists (counter, pad, entries) that the kernels hand on in turns:
+    // coop -> rest -> near -> rest2 -> far -> rest (emptied in between) -> per-lane kernel
     int32_t *d_rest = reinterpret_cast<int32_t *>(d_scratch + n * ((1 << dim) + 1));
     int32_t *d_rest2 = d_rest + 2 + n * (1 << dim);
     if (coop) {

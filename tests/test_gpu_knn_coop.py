@@ -1,5 +1,5 @@
-"""The wavefront-per-cell form of the refine's child-metric search (csrc/knn.hip: child_metric_coop_kernel + the per-lane
-search for what it leaves over) against the per-lane kernel: same bits.  GPU only."""
+"""The wavefront form of the refine's child-metric search (csrc/knn.hip: child_metric_coop_kernel, then child_metric_near_kernel,
+child_metric_far_kernel and the per-lane search for what each leaves over) against the per-lane kernel: same bits.  GPU only."""
 import numpy as np
 import pytest
 import torch as pt
@@ -56,7 +56,7 @@ def test_wavefront_per_cell_equals_per_lane(monkeypatch, dim, k, cloud):
 def test_refine_goldens_through_the_wavefront_kernels(monkeypatch, name):
     """the reference's grids (cell ids / levels / centres / faces / vertices / per-cell metric + gain, bit for bit) with every batch
     forced through the wavefront-per-cell kernel, the streaming search and the per-lane search for what they leave
-    (S3_KNN_COOP=1; by default only batches of >= 4096 cells take that route)"""
+    (S3_KNN_COOP=1: whatever S3_KNN_COOP_MIN says)"""
     import sparsespatialsampling_amd.s_cube as s_cube
     from sparsespatialsampling_amd import geometry
     from inputs import refine_inputs, sha

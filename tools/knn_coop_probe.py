@@ -44,8 +44,9 @@ for lv in (6, 7, 8, 9, 10):
         run = lambda: hipops.child_gain_reuse(knn, k, center, level, 8, n, width, lf, 1.0, metric_d, gain_d, scratch, parents, 0, child)
         ms = timed(run)
         tail = scratch[n * (nch + 1):].view(pt.int32)
-        left = (int(tail[0]), int(tail[2 + n * nch])) if mode == "1" else (0, 0)
+        # second list: what the grouped search left to one wavefront per query; first list (reused): what that left per lane
+        left = (int(tail[2 + n * nch]), int(tail[0])) if mode == "1" else (0, 0)
         out[mode] = (ms, child[8:8 + n].clone(), gain_d[8:8 + n].clone(), left)
     same = bool(pt.equal(out["1"][1], out["0"][1]) and pt.equal(out["1"][2], out["0"][2]))
-    print(f"level {lv} (cell {width / 2 ** lv:.5f}, quarter {width / 2 ** lv / 4:.5f}): wavefront per cell {out['1'][0]:.3f} ms "
-          f"({out['1'][3][0]} of {n * nch} queries to the streaming search, {out['1'][3][1]} to the per-lane search), per-lane kernel {out['0'][0]:.3f} ms, same bits {same}", flush=True)
+    print(f"level {lv} (cell {width / 2 ** lv:.5f}, quarter {width / 2 ** lv / 4:.5f}): wavefront kernels {out['1'][0]:.3f} ms "
+          f"({out['1'][3][0]} of {n * nch} queries to one wavefront each, {out['1'][3][1]} to the per-lane search), per-lane kernel {out['0'][0]:.3f} ms, same bits {same}", flush=True)

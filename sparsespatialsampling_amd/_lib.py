@@ -146,6 +146,12 @@ TOPO_SIGNATURES = {
     "s3set_discard": (None, [c_vp, c_i64]),
     "s3set_update_ids": (c_int, [c_vp, c_vp, c_i64]),
     "s3set_update_range": (c_int, [c_vp, c_i64, c_i64]),
+    "s3set_update_rangeset": (c_int, [c_vp, c_i64, c_i64]),
+    "s3set_range_mask": (c_i64, [c_i64]),
+    "s3set_difference_update_ids": (c_int, [c_vp, c_vp, c_i64]),
+    "s3set_update_rangeset_async": (c_int, [c_vp, c_i64, c_i64]),
+    "s3set_difference_update_ids_async": (c_int, [c_vp, c_vp, c_i64]),
+    "s3set_wait": (c_int, [c_vp]),
     "s3set_update_set": (c_int, [c_vp, c_vp]),
     "s3set_difference_update": (c_int, [c_vp, c_vp]),
     "s3set_to_array": (None, [c_vp, c_vp]),

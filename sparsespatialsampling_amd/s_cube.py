@@ -20,6 +20,7 @@ The reference rejects nothing on the CPU; this implementation has no CPU compute
 """
 import ctypes as C
 import logging
+import os
 from time import time
 from typing import Union
 
@@ -27,7 +28,7 @@ import numpy as np
 import torch as pt
 
 from . import _lib
-from .intset import IntSet
+from .intset import IntSet, RangeSet
 
 logger = logging.getLogger(__name__)
 logging.basicConfig(level=logging.INFO, format='[%(asctime)s] %(levelname)-8s %(message)s', datefmt='%Y-%m-%d %H:%M:%S',
@@ -54,7 +55,7 @@ def _make_backend(vertices, target, k):
 
 def _ordered(ids):
     """the elements of an ``IntSet`` / ``set`` in iteration order, int64"""
-    if isinstance(ids, IntSet):
+    if isinstance(ids, (IntSet, RangeSet)):
         return ids.to_array()
     return np.fromiter(ids, dtype=np.int64, count=len(ids))
 
@@ -469,7 +470,8 @@ class SamplingTree(object):
         # IntSet = CPython's set restated natively (same iteration order); the 2:1-balance mode interleaves single
         # insertions with topology queries and stays on the interpreter's sets
         self._new_set = set if max_delta_level else IntSet
-        self._leaf_cells = self._new_set()
+        # (S3_LEAF_SET_THREAD=0: every update of the leaf set on the caller's thread)
+        self._leaf_cells = set() if max_delta_level else IntSet(deferred=os.environ.get("S3_LEAF_SET_THREAD", "1") != "0")
         self._n_cells_after_uniform = None
         self._N_cells_per_iter = []
         self._final_nodes = None
@@ -545,9 +547,25 @@ class SamplingTree(object):
             self._values = self._backend.download(self._topo_engine.n_created)
         return self._values
 
-    def _update_leaf_cells(self, idx_parents: set, idx_children: set) -> None:
-        self._leaf_cells -= idx_parents
+    def _update_leaf_cells(self, idx_parents, idx_children) -> None:
+        """``_leaf_cells -= all_parents; _leaf_cells.update(all_children)`` (s_cube.py:552-553, 897-898).  With the native
+        sets the parents arrive as the ordered id array (discards do not depend on their order: the set ``all_parents`` is
+        never built) and the children as a ``RangeSet``"""
+        if isinstance(idx_parents, np.ndarray):
+            self._leaf_cells.difference_update_ids(idx_parents)
+        else:
+            self._leaf_cells -= idx_parents
         self._leaf_cells.update(idx_children)
+
+    def _batch_sets(self, order, first, n_new):
+        """(all_parents, all_children) of a refine batch: Python sets in the 2:1-balance mode, otherwise the parents' id array
+        and the virtual set of the consecutive new ids"""
+        if self._new_set is set:
+            all_parents, all_children = set(), set()
+            all_parents.update(order.tolist())
+            all_children.update(range(first, first + n_new))
+            return all_parents, all_children
+        return order, RangeSet(first, first + n_new)
 
     def _update_min_ref_level(self) -> None:
         level = self._topo_engine.level_now
@@ -616,9 +634,7 @@ class SamplingTree(object):
             logger.info(f"\r\tStarting iteration no. {j}, N_cells = {len(self._leaf_cells)}")
             order = _ordered(self._leaf_cells)
             first, n_new = self._refine_batch(order, uniform=True)
-            all_parents, all_children = self._new_set(), self._new_set()
-            all_parents.update(order.tolist() if self._new_set is set else order)
-            all_children.update(range(first, first + n_new))
+            all_parents, all_children = self._batch_sets(order, first, n_new)
             self._update_leaf_cells(all_parents, all_children)
             self._current_min_level += 1
             self._current_max_level += 1
@@ -634,9 +650,7 @@ class SamplingTree(object):
         if len(order):
             self._current_max_level = max(self._current_max_level, int(self._topo_engine.level_now[order].max()) + 1)
         first, n_new = self._refine_batch(order, uniform=False)
-        all_parents, all_children = self._new_set(), self._new_set()
-        all_parents.update(order.tolist() if self._new_set is set else order)
-        all_children.update(range(first, first + n_new))
+        all_parents, all_children = self._batch_sets(order, first, n_new)
         self._update_leaf_cells(all_parents, all_children)
         self._new_children = all_children          # == set(range(first, first + n_new)), reused by the callers
         return first, n_new
@@ -674,8 +688,13 @@ class SamplingTree(object):
         elif _refine_geometry:
             return _idx
         else:
-            self._topo_engine.submit_mark_invalid(_ordered(_idx))
-            self._leaf_cells -= _idx
+            invalid = _ordered(_idx)
+            self._topo_engine.submit_mark_invalid(invalid)
+            if isinstance(self._leaf_cells, IntSet):
+                # (== `-= _idx`: discards do not depend on their order; the ids are the new cells just merged in)
+                self._leaf_cells.difference_update_ids(invalid)
+            else:
+                self._leaf_cells -= _idx
             return None
 
     def refine(self) -> None:

@@ -130,3 +130,106 @@ def test_errors_and_views():
     t = s.copy()
     t -= s
     assert len(t) == 0 and not t and s.issubset(IntSet(range(0, 10)))
+
+
+
+@pytest.mark.parametrize("n", [0, 1, 4, 5, 6, 19, 20, 77, 1229, 13107, 13108, 50000, 52429, 52430, 209715, 209716, 400000])
+def test_range_sets_without_their_table(n):
+    """set(); s.update(range(a, a + n)) in closed form (IntSet.update(range) on a new set, RangeSet): table, mask, order"""
+    from sparsespatialsampling_amd.intset import RangeSet
+    for a in (0, 1, 7, 4096, 123457, 1 << 22):
+        py = set()
+        py.update(range(a, a + n))
+        nat = IntSet()
+        nat.update(range(a, a + n))
+        assert same(py, nat), (a, n)
+        r = RangeSet(a, a + n)
+        m, _, _ = real_table(py)
+        assert (n == 0 or r.mask == m) and r.to_array().tolist() == list(py) and len(r) == n
+        assert (a in r) == (a in py) and (a + n in r) == (a + n in py)
+
+
+@pytest.mark.parametrize("deferred", [False, True])
+@pytest.mark.parametrize("seed", range(8))
+def test_refine_loop_trace_with_virtual_sets(seed, deferred):
+    """the refine loop's bookkeeping (leaf -= all_parents; leaf |= all_children; leaf -= invalid) with all_parents replaced
+    by its id array (IntSet.difference_update_ids) and all_children by a RangeSet, against real Python sets slot by slot;
+    deferred: the two bulk updates applied by the set's worker thread"""
+    from sparsespatialsampling_amd.intset import RangeSet
+    rng = np.random.default_rng(seed)
+    py, nat = set(), IntSet(deferred=deferred)
+    py.add(0); nat.add(0)
+    first, nch = 1, (4 if seed % 2 else 8)
+    for it in range(30):
+        leaves = np.fromiter(py, dtype=np.int64, count=len(py))
+        if it < 3:
+            picked = leaves
+        else:
+            picked = rng.choice(leaves, min(max(1, len(leaves) // 6), int(rng.choice([40, 900, 7000]))), replace=False)
+        to_refine_py, to_refine_nat = set(), IntSet()
+        to_refine_py.update(picked.tolist()); to_refine_nat.update(picked)
+        order = to_refine_nat.to_array()
+        assert order.tolist() == list(to_refine_py)
+        n_new = nch * len(order)
+        all_parents, all_children = set(), set()
+        all_parents.update(order.tolist())
+        all_children.update(range(first, first + n_new))
+        py -= all_parents
+        py.update(all_children)
+        children = RangeSet(first, first + n_new)
+        assert children.to_array().tolist() == list(all_children)
+        nat.difference_update_ids(order)
+        nat.update(children)
+        assert same(py, nat), (seed, it)
+        new_ids = children.to_array()
+        bad = new_ids[rng.random(n_new) < (0.15 if it % 4 == 0 else 0.0)]
+        bad_py = set(i for i in bad.tolist() if i)
+        py -= bad_py
+        nat -= IntSet().update_flagged(new_ids, np.isin(new_ids, bad))
+        assert same(py, nat), (seed, it)
+        first += n_new
+    other = IntSet()
+    other.update(RangeSet(10, 500))                 # empty target: the slot-wise copy / clean insertion paths of set_merge
+    ref = set()
+    ref.update(set(range(10, 500)))
+    assert same(ref, other)
+    nat -= RangeSet(first - 5, first)
+    py -= set(range(first - 5, first))
+    assert same(py, nat)
+
+
+def test_deferred_sets_end_their_thread_and_serve_as_sources():
+    import threading
+    from sparsespatialsampling_amd.intset import RangeSet
+    before = threading.active_count()                  # (native threads are not counted: this only checks nothing leaks here)
+    for _ in range(50):
+        s = IntSet(deferred=True)
+        s.update(RangeSet(5, 70000))
+        s.difference_update_ids(np.arange(100, 60000))
+        t = IntSet(s)                                  # a set with queued updates as the source of another set's update
+        ref = set()
+        ref.update(set(range(5, 70000)))
+        ref -= set(range(100, 60000))
+        assert same(ref, s) and sorted(t.to_array().tolist()) == sorted(ref)
+        assert (99 in s) and (100 not in s) and len(s) == len(ref)
+        del s, t
+    assert threading.active_count() == before
+
+
+def test_deferred_updates_declare_their_effect_on_the_length():
+    """len() of a deferred set answers from the declared effect of the queued updates; when the queue is drained a declaration
+    that did not hold (ids that were not new / not members) raises"""
+    from sparsespatialsampling_amd.intset import RangeSet
+    s = IntSet(deferred=True)
+    s.update(RangeSet(0, 1000))
+    s.difference_update_ids(np.arange(10, 20))
+    assert len(s) == 990 and s.to_array().size == 990
+    s.update(RangeSet(500, 600))                       # not new
+    assert len(s) == 1090
+    with pytest.raises(RuntimeError):
+        s.to_array()
+    assert len(s) == 990                               # the set itself is what CPython's would be
+    s.difference_update_ids(np.arange(10, 20))         # not members
+    with pytest.raises(RuntimeError):
+        5 in s
+    assert len(s) == 990

@@ -53,14 +53,25 @@ def synchronize():
 
 
 def to_device(x, dtype=None):
-    """numpy / CPU tensor / CUDA tensor -> contiguous CUDA tensor (optionally cast).  Large host tensors go through the
-    native staged upload (s3_upload_rows), small ones through a plain copy."""
+    """numpy / CPU tensor / CUDA tensor -> contiguous CUDA tensor (optionally cast).  Host tensors go through the native
+    staged upload (s3_upload_rows: a memcpy into a page-locked buffer plus an asynchronous copy on the current stream -- a
+    plain copy from pageable memory blocks the caller for ~0.2 ms however small it is, and the refine loop uploads two id
+    lists per iteration), in 1-MiB rows when they are large."""
     if isinstance(x, np.ndarray):
         x = pt.from_numpy(np.ascontiguousarray(x))
     if dtype is not None and x.dtype != dtype:
         x = x.to(dtype)
     dev = device()
-    if x.is_cuda or not x.is_contiguous() or x.numel() * x.element_size() < (32 << 20):
+    if x.is_cuda or not x.is_contiguous() or x.numel() == 0:
+        return x.to(dev, non_blocking=False).contiguous()
+    nbytes = x.numel() * x.element_size()
+    if nbytes <= (4 << 20):
+        out = pt.empty(x.shape, dtype=x.dtype, device=dev)
+        rc = _lib.hip_lib().s3_upload_rows(C.c_void_p(x.data_ptr()), 1, nbytes, C.c_void_p(out.data_ptr()), nbytes, _stream())
+        if rc == 0:
+            return out                                          # (x was copied into the staging buffer: it may be reused)
+        return x.to(dev, non_blocking=False).contiguous()       # no page-locked staging memory on this host
+    if nbytes < (32 << 20):
         return x.to(dev, non_blocking=False).contiguous()
     out = pt.empty(x.shape, dtype=x.dtype, device=dev)
     flat_h, flat_d = x.reshape(-1), out.reshape(-1)

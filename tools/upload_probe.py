@@ -1,41 +1,41 @@
-"""dev helper: host -> device upload strategies for one snapshot batch [N, T] fp32 into 128-B-pitched device rows"""
-import sys, time
-import torch as pt
-sys.path.insert(0, ".")
-from sparsespatialsampling_amd import hipops
-N = 4_991_774
-for T in (25, 200):
-    d = pt.randn((N, T), dtype=pt.float32)
-    rows = hipops.padded_rows(N, T, pt.float32, "cuda")
-    def t_(f, reps=3):
-        f(); pt.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            f()
-        pt.cuda.synchronize()
-        return (time.perf_counter() - t0) / reps
-    gb = d.numel() * 4 / 1e9
-    a = t_(lambda: rows.copy_(d))
-    print(f"T={T}: {gb:.2f} GB  direct strided copy_      {a*1e3:8.1f} ms  {gb/a:6.1f} GB/s", flush=True)
-    dev = pt.empty((N, T), dtype=pt.float32, device="cuda")
-    b = t_(lambda: (dev.copy_(d), rows.copy_(dev)))
-    print(f"T={T}:          contiguous H2D + device repitch {b*1e3:8.1f} ms  {gb/b:6.1f} GB/s", flush=True)
-    for slab_mb in (64, 256):
-        slab = max(1, slab_mb * (1 << 20) // (T * 4))
-        pins = [pt.empty((slab, T), dtype=pt.float32).pin_memory() for _ in range(2)]
-        evs = [pt.cuda.Event() for _ in range(2)]
-        def piped():
-            i = 0
-            for s0 in range(0, N, slab):
-                s1 = min(N, s0 + slab)
-                evs[i].synchronize()                       # the pinned buffer is free again
-                pins[i][: s1 - s0].copy_(d[s0:s1])         # host memcpy (torch parallelises it)
-                rows[s0:s1].copy_(pins[i][: s1 - s0], non_blocking=True)
-                evs[i].record()
-                i ^= 1
-        c = t_(piped)
-        print(f"T={T}:          pinned double buffer {slab_mb:4d} MB      {c*1e3:8.1f} ms  {gb/c:6.1f} GB/s", flush=True)
-    dp = d.pin_memory()
-    e = t_(lambda: rows.copy_(dp, non_blocking=True))
-    print(f"T={T}:          source already pinned            {e*1e3:8.1f} ms  {gb/e:6.1f} GB/s", flush=True)
-    del d, dp, rows, dev
+"""dev helper: where the time of a small host -> device upload goes (hipops.to_device on a 20 KB id list)"""
+import os, sys, time, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch as pt
+from sparsespatialsampling_amd import hipops, _lib
+
+x = np.arange(5000, dtype=np.int32)
+hipops.to_device(x); pt.cuda.synchronize()
+
+
+def t(label, fn, n=200, sync_each=False):
+    pt.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+        if sync_each:
+            pt.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    pt.cuda.synchronize()
+    print(f"{label:50s} {dt * 1e6:8.1f} us")
+
+
+xt = pt.from_numpy(x)
+dev = hipops.device()
+out = pt.empty(5000, dtype=pt.int32, device=dev)
+lib = _lib.hip_lib()
+t("hipops.device()", lambda: hipops.device())
+t("pt.from_numpy + ascontiguousarray", lambda: pt.from_numpy(np.ascontiguousarray(x)))
+t("pt.empty on device", lambda: pt.empty(5000, dtype=pt.int32, device=dev))
+t("hipops._stream()", lambda: hipops._stream())
+t("s3_upload_rows 20 KB", lambda: lib.s3_upload_rows(C.c_void_p(xt.data_ptr()), 1, 20000, C.c_void_p(out.data_ptr()), 20000, hipops._stream()))
+t("s3_upload_rows 20 KB, sync each", lambda: lib.s3_upload_rows(C.c_void_p(xt.data_ptr()), 1, 20000, C.c_void_p(out.data_ptr()), 20000, hipops._stream()), sync_each=True)
+t("x.to(dev) 20 KB", lambda: xt.to(dev))
+t("hipops.to_device 20 KB", lambda: hipops.to_device(x))
+big = np.arange(250000, dtype=np.int32)
+bt = pt.from_numpy(big)
+t("hipops.to_device 1 MB", lambda: hipops.to_device(big))
+t("x.to(dev) 1 MB", lambda: bt.to(dev))
+flags = pt.zeros(40000, dtype=pt.uint8, device=dev)
+t("flags.cpu() 40 KB", lambda: flags.cpu())
+t("sync only", lambda: pt.cuda.synchronize())

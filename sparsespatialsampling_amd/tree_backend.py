@@ -90,15 +90,17 @@ class HipTreeBackend:
         if e > b:
             scratch = pt.empty((e - b) * (self.nch + 1) + 2 + (e - b) * self.nch, dtype=pt.float64, device=self.dev)
             # a new cell's centre is a point its parent's call predicted already: only the 2^d child points are searched
-            # (8 of 9 queries in 3-D).  Not for the root's children (the root was evaluated on the host) and not with several
-            # ranks, where a parent's entry may live on another rank (the values are the same either way).
-            reuse = self.comm.world == 1 and self._parents_known(parents)
+            # (8 of 9 queries in 3-D), by the wavefront kernels.  Not for the root's children (the root was evaluated on the
+            # host).  With several ranks the rows of child_metric travel with the metric and the gain below, so a parent's
+            # entry is at hand whichever rank computed it.
+            reuse = self._parents_known(parents)
             hipops.child_gain_reuse(self.knn, self.k, self.center, self.level, first + b, e - b, float(self.width),
                                     self.level_factor, self.gain0, self.metric, self.gain, scratch,
                                     self._parents if reuse else None, b, self.child_metric)
         # ... and one grouped all-gather hands every rank the others' slices
         if self.comm.world > 1:
-            self.comm.allgather_inplace([self.metric[first:], self.gain[first:]], [chunk, chunk])
+            self.comm.allgather_inplace([self.metric[first:], self.gain[first:], self.child_metric[first:].view(-1)],
+                                        [chunk, chunk, chunk * self.nch])
         return n_new
 
     def _parents_known(self, parents):

@@ -75,7 +75,13 @@ class HipTreeBackend:
         self.metric[0] = float(root_metric)
         self.gain[0] = float(root_gain)
         self.leaf[0] = 1
-        self._child_metric_from = 1          # cells with this id or a larger one have their row of child_metric filled
+        # the root's own row of child_metric (the centre values of its children), so that the first batch already takes the
+        # 8-query wavefront route: the root as a batch of one cell, its metric and gain (known from the host) written aside
+        aside = pt.zeros(2, dtype=pt.float64, device=self.dev)
+        scratch = pt.empty((self.nch + 1) + 2 + self.nch, dtype=pt.float64, device=self.dev)
+        hipops.child_gain_reuse(self.knn, self.k, self.center, self.level, 0, 1, float(self.width), self.level_factor,
+                                self.gain0, aside[:1], aside[1:], scratch, pt.zeros(1, dtype=pt.int32, device=self.dev), 0,
+                                self.child_metric)
 
     def refine_batch(self, parents, first):
         """children of the ordered ``parents`` become cells first..first+len*2^d-1; their metric and gain are
@@ -90,23 +96,17 @@ class HipTreeBackend:
         if e > b:
             scratch = pt.empty((e - b) * (self.nch + 1) + 2 + (e - b) * self.nch, dtype=pt.float64, device=self.dev)
             # a new cell's centre is a point its parent's call predicted already: only the 2^d child points are searched
-            # (8 of 9 queries in 3-D), by the wavefront kernels.  Not for the root's children (the root was evaluated on the
-            # host).  With several ranks the rows of child_metric travel with the metric and the gain below, so a parent's
-            # entry is at hand whichever rank computed it.
-            reuse = self._parents_known(parents)
+            # (8 of 9 queries in 3-D), by the wavefront kernels (the root's row was filled by start()).  With several ranks
+            # the rows of child_metric travel with the metric and the gain below, so a parent's entry is at hand whichever
+            # rank computed it.
             hipops.child_gain_reuse(self.knn, self.k, self.center, self.level, first + b, e - b, float(self.width),
-                                    self.level_factor, self.gain0, self.metric, self.gain, scratch,
-                                    self._parents if reuse else None, b, self.child_metric)
+                                    self.level_factor, self.gain0, self.metric, self.gain, scratch, self._parents, b,
+                                    self.child_metric)
         # ... and one grouped all-gather hands every rank the others' slices
         if self.comm.world > 1:
             self.comm.allgather_inplace([self.metric[first:], self.gain[first:], self.child_metric[first:].view(-1)],
                                         [chunk, chunk, chunk * self.nch])
         return n_new
-
-    def _parents_known(self, parents):
-        """every parent of the batch was itself created by ``refine_batch`` of this backend with one rank (its entry of
-        ``child_metric`` is filled): all but the root"""
-        return int(np.min(parents)) >= self._child_metric_from
 
     def mask(self, geometries, refine_mode, cells=None, first=0, n=None):
         """OR of the geometry verdicts (s_cube.py:1831-1837) for the cells ``cells`` (ordered id array) or the id

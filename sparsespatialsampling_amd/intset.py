@@ -36,12 +36,13 @@ class IntSet:
     the leaves just refined / new cells just found invalid) -- so ``len()`` answers from that bookkeeping without waiting
     and the worker may run several iterations behind; when the queue is drained the real length is compared with the
     declared one and a mismatch raises."""
-    __slots__ = ("_lib", "_h", "_deferred", "_declared")
+    __slots__ = ("_lib", "_h", "_deferred", "_declared", "_order")
 
     def __init__(self, items=None, deferred=False):
         self._lib = _lib.topo_lib()
         self._deferred = bool(deferred)
         self._declared = None              # length after the queued updates, while any are outstanding
+        self._order = None                 # to_array() of the current state (read-only), dropped by every update
         self._h = C.c_void_p(self._lib.s3set_create())
         if not self._h.value:
             raise MemoryError("IntSet: out of host memory")
@@ -58,6 +59,7 @@ class IntSet:
     def update(self, items):
         """``s.update(x)``: ``x`` an IntSet (set_merge), a ``range`` with step 1, or a sequence / array of ids (one
         insertion per element, in order)"""
+        self._order = None
         if isinstance(items, RangeSet) and self._deferred:
             self._declared = len(self) + len(items)
             _check(self._lib.s3set_update_rangeset_async(self._h, items.start, items.stop))
@@ -81,6 +83,7 @@ class IntSet:
         if len(a) != len(f):
             raise ValueError("ids and flags differ in length")
         self._settle()
+        self._order = None
         _check(self._lib.s3set_update_flagged(self._h, a.ctypes.data_as(C.c_void_p), f.ctypes.data_as(C.c_void_p), len(a)))
         return self
 
@@ -95,6 +98,7 @@ class IntSet:
             other = IntSet(other)
         self._settle()
         other._settle()
+        self._order = None
         _check(self._lib.s3set_difference_update(self._h, other._h))
         return self
 
@@ -102,6 +106,7 @@ class IntSet:
         """``s -= set(ids)`` for distinct ids without building that set: discards do not depend on their order, and the
         rebuild rule of set_difference_update_internal looks at the table once, at the end"""
         a = _ids(ids)
+        self._order = None
         if self._deferred:
             self._declared = len(self) - len(a)
             _check(self._lib.s3set_difference_update_ids_async(self._h, a.ctypes.data_as(C.c_void_p), len(a)))   # (copies the ids)
@@ -124,10 +129,12 @@ class IntSet:
 
     def add(self, key):
         self._settle()
+        self._order = None
         _check(self._lib.s3set_add(self._h, int(key)))
 
     def discard(self, key):
         self._settle()
+        self._order = None
         self._lib.s3set_discard(self._h, int(key))
 
     # -- queries ----------------------------------------------------------------------------------------------
@@ -144,11 +151,15 @@ class IntSet:
         return bool(self._lib.s3set_contains(self._h, int(key)))
 
     def to_array(self):
-        """the elements in iteration order, int64"""
+        """the elements in iteration order, int64 (read-only: the array is kept until the set changes -- the tree asks for the
+        order of its 10^7 leaves three times in a row at the end of a refine, each a scan of a 256 MB table)"""
         self._settle()
-        out = np.empty(len(self), dtype=np.int64)
-        self._lib.s3set_to_array(self._h, out.ctypes.data_as(C.c_void_p))
-        return out
+        if self._order is None:
+            out = np.empty(len(self), dtype=np.int64)
+            self._lib.s3set_to_array(self._h, out.ctypes.data_as(C.c_void_p))
+            out.setflags(write=False)
+            self._order = out
+        return self._order
 
     def __iter__(self):
         return iter(self.to_array().tolist())

@@ -19,4 +19,6 @@ if [ "$lease" = "1" ]; then
         find $out/refine_$w -name "*kernel_stats.csv" -exec cp {} $out/refine_${w}_kernel_stats.csv \; ; rm -rf $out/refine_$w
     done
     cd $root
+    for w in cylinder3D_Re3900 box5e7; do bash tools/knn_batches.sh $w > /dev/null || exit 1; cp gpurun_out/knn_batches_$w.txt gpurun_out/knn_wall_$w.txt $out/; done
+    python3 tools/knn_coop_probe.py > $out/knn_coop_probe.txt 2>&1
 fi

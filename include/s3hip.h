@@ -117,9 +117,10 @@ int s3_child_gain(const s3_knn *knn, int k, const double *d_center, const int32_
  * points are searched (cells whose parent has no entry: the root).  Either way the children's values of the n cells are
  * stored in d_child_metric.  d_scratch: n*(2^dim+1) doubles + 2*(2 + n*2^dim) int32.  With d_parents every cell is given to
  * one wavefront (shared candidate box of the 2^dim child points; selection by histogram instead of sorted insertion:
- * csrc/knn.hip); the queries that scheme cannot answer (coarse cells, points next to a body) are listed behind the doubles
- * for a streaming search with one wavefront per query, and what that cannot answer either (refined buckets, ties in distance,
- * k > 48) for the per-lane search. */
+ * csrc/knn.hip); the queries that scheme cannot answer are listed behind the doubles and handed on: to a grouped search
+ * (2^dim queries per wavefront, each its own small box: cells too large for one box), then to one wavefront per query
+ * (next to a body, at the edge of the cloud, outside it), and what is still left (refined buckets, ties in distance, k > 48)
+ * to the per-lane search.  Same bits whichever kernel answers. */
 int s3_child_gain_reuse(const s3_knn *knn, int k, const double *d_center, const int32_t *d_level, int64_t first, int64_t n,
                         int dim, double width, const double *d_level_factor, double gain0, double *d_metric /*[cap]*/,
                         double *d_gain /*[cap]*/, double *d_scratch, const int32_t *d_parents /*or NULL*/,

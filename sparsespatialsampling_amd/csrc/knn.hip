@@ -1007,6 +1007,7 @@ child_metric_coop_kernel(Grid<DIM> g, const double *__restrict__ pts, const int3
 constexpr int FAR_ROWS = 1024;            // >= (2 * max radius + 1)^(DIM - 1)
 constexpr int FAR_NB = 256;               // histogram bins
 constexpr int FAR_MAX_POINTS = 1 << 16;
+constexpr int FAR_UNROLL = 4;            // slots of the box a lane has in flight per pass step (one round trip each step)
 constexpr int FAR_RMAX = 15;             // buckets on either side of the query's bucket, at most
 __device__ constexpr double FAR_BALLS[4] = {1.8, 3.5, 7.0, 13.0};   // radius of the ball the box must hold, in units of `reach`
 
@@ -1126,15 +1127,15 @@ __device__ __forceinline__ bool far_solve(const Grid<DIM> &g, const double *__re
         return d;
     };
     // ---- pass A: histogram ---------------------------------------------------------------------------------------------------
-    for (int t0 = lane; t0 < M; t0 += 4 * 64) {
-        int p[4];
-        double d[4];
+    for (int t0 = lane; t0 < M; t0 += FAR_UNROLL * 64) {
+        int p[FAR_UNROLL];
+        double d[FAR_UNROLL];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) p[u] = point_of(min(t0 + 64 * u, M - 1));
+        for (int u = 0; u < FAR_UNROLL; ++u) p[u] = point_of(min(t0 + 64 * u, M - 1));
 #pragma unroll
-        for (int u = 0; u < 4; ++u) d[u] = dist2(p[u]);
+        for (int u = 0; u < FAR_UNROLL; ++u) d[u] = dist2(p[u]);
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < FAR_UNROLL; ++u)
             if (t0 + 64 * u < M && d[u] < lim2) atomicAdd(&L.hist[bin_of(d[u])], 1u);
     }
     wave_sync_lds();
@@ -1171,15 +1172,15 @@ __device__ __forceinline__ bool far_solve(const Grid<DIM> &g, const double *__re
     if (total < (uint32_t)k) { hopeless = whole_grid; return false; }
     if (below > (uint32_t)COOP_CAP) { hopeless = true; return false; }     // ties in bulk
     // ---- pass B: the candidates below the threshold ---------------------------------------------------------------------------
-    for (int t0 = lane; t0 < M; t0 += 4 * 64) {
-        int p[4];
-        double d[4];
+    for (int t0 = lane; t0 < M; t0 += FAR_UNROLL * 64) {
+        int p[FAR_UNROLL];
+        double d[FAR_UNROLL];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) p[u] = point_of(min(t0 + 64 * u, M - 1));
+        for (int u = 0; u < FAR_UNROLL; ++u) p[u] = point_of(min(t0 + 64 * u, M - 1));
 #pragma unroll
-        for (int u = 0; u < 4; ++u) d[u] = dist2(p[u]);
+        for (int u = 0; u < FAR_UNROLL; ++u) d[u] = dist2(p[u]);
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < FAR_UNROLL; ++u)
             if (t0 + 64 * u < M && d[u] < lim2 && bin_of(d[u]) <= b_star) {
                 const uint32_t at = min(atomicAdd(&L.count, 1u), (uint32_t)(COOP_CAP - 1));
                 L.list_d[at] = d[u];

@@ -299,9 +299,24 @@ __host__ __device__ __forceinline__ Key96 key_prefix(const Key96 &k, int nd) {
     return r;
 }
 
+// The digit passes are driven from the device: the state of the selection (prefix of the threshold so far, how many keys of
+// the prefix class are still wanted, done) lives in the scratch buffer, a one-workgroup kernel reads each pass's histogram
+// and advances it, and the next pass's kernels read it from there -- the host queues all passes at once and waits ONCE, for
+// the selected ids (before: a histogram download and a stream synchronisation per digit, four or five per call, more than
+// the kernels themselves at 5 * 10^5 cells).  Passes behind the one that finished return at once.
+struct SelState {
+    unsigned long long prefix_hi;
+    uint32_t prefix_lo;
+    int32_t done;
+    long long need;
+    unsigned long long count;                              // number of ids collected
+};
+
 __global__ void __launch_bounds__(256)
-select_hist_kernel(const double *__restrict__ gain, const uint8_t *__restrict__ leaf, int64_t n, Key96 prefix, int nd,
-                   uint32_t *__restrict__ hist) {
+select_hist_dev_kernel(const double *__restrict__ gain, const uint8_t *__restrict__ leaf, int64_t n,
+                       const SelState *__restrict__ st, int nd, uint32_t *__restrict__ hist) {
+    if (st->done) return;
+    const Key96 prefix{st->prefix_hi, st->prefix_lo};
     __shared__ uint32_t sh[SEL_BINS];
     for (int i = threadIdx.x; i < SEL_BINS; i += 256) sh[i] = 0;
     __syncthreads();
@@ -316,22 +331,133 @@ select_hist_kernel(const double *__restrict__ gain, const uint8_t *__restrict__ 
         if (sh[i]) atomicAdd(&hist[i], sh[i]);
 }
 
+// one workgroup: the bin in which the count from the top reaches `need`; clears the histogram for the next pass
 __global__ void __launch_bounds__(256)
-select_collect_kernel(const double *__restrict__ gain, const uint8_t *__restrict__ leaf, int64_t n, Key96 thr,
-                      int64_t cap, int32_t *__restrict__ out_id, double *__restrict__ out_gain,
-                      unsigned long long *__restrict__ counter) {
+select_pick_kernel(uint32_t *__restrict__ hist, SelState *__restrict__ st, int d) {
+    constexpr int PER = SEL_BINS / 256;
+    __shared__ long long part[256];
+    __shared__ long long s_total, s_above, s_in_bin;
+    __shared__ int s_bin;
+    if (st->done) return;                                  // (uniform: every thread reads the same word)
+    const int t = threadIdx.x;
+    // thread t owns bins SEL_BINS - 1 - t * PER downwards (the scan runs from the top bin)
+    uint32_t mine[PER];
+    long long sum = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        mine[i] = hist[SEL_BINS - 1 - (t * PER + i)];
+        sum += mine[i];
+    }
+    part[t] = sum;
+    if (t == 0) s_bin = -1;
+    __syncthreads();
+    for (int i = t; i < SEL_BINS; i += 256) hist[i] = 0;
+    if (t == 0) {                                          // exclusive prefix of the 256 sums (a few hundred cycles)
+        long long run = 0;
+        for (int i = 0; i < 256; ++i) {
+            const long long v = part[i];
+            part[i] = run;
+            run += v;
+        }
+        s_total = run;
+    }
+    __syncthreads();
+    const long long need = st->need;
+    if (d == 0 && s_total <= need) {                       // fewer leaves than requested: take everything (threshold 0)
+        if (t == 0) {
+            st->prefix_hi = 0;
+            st->prefix_lo = 0;
+            st->done = 1;
+        }
+        return;
+    }
+    long long acc = part[t];
+    if (acc < need && acc + sum >= need) {                 // exactly one thread: the count reaches `need` inside its bins
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            if (acc + mine[i] >= need) {
+                s_bin = SEL_BINS - 1 - (t * PER + i);
+                s_above = acc;
+                s_in_bin = mine[i];
+                break;
+            }
+            acc += mine[i];
+        }
+    }
+    __syncthreads();
+    if (t == 0 && s_bin >= 0) {                            // (the class of the prefix holds >= need keys: a bin is always found)
+        const long long left = need - s_above;             // still wanted from bin s_bin
+        const int shift = 84 - SEL_BITS * d;
+        unsigned long long hi = st->prefix_hi;
+        uint32_t lo = st->prefix_lo;
+        if (shift >= 32) hi |= (unsigned long long)s_bin << (shift - 32);
+        else {
+            const unsigned long long low64 = (unsigned long long)s_bin << shift;
+            hi |= low64 >> 32;
+            lo |= (uint32_t)low64;
+        }
+        st->prefix_hi = hi;
+        st->prefix_lo = lo;
+        st->need = left;
+        if (s_in_bin == left || d == SEL_DIGITS - 1) st->done = 1;     // the whole bin is taken: threshold = this prefix
+    }
+}
+
+__global__ void __launch_bounds__(256)
+select_collect_dev_kernel(const double *__restrict__ gain, const uint8_t *__restrict__ leaf, int64_t n, SelState *__restrict__ st,
+                          int64_t cap, int32_t *__restrict__ out_id, double *__restrict__ out_gain) {
+    const Key96 thr{st->prefix_hi, st->prefix_lo};
     for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         if (!leaf[i]) continue;
         double g = gain[i];
         Key96 k = make_key(g, (uint32_t)i);
         if (k.hi > thr.hi || (k.hi == thr.hi && k.lo >= thr.lo)) {
-            unsigned long long pos = atomicAdd(counter, 1ull);
+            unsigned long long pos = atomicAdd(&st->count, 1ull);
             if ((int64_t)pos < cap) {
                 out_id[pos] = (int32_t)i;
                 out_gain[pos] = g;
             }
         }
     }
+}
+
+// The selected ids in descending key order: a key's place is the number of selected keys above it (the keys are distinct:
+// the id is part of them).  n^2 comparisons -- 2.5 * 10^7 at 5000 ids, 8 * 10^8 at 29 000: microseconds on the device, against
+// 0.15 / 1 ms for the host's std::sort of the same records, which was the largest part of a call.
+constexpr int64_t RANK_MAX = 262144;       // above this many ids the host sorts (n log n beats n^2 / 10^4 lanes)
+
+constexpr int RANK_SPAN = 512;             // keys a workgroup compares its 256 keys with
+
+// partial ranks: workgroup (x, y) counts, for each of the 256 keys of tile x, the keys above it among keys y * RANK_SPAN ..
+__global__ void __launch_bounds__(256)
+select_rank_kernel(const int32_t *__restrict__ ids, const double *__restrict__ gains, const SelState *__restrict__ st,
+                   int64_t cap, int32_t *__restrict__ rank) {
+    __shared__ unsigned long long t_hi[RANK_SPAN];
+    __shared__ uint32_t t_lo[RANK_SPAN];
+    const int64_t n = min((int64_t)st->count, cap);
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x, base = (int64_t)blockIdx.y * RANK_SPAN;
+    if ((int64_t)blockIdx.x * 256 >= n || base >= n) return;              // (uniform)
+    const int m = (int)min((int64_t)RANK_SPAN, n - base);
+    for (int q = threadIdx.x; q < RANK_SPAN; q += 256) {
+        const Key96 k = q < m ? make_key(gains[base + q], (uint32_t)ids[base + q]) : Key96{0, 0};   // (0, 0): above no key
+        t_hi[q] = k.hi;
+        t_lo[q] = k.lo;
+    }
+    __syncthreads();
+    if (i >= n) return;
+    const Key96 mine = make_key(gains[i], (uint32_t)ids[i]);
+    int32_t above = 0;
+#pragma unroll 8
+    for (int q = 0; q < RANK_SPAN; ++q) above += (t_hi[q] > mine.hi || (t_hi[q] == mine.hi && t_lo[q] > mine.lo)) ? 1 : 0;
+    atomicAdd(&rank[i], above);
+}
+
+__global__ void __launch_bounds__(256)
+select_place_kernel(const int32_t *__restrict__ ids, const int32_t *__restrict__ rank, const SelState *__restrict__ st,
+                    int64_t cap, int32_t *__restrict__ sorted) {
+    const int64_t n = min((int64_t)st->count, cap);
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) sorted[rank[i]] = ids[i];
 }
 
 }  // namespace s3
@@ -530,7 +656,7 @@ int s3_sum_ordered(const double *d_values, int64_t n, double *d_out, s3_stream s
 size_t s3_topn_scratch_bytes(int64_t n_cells, int64_t n_top) {
     (void)n_cells;
     if (n_top < 1) n_top = 1;
-    return sizeof(uint32_t) * SEL_BINS + 64 + (size_t)n_top * (sizeof(int32_t) + sizeof(double)) + 64;
+    return sizeof(uint32_t) * SEL_BINS + 64 + (size_t)n_top * (sizeof(int32_t) + sizeof(double) + 2 * sizeof(int32_t)) + 192;
 }
 
 int s3_topn_leaf(const double *d_gain, const uint8_t *d_leaf, int64_t n_cells, int64_t n_top, int32_t *h_out,
@@ -542,74 +668,58 @@ int s3_topn_leaf(const double *d_gain, const uint8_t *d_leaf, int64_t n_cells, i
     hipStream_t st = as_stream(stream);
     char *base = static_cast<char *>(d_scratch);
     uint32_t *d_hist = reinterpret_cast<uint32_t *>(base);
-    unsigned long long *d_counter = reinterpret_cast<unsigned long long *>(base + sizeof(uint32_t) * SEL_BINS);
+    SelState *d_state = reinterpret_cast<SelState *>(base + sizeof(uint32_t) * SEL_BINS);
+    static_assert(sizeof(SelState) <= 64, "the state fits the gap behind the histogram");
     double *d_og = reinterpret_cast<double *>(base + sizeof(uint32_t) * SEL_BINS + 64);
     int32_t *d_oi = reinterpret_cast<int32_t *>(base + sizeof(uint32_t) * SEL_BINS + 64 + sizeof(double) * n_top);
     unsigned grid = grid_for(n_cells, 256, 2048);
 
-    std::vector<uint32_t> hist(SEL_BINS);
-    Key96 prefix{0, 0};
-    int64_t need = n_top;        // how many still to take from the current prefix class
-    Key96 thr{0, 0};             // keys >= thr are selected
-    bool take_all = false;
+    // all digit passes and the collection are queued at once (the state of the selection lives on the device); one wait
+    SelState init{0ull, 0u, 0, (long long)n_top, 0ull};
+    S3_HIP_CHECK(hipMemsetAsync(d_hist, 0, sizeof(uint32_t) * SEL_BINS, st));
+    S3_HIP_CHECK(hipMemcpyAsync(d_state, &init, sizeof(init), hipMemcpyHostToDevice, st));
     for (int d = 0; d < SEL_DIGITS; ++d) {
-        S3_HIP_CHECK(hipMemsetAsync(d_hist, 0, sizeof(uint32_t) * SEL_BINS, st));
-        select_hist_kernel<<<grid, 256, 0, st>>>(d_gain, d_leaf, n_cells, prefix, d, d_hist);
-        S3_LAUNCH_CHECK();
-        S3_HIP_CHECK(hipMemcpyAsync(hist.data(), d_hist, sizeof(uint32_t) * SEL_BINS, hipMemcpyDeviceToHost, st));
-        S3_HIP_CHECK(hipStreamSynchronize(st));
-        int64_t total = 0;
-        for (int b = 0; b < SEL_BINS; ++b) total += hist[b];
-        if (d == 0 && total <= need) {   // fewer leaves than requested: take everything
-            take_all = true;
-            break;
-        }
-        int64_t acc = 0;
-        int b = SEL_BINS - 1;
-        for (; b >= 0; --b) {
-            if (acc + hist[b] >= need) break;
-            acc += hist[b];
-        }
-        // bins above b are taken entirely; from bin b we still need (need - acc) of hist[b]
-        need -= acc;
-        int shift = 84 - SEL_BITS * d;
-        if (shift >= 32) prefix.hi |= (uint64_t)b << (shift - 32);
-        else {
-            uint64_t low64 = (uint64_t)b << shift;      // bits 0..43
-            prefix.hi |= low64 >> 32;
-            prefix.lo |= (uint32_t)low64;
-        }
-        thr = prefix;
-        if ((int64_t)hist[b] == need) break;            // the whole bin is taken: threshold = this prefix
+        select_hist_dev_kernel<<<grid, 256, 0, st>>>(d_gain, d_leaf, n_cells, d_state, d, d_hist);
+        select_pick_kernel<<<1, 256, 0, st>>>(d_hist, d_state, d);
     }
-    if (take_all) thr = Key96{0, 0};
-
-    S3_HIP_CHECK(hipMemsetAsync(d_counter, 0, sizeof(unsigned long long), st));
-    select_collect_kernel<<<grid, 256, 0, st>>>(d_gain, d_leaf, n_cells, thr, n_top, d_oi, d_og, d_counter);
+    select_collect_dev_kernel<<<grid, 256, 0, st>>>(d_gain, d_leaf, n_cells, d_state, n_top, d_oi, d_og);
+    const size_t cap = (size_t)std::min<int64_t>(n_top, n_cells);       // at most this many ids can have been selected
+    // (d_oi ends on a multiple of 4 bytes behind 8-byte entries: the sorted ids follow 64-byte aligned)
+    int32_t *d_sorted = reinterpret_cast<int32_t *>(base + ((sizeof(uint32_t) * SEL_BINS + 64 + (sizeof(double) + sizeof(int32_t)) * (size_t)n_top + 63) / 64) * 64);
+    const bool on_device = (int64_t)cap <= RANK_MAX;
+    int32_t *d_rank = d_sorted + ((cap + 15) / 16) * 16;
+    if (on_device) {
+        S3_HIP_CHECK(hipMemsetAsync(d_rank, 0, sizeof(int32_t) * cap, st));
+        const dim3 rgrid(grid_for((int64_t)cap, 256), (unsigned)((cap + RANK_SPAN - 1) / RANK_SPAN));
+        select_rank_kernel<<<rgrid, 256, 0, st>>>(d_oi, d_og, d_state, (int64_t)cap, d_rank);
+        select_place_kernel<<<grid_for((int64_t)cap, 256), 256, 0, st>>>(d_oi, d_rank, d_state, (int64_t)cap, d_sorted);
+    }
     S3_LAUNCH_CHECK();
-    unsigned long long cnt = 0;
-    S3_HIP_CHECK(hipMemcpyAsync(&cnt, d_counter, sizeof(cnt), hipMemcpyDeviceToHost, st));
+    SelState fin{};
+    std::vector<int32_t> ids(cap);
+    std::vector<double> gs(on_device ? 0 : cap);
+    S3_HIP_CHECK(hipMemcpyAsync(&fin, d_state, sizeof(fin), hipMemcpyDeviceToHost, st));
+    S3_HIP_CHECK(hipMemcpyAsync(ids.data(), on_device ? d_sorted : d_oi, sizeof(int32_t) * cap, hipMemcpyDeviceToHost, st));
+    if (!on_device) S3_HIP_CHECK(hipMemcpyAsync(gs.data(), d_og, sizeof(double) * cap, hipMemcpyDeviceToHost, st));
     S3_HIP_CHECK(hipStreamSynchronize(st));
-    if ((int64_t)cnt > n_top) {
-        s3::set_error("s3_topn_leaf: internal selection error (%llu > %lld)", cnt, (long long)n_top);
+    const unsigned long long cnt = fin.count;
+    if ((int64_t)cnt > n_top || !fin.done) {
+        s3::set_error("s3_topn_leaf: internal selection error (%llu selected, %lld wanted, done %d)", cnt, (long long)n_top, fin.done);
         return S3_EHIP;
     }
-    std::vector<int32_t> ids(cnt);
-    std::vector<double> gs(cnt);
-    if (cnt) {
-        S3_HIP_CHECK(hipMemcpyAsync(ids.data(), d_oi, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, st));
-        S3_HIP_CHECK(hipMemcpyAsync(gs.data(), d_og, sizeof(double) * cnt, hipMemcpyDeviceToHost, st));
-        S3_HIP_CHECK(hipStreamSynchronize(st));
+    if (on_device) {
+        for (size_t i = 0; i < cnt; ++i) h_out[i] = ids[i];
+    } else {
+        // descending (gain, -id): the keys are formed once, then (key, id) records are sorted as a whole
+        struct Rec { uint64_t hi; uint32_t lo; int32_t id; };
+        std::vector<Rec> rec(cnt);
+        for (size_t i = 0; i < cnt; ++i) {
+            const Key96 kk = make_key(gs[i], (uint32_t)ids[i]);
+            rec[i] = Rec{kk.hi, kk.lo, ids[i]};
+        }
+        std::sort(rec.begin(), rec.end(), [](const Rec &a, const Rec &b) { return a.hi > b.hi || (a.hi == b.hi && a.lo > b.lo); });
+        for (size_t i = 0; i < cnt; ++i) h_out[i] = rec[i].id;
     }
-    // descending (gain, -id): the keys are formed once, then (key, id) records are sorted as a whole
-    struct Rec { uint64_t hi; uint32_t lo; int32_t id; };
-    std::vector<Rec> rec(cnt);
-    for (size_t i = 0; i < cnt; ++i) {
-        const Key96 kk = make_key(gs[i], (uint32_t)ids[i]);
-        rec[i] = Rec{kk.hi, kk.lo, ids[i]};
-    }
-    std::sort(rec.begin(), rec.end(), [](const Rec &a, const Rec &b) { return a.hi > b.hi || (a.hi == b.hi && a.lo > b.lo); });
-    for (size_t i = 0; i < cnt; ++i) h_out[i] = rec[i].id;
     *h_count = (int64_t)cnt;
     return S3_OK;
 }

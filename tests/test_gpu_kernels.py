@@ -494,8 +494,9 @@ def test_masks_polytopes_golden(ops, key):
 
 # ---- selection + reduction (a6, a8) -----------------------------------------------------------------------------
 @pytest.mark.parametrize("n,n_top,ties", [(50_000, 37, False), (50_000, 5000, True), (300, 1000, False), (200_000, 1, True),
-                                          (70_000, 69_000, True)])
+                                          (70_000, 69_000, True), (29_000 * 8, 29_000, False), (700_000, 300_000, True)])
 def test_topn_vs_oracle(ops, orc, n, n_top, ties):
+    """(the last case is beyond the size the device orders the selection at: the host's sort takes over)"""
     rng = np.random.default_rng(n + n_top)
     gain = rng.random(n) ** 4
     if ties:

@@ -27,6 +27,7 @@
 // states are the same as without it.
 // Pinned against the interpreter's own set objects slot by slot (tests/test_pyset.py reads PySetObject through
 // ctypes), on random add / discard / update / difference traces.
+#include <algorithm>
 #include <condition_variable>
 #include <cstdint>
 #include <cstdlib>
@@ -443,9 +444,46 @@ int s3set_difference_update(void *h, void *other) try {
 // iteration order -> out[0..len)
 void s3set_to_array(void *h, int64_t *out) {
     PySet *s = settled(h);
-    int64_t n = 0;
-    for (int64_t i = 0; i <= s->mask; ++i)
-        if (s->table[i] >= 0) out[n++] = s->table[i];
+    const int64_t size = s->mask + 1;
+    // a 10^7-entry set is a 256 MB table: its slices are counted and then copied by a few threads
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int n_thr = size >= ((int64_t)1 << 22) ? (int)std::min<unsigned>(8u, std::max(1u, hw / 2)) : 1;
+    if (n_thr == 1) {
+        int64_t n = 0;
+        for (int64_t i = 0; i < size; ++i)
+            if (s->table[i] >= 0) out[n++] = s->table[i];
+        return;
+    }
+    try {
+        std::vector<int64_t> cnt(n_thr + 1, 0);
+        const int64_t per = size / n_thr;
+        auto range = [&](int t, int64_t &a, int64_t &b) { a = t * per; b = t == n_thr - 1 ? size : a + per; };
+        {
+            std::vector<std::thread> th;
+            for (int t = 0; t < n_thr; ++t)
+                th.emplace_back([&, t] {
+                    int64_t a, b, c = 0;
+                    range(t, a, b);
+                    for (int64_t i = a; i < b; ++i) c += s->table[i] >= 0;
+                    cnt[t + 1] = c;
+                });
+            for (auto &x : th) x.join();
+        }
+        for (int t = 0; t < n_thr; ++t) cnt[t + 1] += cnt[t];
+        std::vector<std::thread> th;
+        for (int t = 0; t < n_thr; ++t)
+            th.emplace_back([&, t] {
+                int64_t a, b, n = cnt[t];
+                range(t, a, b);
+                for (int64_t i = a; i < b; ++i)
+                    if (s->table[i] >= 0) out[n++] = s->table[i];
+            });
+        for (auto &x : th) x.join();
+    } catch (...) {                                         // no threads to be had: one pass on this one
+        int64_t n = 0;
+        for (int64_t i = 0; i < size; ++i)
+            if (s->table[i] >= 0) out[n++] = s->table[i];
+    }
 }
 
 // {i for i in ids[flags] if i}: insertion of the flagged, non-zero ids in order (s_cube.py:709)

@@ -44,6 +44,9 @@ def update_by_kind(self, items):
 intset.IntSet.update = update_by_kind
 for n in ("submit_refine", "submit_relink_parent_of", "submit_mark_invalid", "sync", "finalize", "gather_cells"):
     wrap(s_cube._Topology, n, "topo." + n)
+for n in ("finalize", "gather_cells", "sync"):
+    wrap(s_cube._DeviceTopology, n, "devtopo." + n)
+wrap(hipops, "to_host", "hipops.to_host")
 for n in ("mask", "refine_batch", "topn", "sumsq", "commit"):
     wrap(tree_backend.HipTreeBackend, n, "backend." + n)
 for n in ("_remove_invalid_cells", "_refine_cells", "_compute_captured_metric", "_refine_uniform", "_refine_geometries", "_resort_nodes_and_indices_of_grid"):

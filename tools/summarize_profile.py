@@ -7,7 +7,7 @@ import csv, glob, json, os, shutil, sys
 tag, name = sys.argv[1], sys.argv[2]
 src, dst = f"gpurun_out/prof_{tag}/{name}", f"profiles/{tag}/{name}"
 os.makedirs(dst, exist_ok=True)
-leases = sorted(d for d in glob.glob(f"{src}/lease*") if os.path.isdir(d)) or [src]
+leases = sorted((d for d in glob.glob(f"{src}/lease*") if os.path.isdir(d)), key=lambda d: int(d.rsplit("lease", 1)[1])) or [src]
 
 
 def one(lease_dir):

@@ -32,3 +32,9 @@ timed("dense over PCIe + re-pitch on the device", lambda: (hipops.upload_rows_in
 chk = pitched.clone()
 hipops.upload_rows_indexed(host, used, pitched); pt.cuda.synchronize()
 print("same rows:", bool(pt.equal(chk, pitched)))
+# where the time goes: the same number of bytes as one contiguous block (no gather on the host), and with pinned source memory
+block = host[:len(used)].contiguous()
+timed("contiguous block, dense (no gather on the host)", lambda: hipops.upload_rows(block, dense))
+pinned = pt.empty((len(used), t), dtype=pt.float32, pin_memory=True)
+pinned.copy_(block)
+timed("page-locked source, one hipMemcpyAsync (PCIe alone)", lambda: dense.copy_(pinned, non_blocking=True))

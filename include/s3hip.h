@@ -270,6 +270,13 @@ int s3_remap_indices(int32_t *d_idx, int64_t n, const int32_t *d_remap, int64_t 
  * source rows in this order in HBM, so that the rows a tile of neighbouring cells gathers lie close together (fewer
  * DRAM pages / address translations per tile than with the CFD mesh's arbitrary numbering). */
 int s3_spatial_order(const double *d_points, int64_t n, int dim, int32_t *d_perm, s3_stream stream);
+/* The two device-wide primitives behind the planner and the device topology (csrc/scan_sort.h, hand-written: three-launch
+ * exclusive scan; stable LSD radix sort with 8-bit digits), exported for the tests.  s3_exclusive_scan: d_out[i] = sum of
+ * d_in[0 .. i-1], int32 (elem_bytes 4) or int64 (8), in place allowed.  s3_sort_pairs: (key, value) pairs ascending by the low
+ * `bits` bits of the keys, stable, in place.  Both return when the work is done.  No counterpart in the reference (torch.unique /
+ * numpy fancy indexing do this work there, export.py:403-444). */
+int s3_exclusive_scan(const void *d_in, void *d_out, int64_t n, int elem_bytes, s3_stream stream);
+int s3_sort_pairs(uint64_t *d_keys, int32_t *d_vals, int64_t n, int bits, s3_stream stream);
 /* d_remap[d_ids[i]] = i for the n distinct row ids, every other entry of d_remap[n_src] = -1 */
 int s3_positions_of(const int32_t *d_ids, int64_t n, int32_t *d_remap, int64_t n_src, s3_stream stream);
 int s3_gather_rows(const void *d_src, int64_t n_src_rows, int64_t row_bytes, int64_t src_pitch_bytes,

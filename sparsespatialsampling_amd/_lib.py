@@ -98,6 +98,8 @@ HIP_SIGNATURES = {
     "s3_compact_rows": (c_int, [c_vp, c_i64, c_vp, C.POINTER(c_i64), c_vp]),
     "s3_remap_indices": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp]),
     "s3_spatial_order": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp]),
+    "s3_exclusive_scan": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp]),
+    "s3_sort_pairs": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp]),
     "s3_positions_of": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp]),
     "s3_gather_rows": (c_int, [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp]),
     "s3_topo_create": (c_int, [c_int, c_dbl, c_vp, C.POINTER(c_vp)]),

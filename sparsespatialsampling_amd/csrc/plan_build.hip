@@ -11,7 +11,7 @@
 #include "common.h"
 #include "plan_build.h"
 
-#include <hipcub/hipcub.hpp>
+#include "scan_sort.h"
 
 #include <cmath>
 #include <vector>
@@ -271,11 +271,14 @@ static int spatial_perm(const double *d_points, int64_t n, int dim, hipStream_t 
     S3_PB_CHECK(tmp.alloc(&val_in, (size_t)n));
     key_kernel<<<grid_for(n, 256), 256, 0, st>>>(d_points, n, kp, key_in, val_in);
     S3_PB_CHECK(hipGetLastError());
-    size_t bytes = 0;
-    S3_PB_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, key_in, key_out, val_in, d_perm, (int)n, 0, dim * kp.bits, st));
-    char *d_sort = nullptr;
-    S3_PB_CHECK(tmp.alloc(&d_sort, bytes));
-    S3_PB_CHECK(hipcub::DeviceRadixSort::SortPairs(d_sort, bytes, key_in, key_out, val_in, d_perm, (int)n, 0, dim * kp.bits, st));
+    // stable LSD radix sort of (key, position) pairs (csrc/scan_sort.h); 48-bit keys: six passes, the result ends in the
+    // buffers it started from
+    int32_t *d_hist = nullptr;
+    const size_t hist_items = sort_hist_items(n);
+    S3_PB_CHECK(tmp.alloc(&d_hist, hist_items + scan_tmp_items((int64_t)hist_items)));
+    bool in_alt = false;
+    S3_PB_CHECK(radix_sort_pairs(key_in, key_out, val_in, d_perm, n, dim * kp.bits, d_hist, st, &in_alt));
+    if (!in_alt) S3_PB_CHECK(hipMemcpyAsync(d_perm, val_in, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, st));
     return S3_OK;
 }
 
@@ -316,12 +319,10 @@ int build_plan_tables(const int32_t *d_idx, int64_t nc, int k, int64_t n_src, co
     S3_PB_CHECK(hipGetLastError());
 
     // ---- 3. offsets + compact tables ---------------------------------------------------------------------------
-    size_t bytes = 0;
-    S3_PB_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, cnt_t, off_t, (int)n_blocks, st));
-    char *d_scan = nullptr;
-    S3_PB_CHECK(tmp.alloc(&d_scan, bytes));
-    S3_PB_CHECK(hipcub::DeviceScan::ExclusiveSum(d_scan, bytes, cnt_t, off_t, (int)n_blocks, st));
-    S3_PB_CHECK(hipcub::DeviceScan::ExclusiveSum(d_scan, bytes, cnt_r, off_r, (int)n_blocks, st));
+    int32_t *d_scan = nullptr;
+    S3_PB_CHECK(tmp.alloc(&d_scan, scan_tmp_items(n_blocks)));
+    S3_PB_CHECK(exclusive_scan<int32_t>(cnt_t, off_t, n_blocks, d_scan, st));
+    S3_PB_CHECK(exclusive_scan<int32_t>(cnt_r, off_r, n_blocks, d_scan, st));
     int32_t last[4] = {0, 0, 0, 0}, bad = 0;                      // offsets and counts of the last block -> totals
     S3_PB_CHECK(hipMemcpyAsync(&last[0], off_t + n_blocks - 1, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     S3_PB_CHECK(hipMemcpyAsync(&last[1], off_r + n_blocks - 1, sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -443,11 +444,9 @@ int s3_compact_rows(int32_t *d_flag_remap, int64_t n_src, int32_t *d_used, int64
     s3::Scratch tmp;
     int32_t *pos = nullptr;
     S3_HIP_CHECK(tmp.alloc(&pos, (size_t)n_src));
-    size_t bytes = 0;
-    S3_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, d_flag_remap, pos, (int)n_src, st));
-    char *d_scan = nullptr;
-    S3_HIP_CHECK(tmp.alloc(&d_scan, bytes));
-    S3_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(d_scan, bytes, d_flag_remap, pos, (int)n_src, st));
+    int32_t *d_scan = nullptr;
+    S3_HIP_CHECK(tmp.alloc(&d_scan, s3::scan_tmp_items(n_src)));
+    S3_HIP_CHECK(s3::exclusive_scan<int32_t>(d_flag_remap, pos, n_src, d_scan, st));
     int32_t last_pos = 0, last_flag = 0;
     S3_HIP_CHECK(hipMemcpyAsync(&last_pos, pos + n_src - 1, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     S3_HIP_CHECK(hipMemcpyAsync(&last_flag, d_flag_remap + n_src - 1, sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -560,6 +559,46 @@ int s3_spatial_order(const double *d_points, int64_t n, int dim, int32_t *d_perm
     const int rc = s3::spatial_perm(d_points, n, dim, s3::as_stream(stream), d_perm, tmp);
     if (rc != S3_OK) return rc;
     S3_HIP_CHECK(hipStreamSynchronize(s3::as_stream(stream)));       // the scratch arrays go away with `tmp`
+    return S3_OK;
+}
+
+// the two primitives of csrc/scan_sort.h on their own (the planner and the device topology use them internally)
+int s3_exclusive_scan(const void *d_in, void *d_out, int64_t n, int elem_bytes, s3_stream stream) {
+    S3_REQUIRE(n >= 0 && (n == 0 || (d_in && d_out)) && (elem_bytes == 4 || elem_bytes == 8), "s3_exclusive_scan: int32 / int64 arrays");
+    if (n == 0) return S3_OK;
+    hipStream_t st = s3::as_stream(stream);
+    s3::Scratch tmp;
+    if (elem_bytes == 4) {
+        int32_t *t = nullptr;
+        S3_HIP_CHECK(tmp.alloc(&t, s3::scan_tmp_items(n)));
+        S3_HIP_CHECK(s3::exclusive_scan<int32_t>(static_cast<const int32_t *>(d_in), static_cast<int32_t *>(d_out), n, t, st));
+    } else {
+        int64_t *t = nullptr;
+        S3_HIP_CHECK(tmp.alloc(&t, s3::scan_tmp_items(n)));
+        S3_HIP_CHECK(s3::exclusive_scan<int64_t>(static_cast<const int64_t *>(d_in), static_cast<int64_t *>(d_out), n, t, st));
+    }
+    S3_HIP_CHECK(hipStreamSynchronize(st));                           // the scratch array goes away with `tmp`
+    return S3_OK;
+}
+
+int s3_sort_pairs(uint64_t *d_keys, int32_t *d_vals, int64_t n, int bits, s3_stream stream) {
+    S3_REQUIRE(n >= 0 && n < ((int64_t)1 << 31) && (n == 0 || (d_keys && d_vals)) && bits >= 1 && bits <= 64, "s3_sort_pairs: bad arguments");
+    if (n == 0) return S3_OK;
+    hipStream_t st = s3::as_stream(stream);
+    s3::Scratch tmp;
+    uint64_t *k2 = nullptr;
+    int32_t *v2 = nullptr, *hist = nullptr;
+    const size_t items = s3::sort_hist_items(n);
+    S3_HIP_CHECK(tmp.alloc(&k2, (size_t)n));
+    S3_HIP_CHECK(tmp.alloc(&v2, (size_t)n));
+    S3_HIP_CHECK(tmp.alloc(&hist, items + s3::scan_tmp_items((int64_t)items)));
+    bool in_alt = false;
+    S3_HIP_CHECK(s3::radix_sort_pairs(d_keys, k2, d_vals, v2, n, bits, hist, st, &in_alt));
+    if (in_alt) {
+        S3_HIP_CHECK(hipMemcpyAsync(d_keys, k2, sizeof(uint64_t) * (size_t)n, hipMemcpyDeviceToDevice, st));
+        S3_HIP_CHECK(hipMemcpyAsync(d_vals, v2, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, st));
+    }
+    S3_HIP_CHECK(hipStreamSynchronize(st));
     return S3_OK;
 }
 

@@ -26,9 +26,9 @@
 //     which is decided from the rows before the call (pass 1), the wipes are applied in pass 2.
 // The host engine (libs3topo.so) remains the executable specification: tests/test_gpu_topology.py compares whole tables.
 #include "common.h"
+#include "scan_sort.h"
 #include "topo_tables.h"
 
-#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <cmath>
@@ -578,8 +578,7 @@ static int upload_ids(s3_topo *t, const int64_t *h_ids, int64_t n) {
 }
 
 static int exclusive_scan(s3_topo *t, const int64_t *in, int64_t *out, int64_t n) {
-    size_t need = 0;
-    S3_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, need, in, out, (int)n, t->st));
+    const size_t need = sizeof(int64_t) * scan_tmp_items(n);
     if (need > t->scan_tmp_bytes) {
         if (t->scan_tmp) {
             S3_HIP_CHECK(hipStreamSynchronize(t->st));
@@ -589,7 +588,7 @@ static int exclusive_scan(s3_topo *t, const int64_t *in, int64_t *out, int64_t n
         S3_HIP_CHECK(hipMalloc(&t->scan_tmp, need));
         t->scan_tmp_bytes = need;
     }
-    S3_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(t->scan_tmp, need, in, out, (int)n, t->st));
+    S3_HIP_CHECK(s3::exclusive_scan<int64_t>(in, out, n, static_cast<int64_t *>(t->scan_tmp), t->st));   // csrc/scan_sort.h
     return S3_OK;
 }
 

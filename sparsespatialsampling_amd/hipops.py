@@ -381,6 +381,24 @@ def gather_rows(src, ids, dst):
     return dst
 
 
+def exclusive_scan(x):
+    """exclusive prefix sum of a contiguous int32 / int64 device tensor (csrc/scan_sort.h) -> new tensor"""
+    if not (x.is_cuda and x.is_contiguous() and x.dtype in (pt.int32, pt.int64) and x.dim() == 1):
+        raise TypeError("exclusive_scan: contiguous 1-D int32 / int64 device tensor required")
+    out = pt.empty_like(x)
+    check(_lib.hip_lib().s3_exclusive_scan(_ptr(x), _ptr(out), int(x.numel()), x.element_size(), _stream()), "s3_exclusive_scan")
+    return out
+
+
+def sort_pairs(keys, vals, bits=64):
+    """stable ascending sort of (key, value) pairs by the low ``bits`` bits of the int64 keys (read as unsigned), in place"""
+    if not (keys.is_cuda and vals.is_cuda and keys.is_contiguous() and vals.is_contiguous() and keys.dtype == pt.int64
+            and vals.dtype == pt.int32 and keys.numel() == vals.numel()):
+        raise TypeError("sort_pairs: contiguous int64 keys and int32 values of one length on the device required")
+    check(_lib.hip_lib().s3_sort_pairs(_ptr(keys), _ptr(vals), int(keys.numel()), int(bits), _stream()), "s3_sort_pairs")
+    return keys, vals
+
+
 def spatial_order(points):
     """Hilbert-curve order of device points [n, 2|3] float64 -> int32 permutation (position -> point) on the device"""
     pts = to_device(points, pt.float64)

@@ -883,3 +883,36 @@ def test_temporal_mean_abs_sum(shape, dtype):
     assert not got_host.is_cuda and got_dev.is_cuda and got_host.dtype == pt.float64
     for got in (got_host, got_dev.cpu()):
         assert got.shape == (shape[0],) and pt.allclose(got, ref, rtol=1e-12, atol=0)
+
+
+# ---- the hand-written scan and radix sort behind the planner and the device topology (csrc/scan_sort.h) ---------------------
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 4095, 4096, 4097, 65_536, 65_537, 1_000_003, 10_000_019])
+def test_exclusive_scan_vs_numpy(ops, n):
+    rng = np.random.default_rng(n)
+    for dtype, hi in ((np.int32, 200), (np.int64, 1 << 40)):
+        x = rng.integers(0, hi if dtype == np.int64 or n < 1_000_000 else 100, n).astype(dtype)
+        got = ops.exclusive_scan(dev(x)).cpu().numpy()
+        want = np.concatenate([[0], np.cumsum(x[:-1], dtype=dtype)]).astype(dtype)
+        assert np.array_equal(got, want), (n, dtype)
+    x = dev(rng.integers(0, 3, n).astype(np.int32))                # in place: csrc/scan_sort.h allows in == out
+    want = np.concatenate([[0], np.cumsum(x.cpu().numpy()[:-1])]).astype(np.int32)
+    from sparsespatialsampling_amd import _lib
+    ops.check(_lib.hip_lib().s3_exclusive_scan(ops._ptr(x), ops._ptr(x), n, 4, None), "s3_exclusive_scan")
+    pt.cuda.synchronize()
+    assert np.array_equal(x.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("n,bits,distinct", [(1, 48, 5), (64, 8, 3), (2049, 16, 40), (100_000, 48, 1 << 47), (461_130, 48, 1 << 47),
+                                             (3_000_001, 48, 1000), (1_000_000, 64, 1 << 62), (70_000, 13, 1 << 13)])
+def test_sort_pairs_is_a_stable_sort(ops, n, bits, distinct):
+    """ascending by the low `bits` bits, equal keys in their original order (the planner's Hilbert keys are 48 bits; many equal
+    keys: points in one curve cell keep their order)"""
+    rng = np.random.default_rng(n + bits)
+    keys = rng.integers(0, distinct, n).astype(np.int64)
+    if bits < 64:
+        keys |= rng.integers(0, 4, n).astype(np.int64) << bits     # bits above `bits` must not matter
+    vals = np.arange(n, dtype=np.int32)
+    k, v = ops.sort_pairs(dev(keys), dev(vals), bits)
+    mask = (1 << bits) - 1 if bits < 64 else -1
+    order = np.argsort(keys & mask, kind="stable")
+    assert np.array_equal(v.cpu().numpy(), vals[order]) and np.array_equal(k.cpu().numpy(), keys[order])

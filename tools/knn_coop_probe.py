@@ -8,12 +8,13 @@ import bench
 from sparsespatialsampling_amd import hipops
 logging.getLogger().setLevel(logging.WARNING)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 40000
-cfg = dict(bench.WORKLOADS["cylinder3D_Re3900"])
-x, metric = bench.synthetic_cylinder3d(cfg)
+BOX = os.environ.get("S3_PROBE_CLOUD") == "box5e7"       # the 5e7-point unit box of C4 instead of the cylinder3D cloud
+cfg = dict(bench.WORKLOADS["box5e7" if BOX else "cylinder3D_Re3900"])
+x, metric = bench.synthetic_box(cfg) if BOX else bench.synthetic_cylinder3d(cfg)
 k, dim, nch = 26, 3, 8
 knn = hipops.KnnIndex(x, hipops.knn_occupancy(k, dim))
 knn.set_values(metric)
-width = 2.4
+width = 1.0 if BOX else 2.4
 rng = np.random.default_rng(0)
 lf = hipops.to_device(np.array([1 / 8 * ((width / 2 ** lv) ** 3) for lv in range(64)]))
 print(f"points {len(x)}, buckets {knn.n_buckets}; bucket side ~ {(2.4 * 2.0 * 0.314 / knn.n_buckets) ** (1 / 3):.5f}")
@@ -29,10 +30,14 @@ def timed(fn, reps=5):
     return a.elapsed_time(b) / reps
 
 
-for lv in (6, 7, 8, 9, 10):
+for lv in ((6, 7, 8) if BOX else (6, 7, 8, 9, 10)):
     cap = n + 8
     x0 = float(os.environ.get("S3_PROBE_X0", "0.2"))
-    center = pt.from_numpy(np.array([x0, 0.2, 0.02]) + rng.random((cap, 3)) * np.array([2.2 - x0, 1.6, 0.27])).cuda()
+    c_host = (0.05 + 0.9 * rng.random((cap, 3))) if BOX else np.array([x0, 0.2, 0.02]) + rng.random((cap, 3)) * np.array([2.2 - x0, 1.6, 0.27])
+    if os.environ.get("S3_PROBE_SORT") == "1":           # cells in a spatial order (bucket-row major) instead of a random one
+        key = np.floor(c_host / (0.0034 if BOX else 0.0084)).astype(np.int64)
+        c_host = c_host[np.lexsort((key[:, 0], key[:, 1], key[:, 2]))]
+    center = pt.from_numpy(np.ascontiguousarray(c_host)).cuda()
     level = pt.full((cap,), lv, dtype=pt.int32, device="cuda")
     metric_d, gain_d = pt.zeros(cap, dtype=pt.float64, device="cuda"), pt.zeros(cap, dtype=pt.float64, device="cuda")
     child = pt.zeros((cap, nch), dtype=pt.float64, device="cuda")

@@ -5,8 +5,12 @@ cylinder3D_Re3900 workload of BASELINE.json / SURVEY.md 8(d).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
 
-A *step* is one pass of the interpolation hot path (ExportData's cached neighbour table -> s3_interp_planned) over one
-batch of synthetic snapshots already resident in HBM: data [N_rows, T_batch] fp32 -> out [N_cells, T_batch] f64 in HBM.
+A *step* is one pass of the interpolation hot path over one batch of synthetic snapshots already resident in HBM IN THE FORM
+THE API RECEIVES IT (interpolate_data(w, idx, data), reference export.py:446-468): a dense tensor [N_points, T_batch] fp32 with
+a row for every point of the CFD mesh, read where it lies through ExportData's cached neighbour table
+(s3_interp_planned_src) -> out [N_cells, T_batch] f64 in HBM.  The same launch on a pre-compacted, pitched copy of the
+referenced rows (the layout ExportData uploads HOST batches into; the headline of rounds 1-3) is the sub-record
+`roofline.pitched_copy`.
 The grid comes from `SamplingTree.refine()` run on the GPU(s) before the timed region; its wall-clock is reported as
 `refine_wall_s` in the same JSON line (second of two runs; the first one of a process, which also pays for the device
 allocations, is `refine_first_run_wall_s`).
@@ -94,7 +98,7 @@ def build_case(name, cfg, geometry):
 
 
 # ---- CPU baselines (rank 0, N = 1 only; the oracle is the checker of the tests, used here as the timed CPU port) --------
-def cpu_baseline(w, idx, data, k, seconds=10.0, n_cells=100_000):
+def cpu_baseline(w, idx, data, k, used, seconds=10.0, n_cells=100_000):
     """the CPU oracle (C + OpenMP restatement of export.py:446-468) on a slice of THIS workload: the first `n_cells` cells of
     the bench's own neighbour table, the source rows they reference, ALL snapshots of the bench's batch"""
     from oracle import s3_oracle as orc
@@ -102,7 +106,7 @@ def cpu_baseline(w, idx, data, k, seconds=10.0, n_cells=100_000):
     i_s, w_s = idx[:nc].cpu().numpy(), w[:nc].cpu().numpy()
     rows, inv = np.unique(i_s, return_inverse=True)
     t = int(data.shape[1])
-    sub = data[pt.from_numpy(rows).to(data.device).long()].contiguous().cpu().numpy().reshape(len(rows), 1, t)
+    sub = data[used.long()[pt.from_numpy(rows).to(data.device).long()]].contiguous().cpu().numpy().reshape(len(rows), 1, t)   # (`idx` holds positions in `used`)
     inv = inv.reshape(i_s.shape)
     orc.interp(w_s, inv, sub)                  # warm
     reps, t0 = 0, time.perf_counter()
@@ -164,18 +168,30 @@ def end_to_end(x, centers, k, batches=(25, 200)):
     return out
 
 
+def code_sha():
+    """fingerprint of the native sources the kernels are built from (csrc/ + include/): the snapshot on the GPU box has no
+    .git, so this is what ties a recorded profile to the code it was taken with"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "sparsespatialsampling_amd", "csrc", "*.h*")) + glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def recorded_traffic(workload_key):
     """HBM bytes per launch of the dominant kernel as RECORDED in the committed PMC passes (profiles/rNN/summary.json:
     FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE from separate rocprofv3 --pmc runs of this
-    command); (None, None) when no pass was recorded for this workload"""
+    command); -> (bytes, file, stale): `stale` when the native sources changed since that collection (`code_sha`);
+    (None, None, None) when no pass was recorded for this workload"""
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "*", "summary.json")), reverse=True):
         try:
             rec = json.load(open(f))
         except (OSError, ValueError):
             continue
         if rec.get("workload_key") == workload_key and "traffic_bytes_per_launch" in rec:
-            return rec["traffic_bytes_per_launch"], os.path.relpath(f, ROOT)
-    return None, None
+            return rec["traffic_bytes_per_launch"], os.path.relpath(f, ROOT), rec.get("code_sha") != code_sha()
+    return None, None, None
 
 
 def copy_bandwidth_gbs(n_bytes=2 << 30, reps=5):
@@ -246,32 +262,47 @@ def ms_stats(ms):
                 kernel_ms_max=float(np.max(ms)), launches=len(ms))
 
 
-def planned_kernel_name(t_elems, k, plan_tiles):
-    """the kernel s3_interp_planned dispatches a batch of fp32 rows of t_elems elements to (csrc/interp_plan.hip: launch_planned)"""
+def planned_kernel_name(t_elems, k, plan_tiles, pitch_elems=None):
+    """the kernel s3_interp_planned / s3_interp_planned_src dispatches a batch of fp32 rows of t_elems elements with a row pitch
+    of pitch_elems elements to (csrc/interp_plan.hip: planned_dispatch / launch_planned); None: whole 128-byte lines"""
+    pitch = pitch_elems if pitch_elems is not None else (t_elems + 31) // 32 * 32
+    even = "true" if t_elems % 2 == 0 else "false"
+    if pitch % 4:                                                    # rows on element boundaries only: the persistent kernel
+        return f"interp_planned_stream_kernel<float,{k},false,{even}>"
     vecs = (t_elems + 3) // 4
     if vecs <= 4:
         return ("interp_planned_short_quad_kernel<float,7>" if vecs == 4 and not os.environ.get("S3_SHORT_NO_QUAD")
                 else "interp_planned_short_reg_kernel<float,26>")
     chunks = (t_elems + 31) // 32
     if chunks <= int(os.environ.get("S3_STREAM_MAX_CHUNKS", "8")) and k in (8, 26) and plan_tiles >= int(os.environ.get("S3_STREAM_MIN_TILES", "64")):
-        return f"interp_planned_stream_kernel<float,{k},true,{'true' if t_elems % 2 == 0 else 'false'}>"
+        return f"interp_planned_stream_kernel<float,{k},true,{even}>"
+    if pitch % 32 and os.environ.get("S3_INPLACE_SHIFT", "1") != "0":  # rows off the 128-byte grid: whole lines, phase undone in LDS
+        return "interp_planned_shift_kernel<float>"
     return "interp_planned_kernel<float,64>"
 
 
-def batch_record(hipops, plan, w, n_rows, nc, k, row_len, label, workload_key, steps, warmup, gen):
-    """roofline sub-record of one batch shape: rows of `row_len` fp32 elements in the layout ExportData uploads into"""
-    data = hipops.padded_rows(n_rows, row_len, pt.float32, "cuda")
-    data.normal_(generator=gen)
+def batch_record(hipops, plan, w, used, n_points, nc, k, row_len, label, workload_key, steps, warmup, gen):
+    """roofline sub-record of one batch shape: a dense [n_points, row_len] fp32 batch read in place (the API's form); the same
+    launch on the pitched copy of the referenced rows (the layout ExportData uploads host batches into) beside it"""
+    n_rows = int(used.numel())
+    table = pt.empty((n_points, row_len), dtype=pt.float32, device="cuda")
+    table.normal_(generator=gen)
     out = pt.empty((nc, row_len), dtype=pt.float64, device="cuda")
-    ms = launch_times_ms(lambda: plan.interp(w, data, out=out), steps, warmup)
+    ms = launch_times_ms(lambda: plan.interp_src(table, out=out), steps, warmup)
     b_alg = n_rows * row_len * 4 + nc * row_len * 8 + nc * k * (4 + 8)
     st = ms_stats(ms)
-    traffic, src = recorded_traffic(workload_key)
-    rec = dict(rows=label, row_bytes=row_len * 4, pitch_bytes=int(data.stride(0)) * 4, kernel=planned_kernel_name(row_len, k, plan.n_tiles),
+    traffic, src, stale = recorded_traffic(workload_key + "/inplace")
+    rec = dict(rows=label + ", dense [N, L] batch of all points read in place", row_bytes=row_len * 4, pitch_bytes=row_len * 4,
+               kernel=planned_kernel_name(row_len, k, plan.n_tiles, row_len),
                algorithmic_bytes=b_alg, achieved=b_alg / (st["kernel_ms"] * 1e-3) / 1e9, unit="GB/s",
                frac=b_alg / (st["kernel_ms"] * 1e-3) / 8e12, frac_best_launch=b_alg / (st["kernel_ms_min"] * 1e-3) / 8e12,
                Gcells_snapshots_per_s=nc * row_len / (st["kernel_ms"] * 1e-3) / 1e9, traffic=traffic,
-               traffic_source=None if traffic is None else f"recorded, not measured in this run: {src}", **st)
+               traffic_source=None if traffic is None else f"recorded, not measured in this run: {src}", traffic_stale=stale, **st)
+    data = hipops.gather_rows(table, used, hipops.padded_rows(n_rows, row_len, pt.float32, "cuda"))
+    del table
+    pms = ms_stats(launch_times_ms(lambda: plan.interp(w, data, out=out), steps, warmup))
+    rec["pitched_copy"] = dict(pitch_bytes=int(data.stride(0)) * 4, kernel=planned_kernel_name(row_len, k, plan.n_tiles),
+                               frac=b_alg / (pms["kernel_ms"] * 1e-3) / 8e12, **pms)
     del data, out
     return rec
 
@@ -279,8 +310,8 @@ def batch_record(hipops, plan, w, n_rows, nc, k, row_len, label, workload_key, s
 def device_resident_input(x, centers, k, t_list, bare_ms):
     """a CUDA tensor [N, 1, T] fp32 as the reference hands batches over (export.py:128-167: every row of the CFD mesh, dense)
     -> ExportData: `interp_ms` = upload step + neighbour table on the device (HIP events; [Nc, T] f64 stays in HBM),
-    `fit_data_ms` = the whole _fit_data incl. transpose and download to the host.  `bare_kernel_ms`: the planned kernel on
-    the pitched copy of the referenced rows (the layout the headline is measured in)."""
+    `fit_data_ms` = the whole _fit_data incl. transpose and download to the host.  `bare_kernel_ms`: the headline's launch
+    (s3_interp_planned_src on the same kind of tensor, without ExportData around it)."""
     from sparsespatialsampling_amd.export import ExportData, _as_float
     s = types.SimpleNamespace(n_dimensions=3, faces=None, centers=pt.from_numpy(centers), vertices=None, levels=None,
                               metric=pt.zeros(len(x), dtype=pt.float64), size_initial_cell=1.0, save_path=".", save_name="bench",
@@ -473,24 +504,26 @@ def main():
     if not args.direct:
         plan = hipops.InterpPlan(idx, n_rows, my_centers, tile_cells=int(os.environ.get("S3_TILE_CELLS", "0")))
         plan.set_weights(w)
+        plan.set_source_ids(used.contiguous(), len(x))       # what ExportData does for device-resident batches
     pt.cuda.synchronize()
     knn_cache_s = time.perf_counter() - t0
     nc, t_b = len(my_centers), cfg["t_batch"]
     row_len = t_b * args.n_comp                      # values per source row: [N, n_comp, T] flattened
 
-    # ---- synthetic snapshot batch resident in HBM ---------------------------------------------------------------
+    # ---- synthetic snapshot batch resident in HBM, as the API receives it ----------------------------------------
+    # dense [N_points, n_comp * T] fp32: a row for EVERY point of the CFD mesh (interpolate_data / ExportData.export get the
+    # field like this, export.py:128-167, 446-468); the kernels read the rows the grid references where they lie
     gen = pt.Generator(device="cuda").manual_seed(1234 + (rank if args.shard == "snapshots" else 0))
-    # the layout the export path uploads into: [rows, T] with the pitch of hipops.padded_rows
-    data = hipops.padded_rows(n_rows, row_len, pt.float32, "cuda", int(os.environ.get("S3_BENCH_PITCH_EXTRA", "0")))
+    data = pt.empty((len(x), row_len), dtype=pt.float32, device="cuda")
     data.normal_(generator=gen)
-    dense = data.contiguous() if args.direct else None
     out = pt.empty((nc, row_len), dtype=pt.float64, device="cuda")
+    idx_full = used.long()[idx.long()].to(pt.int32) if args.direct else None       # --direct: ids in the full table
 
     def step():
         if plan is not None:
-            plan.interp(w, data, out=out)
+            plan.interp_src(data, out=out)
         else:
-            hipops.interp(w, idx, dense, out=out)
+            hipops.interp(w, idx_full, data, out=out)
 
     for _ in range(args.warmup):
         step()
@@ -508,6 +541,18 @@ def main():
     launch_ms = [a.elapsed_time(b) for a, b in ev]                       # HIP events on the launch stream, per launch
     kernel_ms = float(np.mean(launch_ms))
 
+    # the same launch on the pitched, compacted copy of the referenced rows (Hilbert order, whole 128-byte lines per row:
+    # the layout ExportData uploads HOST batches into -- rounds 1-3 quoted the headline on it)
+    pitched = None
+    if rank == 0 and world == 1 and plan is not None:
+        rows_p = hipops.gather_rows(data, used.contiguous(), hipops.padded_rows(n_rows, row_len, pt.float32, "cuda",
+                                                                               int(os.environ.get("S3_BENCH_PITCH_EXTRA", "0"))))
+        pms = launch_times_ms(lambda: plan.interp(w, rows_p, out=out), args.steps, args.warmup)
+        pitched = dict(layout=f"the {n_rows} referenced rows only, Hilbert order, pitch {int(rows_p.stride(0)) * 4} B (whole 128-byte lines)",
+                       kernel=planned_kernel_name(row_len, k, plan.n_tiles), **ms_stats(pms))
+        del rows_p
+        step()                                       # `out` holds the headline's result again
+
     copy_bw = copy_bandwidth_gbs() if rank == 0 else None
     if rank == 0:
         units = (nc * world if args.shard == "snapshots" else nc_total) * t_b * args.steps
@@ -516,21 +561,22 @@ def main():
         # once + idx (int32) / weights (f64) once
         b_alg = n_rows * row_len * 4 + nc * row_len * 8 + nc * k * (4 + 8)
         achieved = b_alg / (kernel_ms * 1e-3) / 1e9
-        workload = (f"{args.workload} (synthetic, SURVEY 8(d)): {len(x)} points of which the {n_rows} rows the grid references "
-                    f"are resident (pitched, Hilbert order) x {t_b} snapshots per step, {nc_total} generated cells, k={k}, "
-                    f"fp32 in / f64 out")
+        workload = (f"{args.workload} (synthetic, SURVEY 8(d)): dense batch [{len(x)} points, {row_len}] fp32 resident in HBM as "
+                    f"interpolate_data receives it, read in place ({n_rows} rows referenced) x {t_b} snapshots per step, "
+                    f"{nc_total} generated cells, k={k}, fp32 in / f64 out")
         shape_key = f"T{t_b}" + (f"x{args.n_comp}" if args.n_comp > 1 else "")
-        traffic, traffic_src = recorded_traffic(f"{args.workload}/{shape_key}") if plan is not None and world == 1 else (None, None)
+        traffic, traffic_src, traffic_stale = (recorded_traffic(f"{args.workload}/{shape_key}/inplace") if plan is not None and world == 1
+                                               else (None, None, None))
         res = {
             "metric": "Mcells*snapshots/s interpolated", "value": value, "unit": "Mcells*snapshots/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak" if args.shard == "snapshots" else "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload, "n_points": len(x), "resident_source_rows": n_rows, "n_cells": nc_total,
-                       "t_batch": t_b, "k": k, "n_comp": args.n_comp, "shape_key": shape_key,
+                       "t_batch": t_b, "k": k, "n_comp": args.n_comp, "shape_key": shape_key, "input": "dense device tensor, read in place",
                        "parallelism": f"{'snapshot-axis' if args.shard == 'snapshots' else 'leaf-cell'} shards x{world}",
                        "cells_per_rank": shard_counts, "collectives": comm.name},
-            "device": device_identity(),
+            "device": device_identity(), "code_sha": code_sha(),
             "refine_wall_s": refine_s, "refine_init_s": t_init, "refine_first_run_wall_s": refine_first_s,
             "refine_runs_s": [t[0] for t in timings],
             "refine_iterations": info["iterations"],
@@ -539,23 +585,28 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "copy_kernel_GBs": copy_bw, "frac_of_copy_kernel": achieved / copy_bw,
                          "traffic": traffic, "traffic_source": None if traffic is None else f"recorded, not measured in this run: {traffic_src}",
-                         "kernel": "interp_kernel<float,4>" if plan is None else planned_kernel_name(row_len, k, plan.n_tiles),
+                         "traffic_stale": traffic_stale,
+                         "kernel": "interp_kernel<float,4>" if plan is None else planned_kernel_name(row_len, k, plan.n_tiles, row_len),
                          "staged_rows_per_launch": None if plan is None else plan.total_rows, **ms_stats(launch_ms),
                          "frac_best_launch": b_alg / (min(launch_ms) * 1e-3) / 8e12,
                          "algorithmic_bytes": b_alg, "resident_source_rows": n_rows, "cells_on_this_rank": nc,
                          "gather_upper_bound_bytes": nc * k * row_len * 4 + nc * row_len * 8},
         }
+        if pitched is not None:
+            pitched["frac"] = b_alg / (pitched["kernel_ms"] * 1e-3) / 8e12
+            pitched["in_place_over_pitched"] = kernel_ms / pitched["kernel_ms"]
+            res["roofline"]["pitched_copy"] = pitched
         if world == 1 and plan is not None and not args.no_batches:
             # the batch lengths the reference exports with (examples/s3_for_cylinder3D_Re3900.py:28-69, utils.py:204-226)
             key = args.workload
             shapes = [("T25", 25, "25 snapshots of a scalar field: 100-byte ragged rows"),
                       ("T25x3", 75, "25 snapshots of a 3-component field: 300-byte rows"),
                       ("T100", 100, "100 snapshots of a scalar field: 400-byte rows")]
-            res["roofline_batches"] = {name: batch_record(hipops, plan, w, n_rows, nc, k, rl, label, f"{key}/{name}",
+            res["roofline_batches"] = {name: batch_record(hipops, plan, w, used.contiguous(), len(x), nc, k, rl, label, f"{key}/{name}",
                                                            args.steps, args.warmup, gen)
                                        for name, rl, label in shapes if rl != row_len}
         if not args.no_cpu_baseline and world == 1:       # reported at N=1 only
-            res["cpu_baseline"] = cpu_baseline(w, idx, data, k)
+            res["cpu_baseline"] = cpu_baseline(w, idx, data, k, used)
             bare = {t_b: kernel_ms}
             if "roofline_batches" in res and "T25" in res["roofline_batches"]:
                 bare[25] = res["roofline_batches"]["T25"]["kernel_ms"]
@@ -570,8 +621,9 @@ def main():
             res["refine_cpu_baseline"] = rcb
             cpu_g = res["cpu_baseline"]["value"] / 1e3                       # G cell*snapshots/s of the CPU port
             ratios = {"in_hbm": value / 1e3 / cpu_g, "cpu_port_Gcells_snapshots_per_s": cpu_g,
-                      "note": "GPU rate / rate of the OpenMP oracle port on this box's host cores; in_hbm: the headline (inputs "
-                              "resident, pitched), device_resident: dense CUDA batch in -> device out, host_to_host: end_to_end"}
+                      "note": "GPU rate / rate of the OpenMP oracle port on this box's host cores; in_hbm: the headline (dense batch "
+                              "resident, read in place), device_resident: the same through ExportData._upload + neighbour table, "
+                              "host_to_host: end_to_end"}
             if "device_resident_input" in res:
                 ratios["device_resident"] = res["device_resident_input"][f"T{t_b}"]["Gcells_snapshots_per_s"] / cpu_g
                 e2e = res["end_to_end"]

@@ -454,6 +454,177 @@ interp_planned_kernel(const int32_t *__restrict__ perm, const int32_t *__restric
 #undef S3_STORE_B
 #undef S3_DECL
 
+// Long rows that start on 16-byte but not on 128-byte boundaries: a dense [N, n_comp * T] batch read where it lies
+// (interpolate_data consumes the caller's table as it stands, export.py:446-468; 1000 fp32 snapshots = 4000-byte rows whose
+// starts sit 0 / 32 / 64 / 96 bytes into a cache line).  The kernel above would stage the 128 bytes [c * 128, c * 128 + 128) of
+// every row per step: for three rows in four that segment straddles two lines, each line is asked for by two consecutive
+// steps (7 us apart -- the L2 has turned over by then), and the launch moves 15-25 % more bytes (4.1 against 3.5 ms).
+// Here every load instruction fetches whole ALIGNED lines: line j of a row = the 128 bytes at (row start rounded down to
+// 128) + j * 128, lane v of the row's eight staging lanes holding its v-th vector.  With ph = (row start mod 128) / 16 the
+// vectors v >= ph of line c and the vectors v < ph of line c + 1 together are the row's segment c, so the two register sets
+// hold two CONSECUTIVE lines and the LDS image of step c takes, per lane, the older set's vector (v >= ph) or the newer
+// one's (v < ph), at slot (v - ph) mod 8 -- one ds_write_b128 per lane and row as before, behind four v_cndmask.  The set
+// that held line c is refilled with line c + 2 right away.  Every line is fetched once, by one full-line request; the LDS
+// image, the accumulate phase and the arithmetic are those of the kernel above (same results bit for bit).
+// Lines that reach beyond the last vector of a row (the row's last one or two, depending on ph) are loaded with the
+// lane's offset clamped to the row's last vector: nothing outside the 128-byte lines that hold the row's own bytes is read.
+// (component-wise: a ternary on the vector STRUCTS selects between their addresses and sends both register sets to scratch)
+__device__ __forceinline__ float4 select16(bool c, const float4 &a, const float4 &b) {
+    return make_float4(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w);
+}
+__device__ __forceinline__ double2 select16(bool c, const double2 &a, const double2 &b) {
+    return make_double2(c ? a.x : b.x, c ? a.y : b.y);
+}
+template <typename T>
+__global__ void __launch_bounds__(256, 2)
+interp_planned_shift_kernel(const int32_t *__restrict__ perm, const int32_t *__restrict__ tile_cell_begin,
+                            const int32_t *__restrict__ tile_row_begin, const int32_t *__restrict__ rows,
+                            const uint16_t *__restrict__ loc, const double *__restrict__ w /*plan order*/, int k, int ucap,
+                            const T *__restrict__ data, int64_t row_len, int64_t in_stride, double *__restrict__ out,
+                            int64_t n_tiles, int64_t tiles_per_xcd, int chunks_per_block, int n_chunks) {
+    using V = typename Vec16<T>::type;
+    constexpr int TC = 64;
+    constexpr int EPV = Vec16<T>::N;
+    constexpr int EPC = PL_SEG / (int)sizeof(T);
+    constexpr int BLOCK = TC * 4;
+    constexpr int RPP = BLOCK / 8;
+    extern __shared__ float4 lds_raw[];
+    V *s_data = reinterpret_cast<V *>(lds_raw);                                  // [ucap][8] 16-byte vectors
+    double *s_w = reinterpret_cast<double *>(lds_raw + (size_t)ucap * 8);        // [k][TC]
+    uint16_t *s_loc = reinterpret_cast<uint16_t *>(s_w + (size_t)k * TC);        // [k][TC]
+
+    const int64_t b = blockIdx.x;
+    const int64_t tile = (b & 7) * tiles_per_xcd + (b >> 3);     // XCD-aware (speed only)
+    if (tile >= n_tiles) return;
+    const int c_begin = tile_cell_begin[tile], n_c = tile_cell_begin[tile + 1] - c_begin;
+    const int r_begin = tile_row_begin[tile], n_r = tile_row_begin[tile + 1] - r_begin;
+    const bool even_rows = (row_len & 1) == 0;
+
+    stage_tile_tables(w + (int64_t)c_begin * k, loc + (int64_t)c_begin * k, n_c * k, s_w, s_loc, BLOCK);
+
+    const int cl = threadIdx.x >> 2, v0 = threadIdx.x & 3;
+    const bool has_cell = cl < n_c;
+    const int64_t cell = has_cell ? perm[c_begin + cl] : 0;
+
+    const int chunk0 = blockIdx.y * chunks_per_block;
+    const int chunk1 = min(n_chunks, chunk0 + chunks_per_block);
+
+    const int srow = threadIdx.x >> 3, svec = threadIdx.x & 7;
+    const uintptr_t base = reinterpret_cast<uintptr_t>(data);
+    const uint64_t stride_bytes = (uint64_t)in_stride * sizeof(T);
+    const int n_vec_row = (int)((row_len + EPV - 1) / EPV);      // 16-byte vectors that hold a row's own bytes
+    const int last_vec = n_vec_row - 1;                          // the last of them, counted from the row start
+    const uintptr_t base128 = base & ~(uintptr_t)127;
+    char *const lds_raw_bytes = reinterpret_cast<char *>(lds_raw);
+    // (pointer arithmetic on the kernel argument, so that the loads stay global_load: an integer cast to a pointer gives flat_load)
+    const char *const data128 = reinterpret_cast<const char *>(data) - (base & 127);
+    const int j_safe = n_vec_row / 8 - 1;                        // lines 0 .. j_safe lie inside the row whatever its phase
+    // per staging pass: address of this lane's vector of the row's line 0, its LDS slot, and whether the OLDER of the two
+    // lines in the registers is the one this lane contributes to an image (v >= ph)
+#define S3H_DECL(P)                                                                                              \
+    uint32_t line##P; /* in 16-byte vectors from base128 (the launcher checks that the table ends below 2^32 of them) */ \
+    uint32_t lds##P;  /* LDS byte address of this lane's slot of the row image */                                \
+    bool old##P;      /* this lane takes its vector from the OLDER of the two lines in the registers */          \
+    V preA##P, preB##P;                                                                                          \
+    {                                                                                                            \
+        const uintptr_t a_ = base + (uint64_t)(uint32_t)rows[r_begin + min(P * RPP + srow, n_r - 1)] * stride_bytes; \
+        const int ph_ = (int)(a_ >> 4) & 7;                                                                      \
+        line##P = (uint32_t)(((a_ & ~(uintptr_t)127) - base128) >> 4) + (uint32_t)svec;                          \
+        old##P = svec >= ph_;                                                                                    \
+        /* (passes beyond the tile's last row hold a copy of it and store that copy where the row itself goes) */  \
+        lds##P = (uint32_t)(min(P * RPP + srow, n_r - 1) * 8 + ((svec - ph_) & 7)) * 16u;                         \
+    }
+    S3_REP16(S3H_DECL)
+    // line J of every row of this lane's passes -> register set SET.  Past j_safe the lane's vector index counted from the row
+    // start (J * 8 + svec - ph) is clamped to the row's last vector.
+#define S3H_LOAD_FAST(SET, P) pre##SET##P = *reinterpret_cast<const V *>(data128 + ((uint64_t)(line##P + jvec_) << 4));
+#define S3H_LOAD_SAFE(SET, P)                                                                                    \
+    {                                                                                                            \
+        const int s_ = (int)(lds##P >> 4) & 7;           /* (svec - ph) mod 8 */                                  \
+        const int d_ = s_ <= svec ? s_ : s_ - 8;         /* svec - ph */                                          \
+        const int over_ = max(0, (int)jvec_ + d_ - last_vec);                                                    \
+        pre##SET##P = *reinterpret_cast<const V *>(data128 + ((uint64_t)(line##P + jvec_ - (uint32_t)over_) << 4)); \
+    }
+#define S3H_LOAD_FAST_A(P) S3H_LOAD_FAST(A, P)
+#define S3H_LOAD_FAST_B(P) S3H_LOAD_FAST(B, P)
+#define S3H_LOAD_SAFE_A(P) S3H_LOAD_SAFE(A, P)
+#define S3H_LOAD_SAFE_B(P) S3H_LOAD_SAFE(B, P)
+#define S3H_ISSUE(SET, J)                                        \
+    do {                                                         \
+        const uint32_t jvec_ = (uint32_t)(J) * 8u;               \
+        if ((J) <= j_safe) {                                     \
+            S3_REP16(S3H_LOAD_FAST_##SET)                        \
+        } else {                                                 \
+            S3_REP16(S3H_LOAD_SAFE_##SET)                        \
+        }                                                        \
+    } while (0)
+    // image c from (older set = line c, newer set = line c + 1)
+    // One LDS store per row and lane behind a select of the older / newer line's vector.  (Two stores under complementary
+    // lane masks instead -- no v_cndmask -- were built and measured: 3.85 against 3.51 ms; the LDS write port costs more than
+    // the four vector-ALU instructions.)
+#define S3H_STORE2(P, OLD, NEW) *reinterpret_cast<V *>(lds_raw_bytes + lds##P) = select16(old##P, OLD, NEW);
+#define S3H_STORE_AB(P) S3H_STORE2(P, preA##P, preB##P)
+#define S3H_STORE_BA(P) S3H_STORE2(P, preB##P, preA##P)
+#define S3H_STORES_DONE()
+
+    auto accumulate = [&](int chunk) {
+        if (!has_cell) return;
+        const int64_t col0 = (int64_t)chunk * EPC;
+        double acc0[EPV], acc1[EPV];
+#pragma unroll
+        for (int i = 0; i < EPV; ++i) acc0[i] = acc1[i] = 0.0;
+#pragma unroll 4
+        for (int m = 0; m < k; ++m) {
+            const int pos = s_loc[m * n_c + cl];
+            const double wm = s_w[m * n_c + cl];
+            const V a = s_data[pos * 8 + v0];
+            const V c = s_data[pos * 8 + v0 + 4];
+            const T *ae = reinterpret_cast<const T *>(&a);
+            const T *ce = reinterpret_cast<const T *>(&c);
+#pragma unroll
+            for (int i = 0; i < EPV; ++i) {
+                acc0[i] = fma(wm, (double)ae[i], acc0[i]);
+                acc1[i] = fma(wm, (double)ce[i], acc1[i]);
+            }
+        }
+        double *o = out + cell * row_len + col0;
+        store_piece<EPV>(o + v0 * EPV, acc0, row_len - col0 - (int64_t)v0 * EPV, even_rows);
+        store_piece<EPV>(o + (v0 + 4) * EPV, acc1, row_len - col0 - (int64_t)(v0 + 4) * EPV, even_rows);
+    };
+
+    if (chunk0 < chunk1) {
+        S3H_ISSUE(A, chunk0);
+        S3H_ISSUE(B, chunk0 + 1);
+    }
+    for (int chunk = chunk0; chunk < chunk1; chunk += 2) {
+        S3_REP16(S3H_STORE_AB)
+        S3H_STORES_DONE();
+        __syncthreads();
+        if (chunk + 1 < chunk1) S3H_ISSUE(A, chunk + 2);
+        accumulate(chunk);
+        __syncthreads();
+        if (chunk + 1 >= chunk1) break;
+        S3_REP16(S3H_STORE_BA)
+        S3H_STORES_DONE();
+        __syncthreads();
+        if (chunk + 2 < chunk1) S3H_ISSUE(B, chunk + 3);
+        accumulate(chunk + 1);
+        __syncthreads();
+    }
+#undef S3H_DECL
+#undef S3H_LOAD_FAST
+#undef S3H_LOAD_SAFE
+#undef S3H_LOAD_FAST_A
+#undef S3H_LOAD_FAST_B
+#undef S3H_LOAD_SAFE_A
+#undef S3H_LOAD_SAFE_B
+#undef S3H_ISSUE
+#undef S3H_STORE2
+#undef S3H_STORE_AB
+#undef S3H_STORE_BA
+#undef S3H_STORES_DONE
+}
+
 // Rows that start on element boundaries only (a dense [N, n_comp * T] batch read where it lies: 25 fp32 snapshots make
 // 100-byte rows).  A 16-byte load that is not 16-byte aligned runs at a quarter of the rate on this chip (measured: 0.69 ms
 // against 0.17 ms for the pitched copy of the same batch), so the lanes load ALIGNED vectors -- the eight that cover the
@@ -631,9 +802,11 @@ interp_planned_stream_kernel(const int32_t *__restrict__ perm, const int32_t *__
         if constexpr (ALIGNED) {                                                                                             \
             pre##P = *reinterpret_cast<const V *>(a_ + (ok_ ? svec : 0) * EPV);                                              \
         } else {                                                                                                             \
-            const uintptr_t a0_ = reinterpret_cast<uintptr_t>(a_) & ~(uintptr_t)15;                                          \
-            const uintptr_t p_ = a0_ + 16u * (unsigned)svec;                                                                 \
-            pre##P = *reinterpret_cast<const V *>(p_ < reinterpret_cast<uintptr_t>(a_) + valid_bytes_ ? p_ : a0_);           \
+            /* (offsets from the kernel argument's pointer: an address made from an integer would be a flat_load, which  \
+               counts against lgkmcnt too -- every LDS wait of the accumulate phase would wait for the prefetch) */         \
+            const int mis_ = (int)(reinterpret_cast<uintptr_t>(a_) & 15);                                                    \
+            const int off_ = 16 * svec - mis_;                                                                               \
+            pre##P = *reinterpret_cast<const V *>(reinterpret_cast<const char *>(a_) + (off_ < (int)valid_bytes_ ? off_ : -mis_)); \
         }                                                                                                                    \
     } while (0);
 #define S3S_ISSUE(CH)                                                                    \
@@ -816,6 +989,10 @@ static int64_t stream_min_tiles() {
     const char *e = getenv("S3_STREAM_MIN_TILES");
     return e ? atoll(e) : 64ll;
 }
+static int inplace_shift() {                 // 0: never (A/B runs), 1: rows off the 128-byte grid (default), 2: always (A/B runs)
+    const char *e = getenv("S3_INPLACE_SHIFT");
+    return e ? atoi(e) : 1;
+}
 static int stream_workgroups() {
     static const int v = [] {
         const char *e = getenv("S3_STREAM_WORKGROUPS");
@@ -925,7 +1102,7 @@ static int launch_stream(s3_interp_plan *p, const int32_t *rows, const void *dat
 }
 
 template <typename T>
-static int launch_planned(s3_interp_plan *p, const int32_t *rows, bool aligned, const void *data, int64_t row_len,
+static int launch_planned(s3_interp_plan *p, const int32_t *rows, int64_t n_rows, bool aligned, const void *data, int64_t row_len,
                           int64_t in_stride, double *out, hipStream_t st) {
     if (!aligned) {                              // element-aligned rows read where they lie: the persistent kernel only
         S3_REQUIRE(stream_can_take(p), "s3_interp_planned: rows that are not 16-byte aligned need k = 8 | 26 and 64-cell tiles");
@@ -999,6 +1176,20 @@ static int launch_planned(s3_interp_plan *p, const int32_t *rows, bool aligned, 
     S3_REQUIRE(gx < ((int64_t)1 << 31), "s3_interp_planned: too many tiles");
     const size_t lds = (size_t)p->ucap * PL_SEG + (size_t)p->k * p->tc * (sizeof(double) + sizeof(uint16_t));
     dim3 grid((unsigned)gx, (unsigned)gy);
+    // rows that do not start on 128-byte boundaries (a dense batch read where it lies): whole aligned lines per load, the
+    // per-row phase undone on the way into LDS (S3_INPLACE_SHIFT=0: the kernel below with straddling segments, for A/B runs)
+    const bool off_line = reinterpret_cast<uintptr_t>(data) % PL_SEG != 0 || ((uint64_t)in_stride * sizeof(T)) % PL_SEG != 0;
+    // (the kernel addresses the table in 16-byte vectors with 32 bits: tables of up to 64 GiB)
+    const bool fits32 = (uint64_t)n_rows * (uint64_t)in_stride * sizeof(T) + 2 * PL_SEG < ((uint64_t)1 << 36);
+    if (p->tc == 64 && fits32 && (off_line ? inplace_shift() >= 1 : inplace_shift() >= 2)) {
+        auto kern = interp_planned_shift_kernel<T>;
+        S3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        kern<<<grid, 256, lds, st>>>(p->perm, p->tile_cell_begin, p->tile_row_begin, rows, p->loc, p->wp, p->k, p->ucap,
+                                     static_cast<const T *>(data), row_len, in_stride, out, p->n_tiles, tiles_per_xcd,
+                                     chunks_per_block, n_chunks);
+        S3_LAUNCH_CHECK();
+        return S3_OK;
+    }
     if (p->tc == 128) {
         auto kern = interp_planned_kernel<T, 128>;
         S3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1165,7 +1356,7 @@ int s3_interp_plan_set_weights(s3_interp_plan *p, const double *d_w, s3_stream s
 }
 
 // common part of the two launches: `rows` = the plan's row list in the numbering of d_data's rows
-static int planned_dispatch(s3_interp_plan *p, const int32_t *rows, const char *who, const void *d_data, int dtype,
+static int planned_dispatch(s3_interp_plan *p, const int32_t *rows, int64_t n_rows, const char *who, const void *d_data, int dtype,
                             int64_t row_len, int64_t in_stride, double *d_out, s3_stream stream) {
     S3_REQUIRE(p->has_weights, "%s: no weights (pass d_w or call s3_interp_plan_set_weights first)", who);
     S3_REQUIRE(dtype == S3_DTYPE_F32 || dtype == S3_DTYPE_F64, "%s: unknown dtype %d", who, dtype);
@@ -1189,8 +1380,8 @@ static int planned_dispatch(s3_interp_plan *p, const int32_t *rows, const char *
                    (long long)row_len, (long long)in_stride);
     // output rows start on 8-byte boundaries (pairs are written with element alignment where the row length is odd)
     S3_REQUIRE(a_out % ((row_len & 1) ? 8 : 16) == 0, "%s: output not aligned (row_len %lld)", who, (long long)row_len);
-    if (dtype == S3_DTYPE_F32) return launch_planned<float>(p, rows, aligned, d_data, row_len, in_stride, d_out, as_stream(stream));
-    return launch_planned<double>(p, rows, aligned, d_data, row_len, in_stride, d_out, as_stream(stream));
+    if (dtype == S3_DTYPE_F32) return launch_planned<float>(p, rows, n_rows, aligned, d_data, row_len, in_stride, d_out, as_stream(stream));
+    return launch_planned<double>(p, rows, n_rows, aligned, d_data, row_len, in_stride, d_out, as_stream(stream));
 }
 
 int s3_interp_planned(s3_interp_plan *p, const double *d_w, const void *d_data, int dtype, int64_t row_len,
@@ -1200,7 +1391,7 @@ int s3_interp_planned(s3_interp_plan *p, const double *d_w, const void *d_data, 
         const int rc = s3_interp_plan_set_weights(p, d_w, stream);
         if (rc != S3_OK) return rc;
     }
-    return planned_dispatch(p, p->rows, "s3_interp_planned", d_data, dtype, row_len, in_stride, d_out, stream);
+    return planned_dispatch(p, p->rows, p->n_src, "s3_interp_planned", d_data, dtype, row_len, in_stride, d_out, stream);
 }
 
 __global__ void source_ids_kernel(const int32_t *__restrict__ rows, int64_t n, const int32_t *__restrict__ ids, int32_t n_table,
@@ -1242,7 +1433,7 @@ int s3_interp_planned_src(s3_interp_plan *p, const void *d_table, int dtype, int
     S3_REQUIRE(p->rows_src != nullptr && p->n_table > 0, "s3_interp_planned_src: call s3_interp_plan_set_source_ids first");
     S3_REQUIRE(n_table_rows == p->n_table, "s3_interp_planned_src: the table has %lld rows, the ids were given for %lld",
                (long long)n_table_rows, (long long)p->n_table);
-    return planned_dispatch(p, p->rows_src, "s3_interp_planned_src", d_table, dtype, row_len, in_stride, d_out, stream);
+    return planned_dispatch(p, p->rows_src, p->n_table, "s3_interp_planned_src", d_table, dtype, row_len, in_stride, d_out, stream);
 }
 
 

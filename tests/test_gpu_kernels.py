@@ -253,6 +253,64 @@ def test_interp_src_reads_the_full_table_in_place(ops, orc, row_len, dtype):
     plan.close(); knn.close()
 
 
+@pytest.mark.parametrize("row_len,dtype,layout", [
+    (1000, pt.float32, "dense"),        # 4000-byte rows: starts 0 / 32 / 64 / 96 bytes into a line (the bench's batch)
+    (1004, pt.float32, "dense"),        # 4016-byte rows: every phase 0 .. 7
+    (300, pt.float32, "dense"),         # ten chunks, the last one a 48-byte tail
+    (1001, pt.float32, "pitch+3"),      # ragged rows in a 16-byte pitch
+    (514, pt.float64, "dense"),         # f64: 4112-byte rows
+    (1000, pt.float32, "offset16"),     # the table starts 16 bytes into a line
+    (1000, pt.float32, "tail"),         # the table ends with its allocation
+])
+def test_shift_kernel_reads_rows_off_the_line_grid(ops, orc, row_len, dtype, layout):
+    """long rows that start on 16-byte but not on 128-byte boundaries (a dense [N, n_comp * T] batch read where it lies,
+    reference export.py:446-468) take interp_planned_shift_kernel: whole aligned lines per load, the per-row phase undone
+    on the way into LDS.  Same bits as the direct kernel and as the straddling form (S3_INPLACE_SHIFT=0); the oracle on top."""
+    import os
+    rng = np.random.default_rng(row_len)
+    n, nc, k = 50_000, 5_000, 26
+    x, c = rng.random((n, 3)), rng.random((nc, 3)) * 0.5 + 0.25
+    knn = ops.KnnIndex(x)
+    idx, dist = knn.query(c, k)
+    w = ops.idw_weights(dist)
+    knn.close()
+    gen = pt.Generator(device="cuda").manual_seed(row_len)
+    if layout == "dense":
+        table = pt.empty((n, row_len), dtype=dtype, device="cuda").normal_(generator=gen)
+    elif layout == "pitch+3":
+        buf = pt.empty((n, row_len + 3), dtype=dtype, device="cuda").normal_(generator=gen)
+        table = buf[:, :row_len]
+    elif layout == "offset16":
+        buf = pt.empty(n * row_len + 4, dtype=dtype, device="cuda").normal_(generator=gen)
+        table = buf[4:].view(n, row_len)
+        assert table.data_ptr() % 128 == 16
+    else:                               # the last row ends where the allocation ends: nothing behind it may be read
+        buf = pt.empty(2 * 1024 * 1024 // 4 * 96, dtype=dtype, device="cuda").normal_(generator=gen)      # 96 x 2 MiB
+        table = buf[buf.numel() - n * row_len:].view(n, row_len)
+    assert (table.stride(0) * table.element_size()) % 16 == 0 and table.data_ptr() % 16 == 0
+    assert (table.stride(0) * table.element_size()) % 128 != 0 or table.data_ptr() % 128 != 0
+    direct = ops.interp(w, idx, table.contiguous())
+    used, remap = ops.referenced_rows([idx], n, coords=x)
+    idx_c = idx.clone()
+    ops.remap_indices(idx_c, remap)
+    plan = ops.InterpPlan(idx_c, int(used.numel()), c)
+    plan.set_weights(w)
+    plan.set_source_ids(used.contiguous(), n)
+    got = plan.interp_src(table)
+    assert pt.equal(got, direct)
+    os.environ["S3_INPLACE_SHIFT"] = "0"
+    try:
+        assert pt.equal(plan.interp_src(table), direct)
+    finally:
+        del os.environ["S3_INPLACE_SHIFT"]
+    ref = orc.interp(w.cpu().numpy(), idx.cpu().numpy(), table.contiguous().cpu().numpy().reshape(n, 1, row_len)).reshape(nc, row_len)
+    assert np.abs(got.cpu().numpy() - ref).max() <= 1e-13 * np.abs(ref).max()
+    # the plan over ALL rows (no source ids): s3_interp_planned on the same table
+    plan2 = ops.InterpPlan(idx, n, c)
+    assert pt.equal(plan2.interp(w, table), direct)
+    plan.close(); plan2.close()
+
+
 def test_plan_weights_are_identified_by_the_tensor_not_its_address(ops):
     """a plan must not mistake a new weights tensor that the allocator placed at a freed tensor's address for the
     one it holds"""

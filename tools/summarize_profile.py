@@ -13,8 +13,11 @@ leases = sorted((d for d in glob.glob(f"{src}/lease*") if os.path.isdir(d)), key
 def one(lease_dir):
     bench = json.loads([l for l in open(f"{lease_dir}/bench.json").read().splitlines() if l.startswith("{")][-1])
     stats = list(csv.DictReader(open(f"{lease_dir}/kernel_stats.csv")))
+    # the headline's kernel (bench.json names it; the profiled run has no sub-records, so the largest total is the same one)
+    want = bench["roofline"].get("kernel", "").split("<")[0]
     cand = [r for r in stats if "interp_planned" in r["Name"] and "permute" not in r["Name"]]
-    dom = max(cand, key=lambda r: float(r["TotalDurationNs"]))
+    named = [r for r in cand if want and want in r["Name"]]
+    dom = max(named or cand, key=lambda r: float(r["TotalDurationNs"]))
     short = dom["Name"].split("(")[0].split("::")[-1]
 
     def per_launch(counter):
@@ -41,7 +44,9 @@ def one(lease_dir):
         "algorithmic_bytes": b_alg, "traffic_over_algorithmic": (2.0 * fetch + write) * 1024.0 / b_alg,
         "frac_of_peak_rocprof": b_alg / (float(dom["AverageNs"]) * 1e-9) / 8e12,
         "frac_of_peak_hip_events_unprofiled": b_alg / (events["kernel_ms"] * 1e-3) / 8e12,
-        "workload": cfg["workload"], "workload_key": f"{cfg['workload'].split(' ')[0]}/{cfg.get('shape_key', 'T%d' % cfg['t_batch'])}",
+        "workload": cfg["workload"],
+        "workload_key": f"{cfg['workload'].split(' ')[0]}/{cfg.get('shape_key', 'T%d' % cfg['t_batch'])}" + ("/inplace" if "in place" in cfg.get("input", "") else ""),
+        "code_sha": bench.get("code_sha"),
     }, bench
 
 
@@ -56,6 +61,10 @@ for i, d in enumerate(leases):
 fr = [r["frac_of_peak_rocprof"] for r in records]
 summary = {
     "workload_key": records[0]["workload_key"], "workload": records[0]["workload"], "kernel": records[0]["kernel"],
+    # fingerprint of csrc/ + include/ the collection ran on (bench.py: code_sha; `roofline.traffic_stale` compares it with the
+    # tree it runs in) and the commit the dev container stood at when the summary was made
+    "code_sha": records[-1]["code_sha"], "code_sha_all_leases_equal": len({r["code_sha"] for r in records}) == 1,
+    "git_head_at_summary": os.popen("git rev-parse HEAD 2>/dev/null").read().strip() or None,
     "algorithmic_bytes": records[0]["algorithmic_bytes"], "n_leases": len(records),
     "frac_of_peak_rocprof_min_median_max": [min(fr), sorted(fr)[len(fr) // 2], max(fr)],
     "avg_ms_rocprof_per_lease": [r["avg_ms_rocprof"] for r in records],

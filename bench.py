@@ -154,7 +154,9 @@ def end_to_end(x, centers, k, batches=(25, 200)):
     out = {}
     for t in batches:
         data = pt.empty((len(x), 1, t), dtype=pt.float32).normal_()
-        ex._fit_data(coords, data, "f", 10 ** 9)             # first call builds the cache; warm the transport for this size
+        for _ in range(2):                                   # the first call builds the cache; two calls allocate BOTH pinned
+            ex._fit_data(coords, data, "f", 10 ** 9)         # download buffers of this size (they are used alternately)
+        pt.cuda.synchronize()
         t0 = time.perf_counter()
         reps = 3
         for _ in range(reps):
@@ -163,8 +165,9 @@ def end_to_end(x, centers, k, batches=(25, 200)):
         dt = (time.perf_counter() - t0) / reps
         out[f"T{t}"] = dict(ms_per_batch=dt * 1e3, Gcells_snapshots_per_s=len(centers) * t / dt / 1e9)
         del data
-    out["note"] = ("freshly allocated pageable host tensor [N,1,T] fp32 in, host f64 tensor out; only the source rows the grid "
-                   "references are uploaded")
+    out["note"] = ("pageable host tensor [N,1,T] fp32 in, host f64 tensor out; only the source rows the grid references are "
+                   "uploaded; three batches back to back (steady state of an export: the download of a batch overlaps the upload "
+                   "of the next one), all transfers finished before the clock stops")
     return out
 
 
@@ -321,7 +324,8 @@ def device_resident_input(x, centers, k, t_list, bare_ms):
     out = {}
     for t in t_list:
         data = pt.empty((len(x), 1, t), dtype=pt.float32, device="cuda").normal_()
-        ex._fit_data(coords, data, "f", 10 ** 9)             # builds the cache on the first call; warms this size
+        for _ in range(2):                                   # builds the cache on the first call; two calls allocate both
+            ex._fit_data(coords, data, "f", 10 ** 9)         # pinned download buffers of this size (used alternately)
 
         def on_device():
             batch, in_place = ex._upload(_as_float(data))

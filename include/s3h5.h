@@ -57,6 +57,13 @@ int s3h5_write(s3h5_file *f, const char *path, int dtype, int ndim, const int64_
 int s3h5_write_snapshots_async(s3h5_file *f, const char *group /* "data" */, const char *const *times, int64_t n_snapshots,
                                const char *name, int dtype, int ndim, const int64_t *dims, const void *h_base,
                                int64_t stride_bytes);
+/* the same for a batch whose values are still on their way into h_base (ExportData queues the device-to-host copy of an
+ * interpolated batch and hands the buffer over at once, so that the copy overlaps the upload of the next batch): the writer
+ * starts on the batch once *h_ready >= ready_value -- a 4-byte word in host memory that the producer writes behind the copy,
+ * in the copy's stream.  h_ready == NULL: the values are there already. */
+int s3h5_write_snapshots_async_when(s3h5_file *f, const char *group, const char *const *times, int64_t n_snapshots,
+                                    const char *name, int dtype, int ndim, const int64_t *dims, const void *h_base,
+                                    int64_t stride_bytes, const int32_t *h_ready, int32_t ready_value);
 /* wait until every queued write has been carried out; *n_skipped (optional) = datasets skipped because they existed */
 int s3h5_flush(s3h5_file *f, int64_t *n_skipped);
 /* wait until no queued write reads from [h_base, h_base + bytes) any more (before the buffer is overwritten) */

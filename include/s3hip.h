@@ -40,7 +40,7 @@ extern "C" {
 
 /* what s3_abi_version() of a library built from this header returns; the bindings refuse a library that reports another
  * number (a stale build) with the command that rebuilds it */
-#define S3_ABI_VERSION 3
+#define S3_ABI_VERSION 4
 
 typedef struct s3_knn s3_knn; /* opaque: grid-sorted copy of the original point cloud, resident in HBM */
 typedef void *s3_stream;
@@ -69,6 +69,14 @@ int s3_upload_rows(const void *h_src, int64_t n_rows, int64_t row_bytes, void *d
  * the sparsity of the grid. */
 int s3_upload_rows_indexed(const void *h_src, const int32_t *h_rows /*[n_sel]*/, int64_t n_sel, int64_t row_bytes,
                            void *d_dst, int64_t dst_pitch_bytes, s3_stream stream);
+/* the same for a PIECE of every (selected) row: source row r (h_rows[i], or i when h_rows is NULL) starts at h_src +
+ * r * src_row_stride_bytes + src_offset_bytes and contributes n_segments segments of segment_bytes, segment_stride_bytes
+ * apart; device row i holds them back to back.  This is how ExportData pipelines one export() call (reference
+ * export.py:128-167 hands over the whole batch [N, n_comp, T]): the snapshots [t0, t1) of a field are n_comp segments of
+ * (t1 - t0) values, T values apart, so piece j + 1 crosses PCIe while piece j is interpolated and piece j - 1 comes back. */
+int s3_upload_row_pieces(const void *h_src, const int32_t *h_rows /*[n_rows] or NULL*/, int64_t n_rows,
+                         int64_t src_row_stride_bytes, int64_t src_offset_bytes, int n_segments, int64_t segment_bytes,
+                         int64_t segment_stride_bytes, void *d_dst, int64_t dst_pitch_bytes, s3_stream stream);
 
 /* ---- KNN index over the original CFD points -------------------------------------------------------------------
  * Replaces KNeighborsRegressor(...).fit(vertices, target)           s_cube.py:161-163

@@ -26,7 +26,7 @@ class S3HipError(RuntimeError):
 
 _hip = None
 _topo = None
-ABI_VERSION = 3          # S3_ABI_VERSION of include/s3hip.h this file was written against
+ABI_VERSION = 4          # S3_ABI_VERSION of include/s3hip.h this file was written against
 _REBUILD = "python -c 'import __graft_entry__ as g; g.build()'"
 
 c_i64, c_i32, c_int, c_dbl, c_vp = C.c_int64, C.c_int32, C.c_int, C.c_double, C.c_void_p
@@ -45,6 +45,7 @@ HIP_SIGNATURES = {
     "s3_row_moments": (c_int, [c_vp, c_int, c_i64, c_i64, c_i64, c_int, c_vp, c_vp, c_vp]),
     "s3_row_abs_moments": (c_int, [c_vp, c_int, c_i64, c_i64, c_i64, c_int, c_vp, c_vp, c_vp]),
     "s3_upload_rows_indexed": (c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp]),
+    "s3_upload_row_pieces": (c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_i64, c_i64, c_vp, c_i64, c_vp]),
     "s3_upload_rows": (c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp]),
     "s3_stream_synchronize": (c_int, [c_vp]),
     "s3_knn_create": (c_int, [c_vp, c_i64, c_int, c_dbl, c_vp, C.POINTER(c_vp)]),

@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cerrno>
+#include <chrono>
 #include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
@@ -58,6 +59,10 @@ struct Job {
     hsize_t dims[S3H5_MAX_DIMS];
     const void *data;
     size_t bytes;
+    // (optional) the values are on their way into `data` -- a device-to-host copy the producer queued before this job: they
+    // are complete once *ready >= ready_value (written by the producer's stream behind the copy)
+    const volatile int32_t *ready = nullptr;
+    int32_t ready_value = 0;
 };
 
 }  // namespace
@@ -238,6 +243,32 @@ struct s3h5_file {
             }
             int rc = S3H5_OK, n_skipped = 0;
             std::string msg;
+            // the batch's values may still be coming down from the device: wait for the producer's word (a poll every 50 us;
+            // S3H5_READY_TIMEOUT_S, default 600, bounds it -- a device fault upstream must not hang the writer for ever)
+            for (const Job &j : batch) {
+                if (!j.ready) continue;
+                static const double limit_s = [] { const char *e = getenv("S3H5_READY_TIMEOUT_S"); return e ? atof(e) : 600.0; }();
+                const auto t0 = std::chrono::steady_clock::now();
+                while (*j.ready < j.ready_value) {
+                    std::this_thread::sleep_for(std::chrono::microseconds(50));
+                    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit_s) {
+                        rc = S3H5_EIO;
+                        msg = "the values of '" + j.path + "' never arrived in the host buffer (device-to-host copy not completed)";
+                        break;
+                    }
+                }
+                std::atomic_thread_fence(std::memory_order_acquire);
+                if (rc != S3H5_OK) break;
+            }
+            if (rc != S3H5_OK) {
+                std::lock_guard<std::mutex> lk(m);
+                if (async_error == 0) { async_error = rc; async_message = msg; }
+                busy_data = nullptr;
+                busy_bytes = 0;
+                busy_batch.clear();
+                cv_idle.notify_all();
+                continue;
+            }
             std::vector<Segment> segs;
             std::vector<const Job *> raw_jobs;                // datasets that exist in the file but hold no values yet
             {
@@ -402,6 +433,12 @@ int s3h5_write(s3h5_file *f, const char *path, int dtype, int ndim, const int64_
 
 int s3h5_write_snapshots_async(s3h5_file *f, const char *group, const char *const *times, int64_t n_snapshots, const char *name,
                                int dtype, int ndim, const int64_t *dims, const void *h_base, int64_t stride_bytes) {
+    return s3h5_write_snapshots_async_when(f, group, times, n_snapshots, name, dtype, ndim, dims, h_base, stride_bytes, nullptr, 0);
+}
+
+int s3h5_write_snapshots_async_when(s3h5_file *f, const char *group, const char *const *times, int64_t n_snapshots, const char *name,
+                                    int dtype, int ndim, const int64_t *dims, const void *h_base, int64_t stride_bytes,
+                                    const int32_t *h_ready, int32_t ready_value) {
     if (!f || !group || !times || !name || n_snapshots < 0 || ndim < 0 || ndim > S3H5_MAX_DIMS || (ndim > 0 && !dims) || !h_base ||
         mem_type(dtype) < 0) {
         set_error("s3h5_write_snapshots_async: bad arguments");
@@ -419,6 +456,8 @@ int s3h5_write_snapshots_async(s3h5_file *f, const char *group, const char *cons
         bytes *= (size_t)dims[i];
     }
     proto.bytes = bytes;
+    proto.ready = h_ready;
+    proto.ready_value = ready_value;
     if (stride_bytes < (int64_t)bytes) { set_error("s3h5_write_snapshots_async: snapshots overlap"); return S3H5_EINVAL; }
     {
         std::lock_guard<std::mutex> lk(f->m);

@@ -3,6 +3,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <exception>
 #include <mutex>
@@ -25,16 +27,34 @@ void set_error(const char *fmt, ...) {
 // persistent pinned buffers and each chunk goes up asynchronously, so the host-side copies of all threads and the DMA
 // transfers overlap.
 namespace {
-constexpr int UP_THREADS_MAX = 16;
+constexpr int UP_THREADS_MAX = 32;
 constexpr int UP_BUFS = 2;                           // pinned buffers per thread
 constexpr size_t UP_CHUNK_BYTES = (size_t)8 << 20;   // per buffer
 
 struct UploadLane {
     void *pinned[UP_BUFS] = {nullptr, nullptr};
     hipEvent_t ev[UP_BUFS] = {nullptr, nullptr};
+    int next = 0;                                    // buffer the lane's next chunk goes through (rotates ACROSS calls: a small
+                                                     // upload must not wait for the previous small upload's copy)
 };
 std::mutex g_upload_mutex;
 UploadLane g_lanes[UP_THREADS_MAX];
+
+// host threads that pack rows into the pinned lanes (S3_UPLOAD_THREADS overrides; at most UP_THREADS_MAX).  EIGHT: more of
+// them pack faster than the link carries and then fight the link's DMA -- and the download of the previous batch, which
+// runs at the same time -- for the host's memory system.  MI355X host with 128 hardware threads, 2.43 M referenced rows picked
+// out of a pageable tensor, batches back to back (tools/e2e_probe.py): 200 snapshots (800-byte rows) 47 / 46 / 49 / 50 / 56 ms
+// per batch with 6 / 8 / 12 / 16 / 24 threads (32: 67 -- slower than waiting for the download inside the call, 60);
+// 25 snapshots (100-byte rows) 6.3 / 6.5 / 8.1 / 7.7 / 8.6 ms
+int upload_threads() {
+    static const int v = [] {
+        const char *e = getenv("S3_UPLOAD_THREADS");
+        const int hw = (int)std::thread::hardware_concurrency();
+        int n = e ? atoi(e) : std::min(8, std::max(1, hw / 2));
+        return std::max(1, std::min(n, UP_THREADS_MAX));
+    }();
+    return v;
+}
 
 hipError_t upload_lane_init(UploadLane &l) {
     for (int b = 0; b < UP_BUFS; ++b) {
@@ -55,11 +75,18 @@ hipError_t upload_lane_init(UploadLane &l) {
 
 extern "C" {
 
-// h_rows == NULL: rows 0..n_rows-1 of h_src; otherwise the rows listed in h_rows[n_rows] (any order), packed on the device
-static int upload_rows_impl(const void *h_src, const int32_t *h_rows, int64_t n_rows, int64_t row_bytes, void *d_dst,
-                            int64_t dst_pitch_bytes, s3_stream stream) try {
+// h_rows == NULL: rows 0..n_rows-1 of h_src; otherwise the rows listed in h_rows[n_rows] (any order), packed on the device.
+// Source row r starts at h_src + r * src_stride + src_off and contributes n_seg segments of seg_bytes, seg_stride apart
+// (a snapshot piece [t0, t1) of a field [N, n_comp, T]: n_comp segments of (t1 - t0) values, T values apart); the device
+// row holds them back to back.
+static int upload_rows_impl(const void *h_src, const int32_t *h_rows, int64_t n_rows, int64_t src_stride, int64_t src_off,
+                            int n_seg, int64_t seg_bytes, int64_t seg_stride, void *d_dst, int64_t dst_pitch_bytes,
+                            s3_stream stream) try {
     using namespace s3;
-    S3_REQUIRE(n_rows >= 0 && row_bytes >= 0 && dst_pitch_bytes >= row_bytes, "s3_upload_rows: bad shape");
+    const int64_t row_bytes = (int64_t)n_seg * seg_bytes;
+    S3_REQUIRE(n_rows >= 0 && n_seg >= 1 && seg_bytes >= 0 && dst_pitch_bytes >= row_bytes && src_off >= 0 &&
+               (n_seg == 1 || seg_stride >= seg_bytes) && src_stride >= src_off + (n_seg - 1) * seg_stride + seg_bytes,
+               "s3_upload_rows: bad shape");
     if (n_rows == 0 || row_bytes == 0) return S3_OK;
     S3_REQUIRE(h_src && d_dst, "s3_upload_rows: null array");
     S3_REQUIRE((size_t)dst_pitch_bytes <= UP_CHUNK_BYTES, "s3_upload_rows: rows longer than %zu bytes are not staged", UP_CHUNK_BYTES);
@@ -67,25 +94,37 @@ static int upload_rows_impl(const void *h_src, const int32_t *h_rows, int64_t n_
     std::lock_guard<std::mutex> guard(g_upload_mutex);
     int dev = 0;
     S3_HIP_CHECK(hipGetDevice(&dev));
-    const int64_t rows_per_chunk = std::max<int64_t>(1, (int64_t)(UP_CHUNK_BYTES / (size_t)dst_pitch_bytes));
-    const int64_t n_chunks = (n_rows + rows_per_chunk - 1) / rows_per_chunk;
-    const int hw = (int)std::thread::hardware_concurrency();
-    const int n_thr = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)UP_THREADS_MAX, (int64_t)std::max(1, hw / 2), n_chunks}));
+    // chunk = what one thread packs before its transfer is queued.  No transfer can start before somebody's first chunk is
+    // packed (~0.4 ms per MB and thread), so the first round of chunks is small and the rounds double up to 8 MB: the 243 MB of
+    // a 25-snapshot batch used to be thirty 8-MB chunks packed side by side and THEN sent (7.5 ms where the link needs 4.3).
+    // Small chunks throughout are no answer: 1-MB chunks made the 32 threads queue 240 copies on one stream and the runtime's
+    // per-call cost, serialised by the stream's lock, doubled the time.
+    const int n_lanes = upload_threads();
+    std::vector<int64_t> chunk_begin;
+    for (int64_t r = 0, c = 0; r < n_rows; ++c) {
+        const int64_t bytes = std::min<int64_t>((int64_t)UP_CHUNK_BYTES, ((int64_t)512 << 10) << std::min<int64_t>(4, c / n_lanes));
+        chunk_begin.push_back(r);
+        r += std::max<int64_t>(1, bytes / dst_pitch_bytes);
+    }
+    const int64_t n_chunks = (int64_t)chunk_begin.size();
+    chunk_begin.push_back(n_rows);
+    const int n_thr = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)n_lanes, n_chunks));
     for (int t = 0; t < n_thr; ++t) S3_HIP_CHECK(upload_lane_init(g_lanes[t]));
+    const bool whole_rows = n_seg == 1 && src_stride == row_bytes;       // the selection of rows is one dense block per run
 
     std::atomic<int64_t> next{0};
     std::atomic<int> first_error{(int)hipSuccess};
     auto work = [&](int t) {
         if (hipSetDevice(dev) != hipSuccess) { first_error = (int)hipErrorInvalidDevice; return; }
         UploadLane &l = g_lanes[t];
-        int b = 0;
+        int b = l.next;
         while (first_error.load() == (int)hipSuccess) {
             const int64_t c = next.fetch_add(1);
             if (c >= n_chunks) break;
-            const int64_t r0 = c * rows_per_chunk, rows = std::min(rows_per_chunk, n_rows - r0);
+            const int64_t r0 = chunk_begin[c], rows = chunk_begin[c + 1] - r0;
             hipError_t e = hipEventSynchronize(l.ev[b]);             // the buffer's previous transfer has left it
             if (e == hipSuccess) {
-                const char *base = static_cast<const char *>(h_src);
+                const char *base = static_cast<const char *>(h_src) + src_off;
                 char *stage = static_cast<char *>(l.pinned[b]);
                 char *dst = static_cast<char *>(d_dst) + r0 * dst_pitch_bytes;
                 // long rows are packed in the pinned buffer and the 2-D copy converts the pitch (4000-byte rows: 49 GB/s);
@@ -93,13 +132,28 @@ static int upload_rows_impl(const void *h_src, const int32_t *h_rows, int64_t n_
                 // rows: 32 GB/s, 21 GB/s as a 2-D copy); the padding of the chunk's last row is left alone
                 const bool pitched = row_bytes != dst_pitch_bytes && row_bytes < 512;
                 const int64_t step = pitched ? dst_pitch_bytes : row_bytes;
-                if (h_rows) {
-                    for (int64_t r = 0; r < rows; ++r)
-                        std::memcpy(stage + r * step, base + (int64_t)h_rows[r0 + r] * row_bytes, (size_t)row_bytes);
-                } else if (pitched) {
-                    for (int64_t r = 0; r < rows; ++r) std::memcpy(stage + r * step, base + (r0 + r) * row_bytes, (size_t)row_bytes);
-                } else {
+                if (!h_rows && whole_rows && !pitched) {
                     std::memcpy(stage, base + r0 * row_bytes, (size_t)(rows * row_bytes));
+                } else {
+                    // a scattered selection of rows (or a piece of every row) defeats the hardware prefetcher: every row would
+                    // start with a full memory latency.  The lines of the row `ahead` rows further on are requested while this
+                    // one is copied (ahead chosen so that ~4 KiB per thread are on their way)
+                    const int64_t ahead = std::max<int64_t>(2, std::min<int64_t>(32, 4096 / std::max<int64_t>(64, row_bytes)));
+                    auto row_of = [&](int64_t r) { return base + (int64_t)(h_rows ? h_rows[r0 + r] : r0 + r) * src_stride; };
+                    for (int64_t r = 0; r < rows; ++r) {
+                        if (r + ahead < rows) {
+                            const char *nx = row_of(r + ahead);
+                            for (int sgm = 0; sgm < n_seg; ++sgm)
+                                for (int64_t o = 0; o < seg_bytes + 63; o += 64) __builtin_prefetch(nx + sgm * seg_stride + std::min(o, seg_bytes - 1), 0, 0);
+                        }
+                        const char *src = row_of(r);
+                        if (n_seg == 1) {
+                            std::memcpy(stage + r * step, src, (size_t)row_bytes);
+                        } else {
+                            for (int sgm = 0; sgm < n_seg; ++sgm)
+                                std::memcpy(stage + r * step + sgm * seg_bytes, src + sgm * seg_stride, (size_t)seg_bytes);
+                        }
+                    }
                 }
                 if (row_bytes == dst_pitch_bytes)
                     e = hipMemcpyAsync(dst, stage, (size_t)(rows * row_bytes), hipMemcpyHostToDevice, st);
@@ -113,11 +167,23 @@ static int upload_rows_impl(const void *h_src, const int32_t *h_rows, int64_t n_
             if (e != hipSuccess) { first_error = (int)e; break; }
             b = (b + 1) % UP_BUFS;
         }
+        l.next = b;
     };
+    const bool trace = getenv("S3_UPLOAD_TRACE") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
     std::vector<std::thread> workers;
     for (int t = 1; t < n_thr; ++t) workers.emplace_back(work, t);
+    const auto t_spawned = std::chrono::steady_clock::now();
     work(0);
     for (auto &w : workers) w.join();
+    if (trace) {
+        const auto t_end = std::chrono::steady_clock::now();
+        (void)hipStreamSynchronize(st);
+        const auto t_sync = std::chrono::steady_clock::now();
+        auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "[s3_upload] %lld rows x %lld B, %lld chunks, %d threads: spawn %.2f ms, packed+queued %.2f ms, transfers done %.2f ms\n",
+                (long long)n_rows, (long long)row_bytes, (long long)n_chunks, n_thr, ms(t_begin, t_spawned), ms(t_begin, t_end), ms(t_begin, t_sync));
+    }
     S3_HIP_CHECK((hipError_t)first_error.load());
     return S3_OK;
 } catch (const std::exception &e) {          // thread creation
@@ -127,13 +193,20 @@ static int upload_rows_impl(const void *h_src, const int32_t *h_rows, int64_t n_
 
 int s3_upload_rows(const void *h_src, int64_t n_rows, int64_t row_bytes, void *d_dst, int64_t dst_pitch_bytes,
                    s3_stream stream) {
-    return upload_rows_impl(h_src, nullptr, n_rows, row_bytes, d_dst, dst_pitch_bytes, stream);
+    return upload_rows_impl(h_src, nullptr, n_rows, row_bytes, 0, 1, row_bytes, row_bytes, d_dst, dst_pitch_bytes, stream);
 }
 
 int s3_upload_rows_indexed(const void *h_src, const int32_t *h_rows, int64_t n_sel, int64_t row_bytes, void *d_dst,
                            int64_t dst_pitch_bytes, s3_stream stream) {
     S3_REQUIRE(n_sel == 0 || h_rows != nullptr, "s3_upload_rows_indexed: null row list");
-    return upload_rows_impl(h_src, h_rows, n_sel, row_bytes, d_dst, dst_pitch_bytes, stream);
+    return upload_rows_impl(h_src, h_rows, n_sel, row_bytes, 0, 1, row_bytes, row_bytes, d_dst, dst_pitch_bytes, stream);
+}
+
+int s3_upload_row_pieces(const void *h_src, const int32_t *h_rows, int64_t n_rows, int64_t src_row_stride_bytes,
+                         int64_t src_offset_bytes, int n_segments, int64_t segment_bytes, int64_t segment_stride_bytes,
+                         void *d_dst, int64_t dst_pitch_bytes, s3_stream stream) {
+    return upload_rows_impl(h_src, h_rows, n_rows, src_row_stride_bytes, src_offset_bytes, n_segments, segment_bytes,
+                            segment_stride_bytes, d_dst, dst_pitch_bytes, stream);
 }
 
 // Device -> pageable host memory through the same pinned lanes: every thread brings 8 MiB chunks down into its pinned
@@ -154,8 +227,7 @@ int s3_download(void *h_dst, const void *d_src, size_t bytes, s3_stream stream) 
     S3_HIP_CHECK(hipGetDevice(&dev));
     S3_HIP_CHECK(hipStreamSynchronize(st));                              // the source is complete; lanes use their own order
     const int64_t n_chunks = (int64_t)((bytes + UP_CHUNK_BYTES - 1) / UP_CHUNK_BYTES);
-    const int hw = (int)std::thread::hardware_concurrency();
-    const int n_thr = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)8, (int64_t)std::max(1, hw / 2), n_chunks / 2}));
+    const int n_thr = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)8, (int64_t)upload_threads(), n_chunks / 2}));
     for (int t = 0; t < n_thr; ++t) S3_HIP_CHECK(upload_lane_init(g_lanes[t]));
     std::atomic<int64_t> next{0};
     std::atomic<int> first_error{(int)hipSuccess};

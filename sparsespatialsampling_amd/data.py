@@ -186,10 +186,12 @@ class Datawriter:
                 raise ValueError(f"Unable to create dataset {path!r}: it exists already.")
             logger.warning(place.duplicate_message.format(name=name, t=time_step))
 
-    def write_snapshots(self, name: str, times: list, host_snapshot_major) -> None:
+    def write_snapshots(self, name: str, times: list, host_snapshot_major, ready=None) -> None:
         """``data/<times[i]>/<name>`` = ``host_snapshot_major[i]`` for a whole batch, queued and written in the background
-        (this build's addition: ExportData hands over its snapshot-major download buffer)"""
-        self._file.write_snapshots([str(t) for t in times], name, host_snapshot_major, group=DATA)
+        (this build's addition: ExportData hands over its snapshot-major download buffer).
+        ``ready = (int32 host tensor, value)``: the buffer is still being filled by a device-to-host copy, complete once the
+        tensor's first element reaches ``value``."""
+        self._file.write_snapshots([str(t) for t in times], name, host_snapshot_major, group=DATA, ready=ready)
 
     def wait_buffer(self, host) -> None:
         """returns once no queued write reads from ``host`` any more (a closed file has nothing queued)"""

@@ -4,9 +4,10 @@ bodies cut out of it (``keep_inside=False``: everything inside is discarded).
 
 API mirror of the reference's ``geometry/geometry_base.py`` (``GeometryObject``: verdict policy ``_apply_mask`` at
 reference lines 40-76, common argument checks 78-107, abstract interface 109-222).  On the hot path the per-cell
-predicate runs on the GPU: every in-scope geometry describes itself through ``kernel_spec()`` and the refine loop hands
+predicate runs on the GPU: every built-in geometry describes itself through ``kernel_spec()`` and the refine loop hands
 that description to the matching ``s3_mask_*`` kernel (include/s3hip.h).  ``check_cell`` is the host-side, single-cell
-entry point with the reference's signature and truth table.
+entry point with the reference's signature and truth table; a geometry without a ``kernel_spec`` is evaluated through it.
+Constructor arguments are validated from each class's declarative ``_argument_rules()``.
 """
 import logging
 from abc import ABC, abstractmethod
@@ -61,15 +62,26 @@ class GeometryObject(ABC):
     def check_cell(self, cell_nodes: Tensor, refine_geometry: bool = False) -> bool:
         """verdict for one cell given its ``[2^d, d]`` node coordinates"""
 
-    @abstractmethod
-    def kernel_spec(self) -> tuple:
+    def kernel_spec(self):
         """``(kind, params...)`` consumed by the device mask kernels: ``("box", lo, hi)``, ``("sphere", pos, r)``,
         ``("cylinder", p0, axis, norm, r0, r1, is_cone)``, ``("polygon", xy[nv,2])``, ``("triangle", xy[3,2])``,
-        ``("prism", origin, axis, norm, dims, xy[3,2])`` or ``("tetrahedra", pos[n,4,3], normals[n,3,4])``"""
+        ``("prism", origin, axis, norm, dims, xy[3,2])`` or ``("tetrahedra", pos[n,4,3], normals[n,3,4])``.
 
-    @abstractmethod
+        ``None`` (the default): this geometry has no device predicate.  The refine loop then downloads the node coordinates
+        of the cells in question and asks ``check_cell`` cell by cell -- any user-defined geometry with the reference's
+        interface (s_cube.py:1816-1837 only ever calls ``check_cell(nodes, refine_geometry)``) keeps working, slowly."""
+        return None
+
+    # -- argument checks -------------------------------------------------------------------------------------------
+    def _argument_rules(self) -> tuple:
+        """the constructor-argument rules of the concrete geometry, declaratively: ``(holds, complaint)`` pairs, both
+        callables without arguments (so that a later rule may rely on the earlier ones), checked in order"""
+        return ()
+
     def _check_geometry(self) -> None:
-        """validate the constructor arguments of the concrete geometry"""
+        """raise ``AssertionError`` (the reference's error type for bad geometry arguments) at the first rule that fails"""
+        for holds, complaint in self._argument_rules():
+            assert holds(), f"Geometry '{self._name}': {complaint()}"
 
     @property
     @abstractmethod

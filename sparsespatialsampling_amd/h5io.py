@@ -30,6 +30,8 @@ H5_SIGNATURES = {
     "s3h5_write": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "s3h5_write_snapshots_async": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_char_p, C.c_int, C.c_int,
                                              C.c_void_p, C.c_void_p, C.c_int64]),
+    "s3h5_write_snapshots_async_when": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_char_p, C.c_int, C.c_int,
+                                                  C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32]),
     "s3h5_flush": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "s3h5_wait_buffer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "s3h5_exists": (C.c_int, [C.c_void_p, C.c_char_p]),
@@ -121,10 +123,11 @@ class NativeH5File:
         self._check(rc, f"write {path!r}")
         return True
 
-    def write_snapshots(self, times, name, host, group="data"):
+    def write_snapshots(self, times, name, host, group="data", ready=None):
         """``data/<times[i]>/<name>`` = ``host[i]`` for every i, queued and written in the background.  ``host`` is a
         contiguous snapshot-major array / CPU tensor ``[T, ...]``; it must not be modified before ``flush()`` or
-        ``wait_buffer(host)``."""
+        ``wait_buffer(host)``.  ``ready = (flag, value)``: the values are still being copied into ``host``; they are complete
+        once the int32 host tensor ``flag[0] >= value`` (the producer writes it behind the copy) -- the writer waits for that."""
         t = host if hasattr(host, "data_ptr") else None
         a = host.numpy() if t is not None else np.ascontiguousarray(host)
         if not a.flags.c_contiguous or a.dtype not in _CODES or a.shape[0] != len(times):
@@ -132,10 +135,14 @@ class NativeH5File:
         names = (C.c_char_p * len(times))(*[str(s).encode() for s in times])
         dims = (C.c_int64 * max(a.ndim - 1, 1))(*a.shape[1:])
         stride = a.strides[0] if len(times) else 0
-        self._check(self._lib.s3h5_write_snapshots_async(self._h, group.encode(), names, len(times), name.encode(), _CODES[a.dtype],
-                                                         a.ndim - 1, dims, a.ctypes.data_as(C.c_void_p), stride),
+        flag, value = (C.c_void_p(ready[0].data_ptr()), int(ready[1])) if ready is not None else (None, 0)
+        self._check(self._lib.s3h5_write_snapshots_async_when(self._h, group.encode(), names, len(times), name.encode(),
+                                                              _CODES[a.dtype], a.ndim - 1, dims, a.ctypes.data_as(C.c_void_p),
+                                                              stride, flag, value),
                     f"queue {group}/*/{name}")
         self._keep.append(host)
+        if ready is not None:
+            self._keep.append(ready[0])
 
     def flush(self):
         """wait for the queued writes; returns how many datasets were skipped because they existed"""
@@ -200,7 +207,11 @@ class H5pyFile:
         self._f.create_dataset(path, data=_as_numpy(data))
         return True
 
-    def write_snapshots(self, times, name, host, group="data"):
+    def write_snapshots(self, times, name, host, group="data", ready=None):
+        if ready is not None:                       # (synchronous backend: wait for the producer's word here)
+            import time
+            while int(ready[0][0]) < int(ready[1]):
+                time.sleep(50e-6)
         a = host.numpy() if hasattr(host, "data_ptr") else np.asarray(host)
         self._skipped = getattr(self, "_skipped", 0)
         for i, t in enumerate(times):

@@ -173,10 +173,18 @@ def interp(w, idx, data, out=None):
     return out
 
 
-def snapshot_major(values, n_comp, n_snapshots):
+# ExportData queues its device-to-host copies on a stream of their own and lets them complete behind its back (the host-logic
+# tests replace this module by CPU stand-ins that do not have the attribute: there every copy is immediate)
+ASYNC_TRANSFERS = True
+
+
+def snapshot_major(values, n_comp, n_snapshots, out=None):
     """device [nc, n_comp*T] (or [nc, n_comp, T]) f64 -> device [T, nc, n_comp]: contiguous snapshots for the HDF5 sink"""
     nc = int(values.shape[0])
-    out = pt.empty((int(n_snapshots), nc, int(n_comp)), dtype=pt.float64, device=values.device)
+    if out is None:
+        out = pt.empty((int(n_snapshots), nc, int(n_comp)), dtype=pt.float64, device=values.device)
+    elif not (out.is_cuda and out.is_contiguous() and out.dtype == pt.float64 and out.numel() == values.numel()):
+        raise TypeError("snapshot_major: contiguous float64 device tensor of the batch's size required as out")
     check(_lib.hip_lib().s3_snapshot_major(_ptr(values), nc, int(n_comp), int(n_snapshots), _ptr(out), _stream()),
           "s3_snapshot_major")
     return out
@@ -362,6 +370,29 @@ def upload_rows_indexed(host, row_ids, rows):
     check(_lib.hip_lib().s3_upload_rows_indexed(C.c_void_p(host.data_ptr()), ids.ctypes.data_as(C.c_void_p), len(ids),
                                                 int(host.shape[1]) * item, C.c_void_p(rows.data_ptr()),
                                                 int(rows.stride(0)) * item, _stream()), "s3_upload_rows_indexed")
+    return rows
+
+
+def upload_row_pieces(host, row_ids, t0, t1, rows):
+    """snapshots ``[t0, t1)`` of the rows ``row_ids`` (int32 numpy array, or None: all rows) of the contiguous host field
+    ``host`` [N, n_comp, T] -> device rows ``rows`` [n_sel, n_comp * (t1 - t0)] (unit inner stride; the bytes between two rows
+    may be overwritten) through the native staged upload (s3_upload_row_pieces); asynchronous on the current stream"""
+    if host.is_cuda or not host.is_contiguous() or host.dim() != 3 or host.dtype != rows.dtype:
+        raise TypeError("upload_row_pieces: contiguous host tensor [N, n_comp, T] of the rows' dtype required")
+    n, n_comp, t = (int(v) for v in host.shape)
+    if not 0 <= t0 < t1 <= t:
+        raise ValueError(f"upload_row_pieces: snapshots [{t0}, {t1}) of {t}")
+    ids = None if row_ids is None else np.ascontiguousarray(row_ids, dtype=np.int32)
+    n_sel = n if ids is None else len(ids)
+    if not rows.is_cuda or rows.dim() != 2 or rows.stride(1) != 1 or tuple(rows.shape) != (n_sel, n_comp * (t1 - t0)):
+        raise TypeError("upload_row_pieces: device rows [n_sel, n_comp * (t1 - t0)] with unit inner stride required")
+    if ids is not None and len(ids) and (int(ids.min()) < 0 or int(ids.max()) >= n):
+        raise IndexError("upload_row_pieces: row id outside the host tensor")
+    item = host.element_size()
+    check(_lib.hip_lib().s3_upload_row_pieces(C.c_void_p(host.data_ptr()), None if ids is None else ids.ctypes.data_as(C.c_void_p),
+                                              n_sel, n_comp * t * item, t0 * item, n_comp, (t1 - t0) * item, t * item,
+                                              C.c_void_p(rows.data_ptr()), int(rows.stride(0)) * item, _stream()),
+          "s3_upload_row_pieces")
     return rows
 
 

@@ -21,6 +21,18 @@ def _level_factor_table(width, n_dims, n_levels=64):
     return np.array([1 / (2 ** n_dims) * ((width / (2 ** lv)) ** n_dims) for lv in range(n_levels)], dtype=np.float64)
 
 
+def host_mask(geometry, center, level, width, refine_mode):
+    """verdicts of ``geometry.check_cell`` for the cells with the given centres ``[n, d]`` / levels ``[n]`` (CPU tensors)
+    -> uint8 [n]: the path of a geometry without a device predicate.  The node coordinates are the reference's
+    ``centre + direction * 0.5 * width / 2^level`` (s_cube.py:441, factor 0.5; all scalings exact), ``[2^d, d]`` per cell."""
+    from .s_cube import _directions
+    n, dim = int(center.shape[0]), int(center.shape[1])
+    dirs = pt.from_numpy(np.asarray(_directions(dim), dtype=np.float64))                     # [2^d, d]
+    half = (0.5 * float(width)) / (2.0 ** level.double())                                     # [n]
+    nodes = center.double()[:, None, :] + dirs[None, :, :] * half[:, None, None]             # [n, 2^d, d]
+    return np.fromiter((bool(geometry.check_cell(nodes[i], bool(refine_mode))) for i in range(n)), dtype=np.uint8, count=n)
+
+
 class HipTreeBackend:
     name = "hip"
 
@@ -118,9 +130,14 @@ class HipTreeBackend:
         invalid = pt.zeros(max(n, 1), dtype=pt.uint8, device=self.dev)
         w = float(self.width)
         for g in geometries:
-            spec = g.kernel_spec()
+            spec = g.kernel_spec() if hasattr(g, "kernel_spec") else None
             ki = int(g.keep_inside)
-            if spec[0] == "box":
+            if spec is None:
+                # no device predicate (a user-defined geometry): the reference's own protocol, check_cell(nodes, refine_geometry)
+                # per cell (s_cube.py:1816-1837), on the downloaded node coordinates
+                flags = self._mask_on_host(g, bool(refine_mode), d_cells, first, n)
+                invalid[:n] |= hipops.to_device(flags)
+            elif spec[0] == "box":
                 hipops.mask_box(self.center, self.level, d_cells, first, n, w, spec[1], spec[2], refine_mode, ki, invalid)
             elif spec[0] == "sphere":
                 hipops.mask_sphere(self.center, self.level, d_cells, first, n, w, spec[1], spec[2], refine_mode, ki,
@@ -144,6 +161,13 @@ class HipTreeBackend:
                 raise NotImplementedError(f"geometry kind {spec[0]!r} has no device kernel")
         self._last_invalid = invalid
         return invalid[:n].cpu().numpy().astype(bool)
+
+    def _mask_on_host(self, geometry, refine_mode, d_cells, first, n):
+        if d_cells is not None:
+            center, level = self.center[d_cells.long()].cpu(), self.level[d_cells.long()].cpu()
+        else:
+            center, level = self.center[first:first + n].cpu(), self.level[first:first + n].cpu()
+        return host_mask(geometry, center, level, self.width, refine_mode)
 
     def commit(self, first, n_new, use_invalid):
         """leaf/gain bookkeeping of the batch created by the last ``refine_batch`` (s_cube.py:250-251, 721-723)."""

@@ -77,8 +77,13 @@ class OracleTreeBackend:
         c, lv = self.center[ids], self.level[ids]
         inv = np.zeros(len(ids), dtype=bool)
         for g in geometries:
-            spec, ki = g.kernel_spec(), g.keep_inside
-            if spec[0] == "box":
+            spec, ki = (g.kernel_spec() if hasattr(g, "kernel_spec") else None), g.keep_inside
+            if spec is None:                  # no kernel description: the geometry's own check_cell, cell by cell
+                import torch as pt
+                from sparsespatialsampling_amd.tree_backend import host_mask
+                inv |= host_mask(g, pt.from_numpy(np.ascontiguousarray(c)), pt.from_numpy(np.ascontiguousarray(lv)), self.width,
+                                 refine_mode).astype(bool)
+            elif spec[0] == "box":
                 inv |= orc.mask_box(c, lv, self.width, spec[1], spec[2], refine_mode, ki)
             elif spec[0] == "sphere":
                 inv |= orc.mask_sphere(c, lv, self.width, spec[1], spec[2], refine_mode, ki)

@@ -272,6 +272,43 @@ def test_export_fit_paths_gpu(tmp_path, t, ncomp, on_gpu, n, nc):
         assert ex._used_rows.numel() == len(np.unique(np.concatenate([idx_c.ravel(), idx_v.ravel()])))
 
 
+@pytest.mark.parametrize("t,ncomp,on_gpu,n,chunk", [(200, 1, False, 120000, 100), (130, 3, False, 120000, 60), (96, 1, True, 120000, 100),
+                                                    (257, 1, False, 20000, 100), (64, 2, False, 120000, 30), (101, 1, True, 20000, 100)])
+def test_export_pipeline_pieces_equal_the_single_piece_gpu(tmp_path, t, ncomp, on_gpu, n, chunk, monkeypatch):
+    """one ``export()`` call pipelined over pieces of the snapshot axis (upload of piece j + 1 / kernel of piece j / download
+    of piece j - 1 on three streams, ``chunk_size`` sets the piece length; reference export.py:128-167, 463-467) gives the
+    bits of the one-piece sequence, for host and device-resident batches, scalar and vector fields, centres and vertices,
+    dense and sparse grids, piece lengths that do not divide the batch"""
+    import types
+    from sparsespatialsampling_amd.export import ExportData
+    rng = np.random.default_rng(t + ncomp)
+    nc, nv = 3000, 1500
+    x = rng.random((n, 3))
+    centers, vertices = rng.random((nc, 3)) * 0.3, rng.random((nv, 3)) * 0.3     # n = 120000: a sparse grid (referenced rows only)
+    results = {}
+    for mode in ("1", "0"):
+        # (host batches are cut into pieces on request only: S3_EXPORT_PIPELINE=host; device-resident ones by default)
+        monkeypatch.setenv("S3_EXPORT_PIPELINE", {"1": "1" if on_gpu else "host", "0": "0"}[mode])
+        s = types.SimpleNamespace(n_dimensions=3, faces=None, centers=pt.from_numpy(centers), vertices=pt.from_numpy(vertices),
+                                  levels=None, metric=pt.from_numpy(np.ones(n)), size_initial_cell=1.0,
+                                  save_path=str(tmp_path), save_name="c", grid_name="g")
+        ex = ExportData(s, write_times=[str(i) for i in range(2 * t)], interpolate_at_vertices=True)
+        ex._chunk_size = chunk
+        got = []
+        data_rng = np.random.default_rng(7)
+        for b in range(2):
+            data = pt.from_numpy(data_rng.standard_normal((n, ncomp, t)).astype(np.float32))
+            ex._fit_data(pt.from_numpy(x), data.cuda() if on_gpu else data, "f", 2 * t)
+            got.append((ex._interpolated_fields.centers.clone(), ex._interpolated_fields.vertices.clone()))
+            assert ex._interpolated_fields.centers[:, :, 0].is_contiguous()
+        pieces = ex._snapshot_pieces(data.cuda() if on_gpu else data, ncomp, t)
+        assert (len(pieces) > 1) == (mode == "1" and not (on_gpu and ncomp != 1)), pieces
+        assert pieces[0][0] == 0 and pieces[-1][1] == t and all(a[1] == b[0] for a, b in zip(pieces, pieces[1:]))
+        results[mode] = got
+    for (c1, v1), (c0, v0) in zip(results["1"], results["0"]):
+        assert pt.equal(c1, c0) and pt.equal(v1, v0)
+
+
 def test_c1_cylinder2d_full_size_matches_reference():
     """BASELINE config C1 at full size (14 350 points, 87 adaptive iterations, body refined to level 9): grid, faces and
     iteration histories against the real reference (18 s there, tests/golden/gen_golden.py c1)"""
@@ -501,3 +538,10 @@ def test_refine_random_configurations_gpu(seed):
     HIP path against the real reference's grid"""
     from tests.test_tree_host_logic import check_random_case
     check_random_case(seed)
+
+
+@pytest.mark.parametrize("name", ["refine_2d_metric", "refine_3d_metric"])
+def test_geometry_without_kernel_spec_takes_the_host_path_gpu(name):
+    """a user-defined geometry (only ``check_cell``, reference s_cube.py:1816-1837) on the HIP backend"""
+    from tests.test_tree_host_logic import check_geometry_fallback
+    check_geometry_fallback(name)

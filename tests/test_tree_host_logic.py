@@ -161,3 +161,55 @@ def test_close_twice_is_harmless(oracle_backend):
     tree.close()
     tree.close()
     assert pt.equal(tree.all_centers, centers)                # the results stay valid
+
+
+class DuckGeometry:
+    """a user-defined geometry with the reference's interface only (s_cube.py:1816-1837 calls nothing but ``check_cell``):
+    no ``kernel_spec``, every verdict comes from the wrapped object's host predicate"""
+
+    def __init__(self, inner):
+        self._inner = inner
+
+    def check_cell(self, cell_nodes, refine_geometry=False):
+        return self._inner.check_cell(cell_nodes, refine_geometry)
+
+    def __getattr__(self, item):
+        if item == "kernel_spec":
+            raise AttributeError(item)
+        return getattr(self._inner, item)
+
+
+def check_geometry_fallback(name="refine_2d_metric"):
+    """bodies WITHOUT a device predicate take the host path (check_cell on the cells' node coordinates) and give the
+    reference's grid all the same"""
+    z = load(name)
+    x, y, geos, kw = refine_inputs(name, geometry)
+    geos = [g if g.keep_inside else DuckGeometry(g) for g in geos]
+    assert any(isinstance(g, DuckGeometry) for g in geos)
+    tree = s_cube.SamplingTree(pt.from_numpy(x), pt.from_numpy(y), geometry_obj=geos, **kw)
+    tree.refine()
+    check_tree_against_golden(tree, z)
+    check_outputs_against_golden(tree, z)
+
+
+@pytest.mark.parametrize("name", ["refine_2d_metric", "refine_3d_metric"])
+def test_geometry_without_kernel_spec_takes_the_host_path(oracle_backend, name):
+    check_geometry_fallback(name)
+
+
+def test_base_class_kernel_spec_defaults_to_none():
+    class Slab(geometry.GeometryObject):
+        type, main_width, center = "slab", 1.0, pt.zeros(2)
+
+        def check_cell(self, cell_nodes, refine_geometry=False):
+            return self._apply_mask(cell_nodes[:, 0] <= 0.5, refine_geometry)
+
+        def _compute_main_width(self):
+            return 1.0
+
+        def _compute_center(self):
+            return pt.zeros(2)
+
+    g = Slab("slab", False)
+    assert g.kernel_spec() is None
+    assert g.check_cell(pt.tensor([[0.1, 0.0], [0.2, 0.0], [0.3, 1.0], [0.4, 1.0]])) is True

@@ -182,6 +182,37 @@ def code_sha():
     return h.hexdigest()[:16]
 
 
+def export_sharded(x, centers, k, comm, t=200, reps=3):
+    """N > 1: what ExportData.export does with N ranks (SPMD), next to the bare step: every rank holds the dense device batch
+    [N_points, 1, t] fp32, interpolates its shard of the cells from it and writes its rows -- transposed to snapshot-major --
+    through its own PCIe link into the batch buffer all ranks map; timed up to the point where rank 0 could hand the buffer
+    to the HDF5 writer (barrier-bracketed, max over ranks).  No value crosses xGMI."""
+    from sparsespatialsampling_amd.export import ExportData
+    s = types.SimpleNamespace(n_dimensions=3, faces=None, centers=pt.from_numpy(centers), vertices=None, levels=None,
+                              metric=pt.zeros(len(x), dtype=pt.float64), size_initial_cell=1.0, save_path=".", save_name="bench",
+                              grid_name="g")
+    ex = ExportData(s, write_times=[str(i) for i in range(100000)], n_neighbors=k)
+    coords = pt.from_numpy(x)
+    data = pt.empty((len(x), 1, t), dtype=pt.float32, device="cuda").normal_(generator=pt.Generator(device="cuda").manual_seed(99))
+    for _ in range(2):                                       # cache, plans, both shared buffers
+        ex._fit_data(coords, data, "f", 10 ** 9)
+    pt.cuda.synchronize()
+    comm.barrier()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ex._fit_data(coords, data, "f", 10 ** 9)
+    pt.cuda.synchronize()
+    comm.barrier()
+    dt = comm.allreduce_max(time.perf_counter() - t0) / reps
+    table = ex._table_centers
+    return dict(t_batch=t, ms_per_batch=dt * 1e3, Gcells_snapshots_per_s=len(centers) * t / dt / 1e9,
+                cells_on_this_rank=int(len(table.shard.mine)), rows_uploaded_by_this_rank=0, xgmi_bytes_per_batch=0,
+                host_bytes_written_by_this_rank=int(len(table.shard.mine)) * t * 8,
+                direct_device_writes=bool(ex._shared and all(b.device_ptr is not None for b in ex._shared.values())),
+                note="dense device batch in -> the ranks' rows in ONE shared host buffer (snapshot-major, file order), "
+                     "ready for the writer of rank 0; each rank over its own PCIe link")
+
+
 def recorded_traffic(workload_key):
     """HBM bytes per launch of the dominant kernel as RECORDED in the committed PMC passes (profiles/rNN/summary.json:
     FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE from separate rocprofv3 --pmc runs of this
@@ -557,6 +588,14 @@ def main():
         del rows_p
         step()                                       # `out` holds the headline's result again
 
+    # N > 1: the product's export path with N ranks (every rank takes part; after the timed region of the headline)
+    sharded_leg = None
+    if world > 1 and args.shard == "cells" and plan is not None and not cfg.get("kind") == "box":
+        del data
+        pt.cuda.empty_cache()
+        sharded_leg = export_sharded(x, centers, k, comm)
+        data = None
+
     copy_bw = copy_bandwidth_gbs() if rank == 0 else None
     if rank == 0:
         units = (nc * world if args.shard == "snapshots" else nc_total) * t_b * args.steps
@@ -600,6 +639,8 @@ def main():
             pitched["frac"] = b_alg / (pitched["kernel_ms"] * 1e-3) / 8e12
             pitched["in_place_over_pitched"] = kernel_ms / pitched["kernel_ms"]
             res["roofline"]["pitched_copy"] = pitched
+        if sharded_leg is not None:
+            res["export_sharded"] = sharded_leg
         if world == 1 and plan is not None and not args.no_batches:
             # the batch lengths the reference exports with (examples/s3_for_cylinder3D_Re3900.py:28-69, utils.py:204-226)
             key = args.workload

@@ -58,6 +58,10 @@ int s3_stream_synchronize(s3_stream stream);
 /* device -> pageable host array through persistent pinned buffers drained by several host threads (a plain copy into
  * pageable memory runs at 12-15 GB/s); returns when h_dst is complete */
 int s3_download(void *h_dst, const void *d_src, size_t bytes, s3_stream stream);
+/* page-lock host memory that was not allocated through HIP (a POSIX shared-memory mapping shared by the ranks of a node) and
+ * map it into the device's address space: *d_ptr is what kernels write through.  Undo with s3_host_unregister. */
+int s3_host_register(void *h_ptr, size_t bytes, void **d_ptr);
+int s3_host_unregister(void *h_ptr);
 /* upload target of a snapshot batch (the .to(device) of a host tensor handed to ExportData.export, export.py:128-167):
  * pageable host rows [n_rows][row_bytes] -> device rows with pitch dst_pitch_bytes, staged through persistent pinned
  * buffers filled by several host threads; asynchronous on `stream` (the host data may be reused on return).  The
@@ -200,6 +204,11 @@ int s3_interp(const double *d_w /*[nc,k]*/, const int32_t *d_idx /*[nc,k]*/, int
 /* a19 hand-over: [nc][n_comp][T] -> [T][nc][n_comp], the snapshot-major image of an interpolated batch, so that the HDF5
  * sink (one dataset per snapshot, export.py:283-299) gets contiguous snapshots instead of slicing out[:, :, i] on the host. */
 int s3_snapshot_major(const double *d_in, int64_t nc, int n_comp, int64_t n_snapshots, double *d_out, s3_stream stream);
+/* the same for a SHARD of the cells (several ranks): input cell c becomes row d_rows[c] of an output with n_out
+ * rows, [T][n_out][n_comp] -- every rank writes its rows of the one batch buffer the ranks share (host memory registered with
+ * s3_host_register: the values cross this rank's own PCIe link, nothing is sent to the rank that writes the file). */
+int s3_snapshot_major_rows(const double *d_in, int64_t nc, int n_comp, int64_t n_snapshots, const int32_t *d_rows /*[nc]*/,
+                           int64_t n_out, double *d_out, s3_stream stream);
 
 /* Metric upstream of S^3 (what the reference's example scripts compute with torch before the grid is generated:
  * metric = pt.std(field, dim=1), examples/s3_for_OAT15_airfoil.py:91): temporal mean and standard deviation of every row

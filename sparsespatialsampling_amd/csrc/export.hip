@@ -126,11 +126,13 @@ interp_kernel(const double *__restrict__ w, const int32_t *__restrict__ idx, int
     }
 }
 
-// [nc][n_comp][T] -> [T][nc][n_comp]: snapshot-major image of an interpolated batch for the HDF5 sink, which writes one
+// [nc][n_comp][T] -> [T][n_out][n_comp]: snapshot-major image of an interpolated batch for the HDF5 sink, which writes one
 // dataset per snapshot (reference export.py:283-299 slices out[:, :, i] on the host).  32x32 tiles through LDS: reads run
-// along t, writes along the cell axis.
+// along t, writes along the cell axis.  `rows` (optional): input cell c is row rows[c] of the output (a rank's shard of the
+// cells -- ascending ids, mostly runs of siblings -- written into the batch buffer all ranks share); NULL: row c, n_out = nc.
 __global__ void __launch_bounds__(256)
-snapshot_major_kernel(const double *__restrict__ in, int64_t nc, int n_comp, int64_t T, double *__restrict__ out) {
+snapshot_major_kernel(const double *__restrict__ in, int64_t nc, int n_comp, int64_t T, const int32_t *__restrict__ rows,
+                      int64_t n_out, double *__restrict__ out) {
     __shared__ double tile[32][33];
     const int j = blockIdx.z;
     const int64_t c0 = (int64_t)blockIdx.x * 32, t0 = (int64_t)blockIdx.y * 32;   // cells on x: up to 2^31 tiles
@@ -140,9 +142,11 @@ snapshot_major_kernel(const double *__restrict__ in, int64_t nc, int n_comp, int
         if (c < nc && t < T) tile[r][tx] = in[(c * n_comp + j) * T + t];
     }
     __syncthreads();
+    const int64_t c = c0 + tx;
+    const int64_t row = c < nc ? (rows ? (int64_t)rows[c] : c) : 0;
     for (int r = ty; r < 32; r += 8) {
-        const int64_t t = t0 + r, c = c0 + tx;
-        if (c < nc && t < T) out[(t * nc + c) * n_comp + j] = tile[tx][r];
+        const int64_t t = t0 + r;
+        if (c < nc && t < T) out[(t * n_out + row) * n_comp + j] = tile[tx][r];
     }
 }
 
@@ -199,16 +203,22 @@ int s3_interp(const double *d_w, const int32_t *d_idx, int64_t nc, int k, const 
     return launch_interp<double, 1>(d_w, d_idx, nc, k, d_data, row_len, d_out, st);
 }
 
-int s3_snapshot_major(const double *d_in, int64_t nc, int n_comp, int64_t n_snapshots, double *d_out, s3_stream stream) {
-    S3_REQUIRE(nc >= 0 && n_comp >= 1 && n_snapshots >= 0, "s3_snapshot_major: bad shape");
+int s3_snapshot_major_rows(const double *d_in, int64_t nc, int n_comp, int64_t n_snapshots, const int32_t *d_rows,
+                           int64_t n_out, double *d_out, s3_stream stream) {
+    S3_REQUIRE(nc >= 0 && n_comp >= 1 && n_snapshots >= 0 && n_out >= nc, "s3_snapshot_major: bad shape");
     if (nc == 0 || n_snapshots == 0) return S3_OK;
     S3_REQUIRE(d_in && d_out && d_in != d_out, "s3_snapshot_major: null or aliased array");
+    S3_REQUIRE(d_rows != nullptr || n_out == nc, "s3_snapshot_major: without a row list the output has the input's rows");
     const int64_t gx = (nc + 31) / 32, gy = (n_snapshots + 31) / 32;
     S3_REQUIRE(gx < ((int64_t)1 << 31) && gy <= 65535 && n_comp <= 65535, "s3_snapshot_major: shape too large for one launch");
     snapshot_major_kernel<<<dim3((unsigned)gx, (unsigned)gy, (unsigned)n_comp), 256, 0, as_stream(stream)>>>(
-        d_in, nc, n_comp, n_snapshots, d_out);
+        d_in, nc, n_comp, n_snapshots, d_rows, n_out, d_out);
     S3_LAUNCH_CHECK();
     return S3_OK;
+}
+
+int s3_snapshot_major(const double *d_in, int64_t nc, int n_comp, int64_t n_snapshots, double *d_out, s3_stream stream) {
+    return s3_snapshot_major_rows(d_in, nc, n_comp, n_snapshots, nullptr, nc, d_out, stream);
 }
 
 }  // extern "C"

@@ -313,6 +313,31 @@ int s3_free(void *d_ptr) {
     return S3_OK;
 }
 
+// Host memory that several processes share (a POSIX shared-memory mapping: the sharded export's snapshot-major batch buffer)
+// made visible to this process's device, so that kernels can write their results straight into it over this GPU's own PCIe link.
+int s3_host_register(void *h_ptr, size_t bytes, void **d_ptr) {
+    S3_REQUIRE(h_ptr != nullptr && bytes > 0 && d_ptr != nullptr, "s3_host_register: null argument");
+    *d_ptr = nullptr;
+    hipError_t e = hipHostRegister(h_ptr, bytes, hipHostRegisterMapped | hipHostRegisterPortable);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        s3::set_error("hipHostRegister(%zu bytes): %s", bytes, hipGetErrorString(e));
+        return e == hipErrorOutOfMemory ? S3_ENOMEM : S3_EHIP;
+    }
+    e = hipHostGetDevicePointer(d_ptr, h_ptr, 0);
+    if (e != hipSuccess) {
+        (void)hipHostUnregister(h_ptr);
+        s3::set_error("hipHostGetDevicePointer: %s", hipGetErrorString(e));
+        return S3_EHIP;
+    }
+    return S3_OK;
+}
+
+int s3_host_unregister(void *h_ptr) {
+    if (h_ptr) S3_HIP_CHECK(hipHostUnregister(h_ptr));
+    return S3_OK;
+}
+
 int s3_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes, s3_stream stream) {
     S3_HIP_CHECK(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, s3::as_stream(stream)));
     return S3_OK;

@@ -190,6 +190,15 @@ def snapshot_major(values, n_comp, n_snapshots, out=None):
     return out
 
 
+def snapshot_major_rows(values, n_comp, n_snapshots, rows, n_out, out_ptr):
+    """a shard's values, device [n_mine, n_comp*T] f64, -> rows ``rows`` (device int32 [n_mine]) of the snapshot-major batch
+    buffer ``[T, n_out, n_comp]`` at device address ``out_ptr`` (host memory all ranks share, s3_snapshot_major_rows)"""
+    if not (rows.is_cuda and rows.dtype == pt.int32 and rows.is_contiguous() and rows.numel() == values.shape[0]):
+        raise TypeError("snapshot_major_rows: one int32 device row id per input row required")
+    check(_lib.hip_lib().s3_snapshot_major_rows(_ptr(values), int(values.shape[0]), int(n_comp), int(n_snapshots), _ptr(rows),
+                                                int(n_out), C.c_void_p(int(out_ptr)), _stream()), "s3_snapshot_major_rows")
+
+
 class InterpPlan:
     """De-duplicated, LDS-tiled form of a static neighbour table (s3_interp_plan_*): build once per KNN cache, reuse for
     every snapshot batch.  ``centers`` (cell centres, [nc, dim]) gives the Hilbert-curve processing order."""

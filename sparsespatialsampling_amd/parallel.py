@@ -5,8 +5,9 @@ Multi-GPU layer of the S^3 path: one process per GPU, the collectives run inside
 * **interpolation** -- the generated cells are split into spatially compact, cost-balanced shards (``LeafShards``: stretches
   of the cells' Hilbert curve; the cut needs one small all-gather of cost profiles, no rank builds the table of all cells);
   every rank builds the KNN cache / plan of its shard, uploads only the source rows that shard references and computes its
-  own output rows.  The bench step has no collective; ``ExportData``, which ends in ONE file, sends every rank's rows to the
-  rank that writes it (``gather_to_root``: grouped ncclSend / ncclRecv, every byte crosses xGMI once).
+  own output rows.  The bench step has no collective; ``ExportData``, which ends in ONE file, lets every rank write its rows
+  -- transposed to snapshot-major on the way -- into ONE host buffer all ranks of the node map (``SharedHostArray``), each
+  through its own PCIe link; the rank that writes the file hands that buffer to the HDF5 writer.  Nothing crosses xGMI.
 * **refine** -- point cloud, KNN index and cell arrays are replicated; per batch every rank evaluates the KNN metric /
   gain of its 1/W slice of the new cells (``batch_slice``; the reference spreads the same work over a process pool,
   s_cube.py:207-241) and ONE grouped all-gather returns the slices to everybody.  The captured metric
@@ -136,6 +137,10 @@ class SoloComm:
     def barrier(self):
         pass
 
+    def broadcast_bytes(self, data, root=0):
+        """``data`` of rank ``root`` on every rank (host-side plumbing: names of shared-memory segments)"""
+        return data
+
     def close(self):
         pass
 
@@ -185,6 +190,11 @@ class GlooComm(SoloComm):
     def barrier(self):
         self._dist.barrier()
 
+    def broadcast_bytes(self, data, root=0):
+        box = [data if self.rank == root else None]
+        self._dist.broadcast_object_list(box, src=root)
+        return box[0]
+
 
 class RcclComm(SoloComm):
     """communicator inside libs3hip.so (RCCL); device tensors only"""
@@ -212,6 +222,7 @@ class RcclComm(SoloComm):
                 raise RuntimeError(f"rank 0 could not create the RCCL id: {blob[4:].decode(errors='replace')}")
             ident.raw = blob[4:4 + 128]
         self._h = C.c_void_p(0)
+        self._store, self._n_broadcasts = store, 0           # (the rendezvous store stays the host-side channel)
         hipops.device()
         hipops.check(lib.s3_comm_init(ident, 128, self.rank, self.world, C.byref(self._h)), "s3_comm_init")
         self._scalar = pt.zeros(1, dtype=pt.float64, device=hipops.device())
@@ -253,11 +264,76 @@ class RcclComm(SoloComm):
     def barrier(self):
         self._allreduce(0.0, 0)
 
+    def broadcast_bytes(self, data, root=0):
+        """through the rendezvous store the communicator was bootstrapped over (a blocking get on the other ranks)"""
+        key = f"bcast_{self._n_broadcasts}"
+        self._n_broadcasts += 1
+        if self.rank == root:
+            self._store.set(key, bytes(data))
+            return bytes(data)
+        return bytes(self._store.get(key))
+
     def close(self):
         h = getattr(self, "_h", None)
         if h is not None and h.value:
             self._lib.hip_lib().s3_comm_destroy(h)
             self._h = C.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # interpreter shutdown
+            pass
+
+
+class SharedHostArray:
+    """``n_bytes`` of host memory that every rank of the node maps (POSIX shared memory) and that every rank's GPU can write
+    through its own PCIe link (``s3_host_register``): the snapshot-major batch buffer of the sharded export.  Collective:
+    every rank constructs it at the same point of the program.  The root creates ``/dev/shm/<name>``, the others open it by
+    the broadcast name, and once everybody holds a mapping the root unlinks the name -- nothing is left behind whatever
+    happens to the processes later.  ``array``: uint8 numpy view; ``device_ptr``: the mapping as this rank's kernels see it
+    (None where registration is not possible: the caller then copies through a buffer of its own)."""
+    _serial = 0
+
+    def __init__(self, comm, n_bytes, register=True):
+        import mmap
+        self.n_bytes = int(n_bytes)
+        SharedHostArray._serial += 1
+        name = comm.broadcast_bytes(f"s3_{os.getpid()}_{SharedHostArray._serial}".encode() if comm.rank == 0 else None).decode()
+        path = os.path.join("/dev/shm", name)
+        if comm.rank == 0:
+            fd = os.open(path, os.O_CREAT | os.O_EXCL | os.O_RDWR, 0o600)
+            os.ftruncate(fd, max(self.n_bytes, 1))
+        comm.barrier()                                       # the segment exists and has its size
+        try:
+            if comm.rank != 0:
+                fd = os.open(path, os.O_RDWR)
+            self._map = mmap.mmap(fd, max(self.n_bytes, 1))
+            os.close(fd)
+        finally:
+            comm.barrier()                                   # everybody holds a mapping (or has failed loudly)
+            if comm.rank == 0:
+                os.unlink(path)
+        self.array = np.frombuffer(self._map, dtype=np.uint8)
+        self.device_ptr = None
+        if register and self.n_bytes:
+            from . import _lib
+            d_ptr = C.c_void_p(0)
+            if _lib.hip_lib().s3_host_register(C.c_void_p(self.array.ctypes.data), self.n_bytes, C.byref(d_ptr)) == 0:
+                self.device_ptr = d_ptr.value
+
+    def close(self):
+        if getattr(self, "device_ptr", None):
+            from . import _lib
+            _lib.hip_lib().s3_host_unregister(C.c_void_p(self.array.ctypes.data))
+            self.device_ptr = None
+        self.array = None
+        if getattr(self, "_map", None) is not None:
+            try:
+                self._map.close()
+            except BufferError:                              # a tensor view is still alive: the mapping goes with it
+                pass
+            self._map = None
 
     def __del__(self):
         try:
@@ -342,7 +418,7 @@ def get_comm():
         if "gloo" in str(dist.get_backend()):
             return init("gloo")
         # an RCCL process group of the caller: bootstrap over its store
-        _comm = RcclComm(dist.get_rank(), dist.get_world_size(), dist.distributed_c10d._get_default_store())
+        _comm = RcclComm(dist.get_rank(), dist.get_world_size(), dist.PrefixStore("s3_comm", dist.distributed_c10d._get_default_store()))
         return _comm
     return SoloComm()
 

@@ -311,6 +311,29 @@ def test_shift_kernel_reads_rows_off_the_line_grid(ops, orc, row_len, dtype, lay
     plan.close(); plan2.close()
 
 
+@pytest.mark.parametrize("n_mine,n_out,n_comp,t", [(1000, 5000, 1, 37), (333, 400, 3, 8), (64, 64, 2, 33)])
+def test_snapshot_major_rows_into_registered_host_memory(ops, n_mine, n_out, n_comp, t):
+    """s3_snapshot_major_rows: a shard's [n_mine, n_comp, T] values land transposed in ITS rows of a [T, n_out, n_comp] batch
+    buffer -- here ordinary host memory (a numpy array) made visible to the device with s3_host_register, as the ranks of a
+    sharded export do with their shared mapping; rows of other shards are left alone"""
+    import ctypes as C
+    from sparsespatialsampling_amd import _lib
+    rng = np.random.default_rng(n_mine)
+    rows = np.sort(rng.choice(n_out, n_mine, replace=False)).astype(np.int32)
+    vals = pt.from_numpy(rng.standard_normal((n_mine, n_comp * t))).cuda()
+    host = np.full((t, n_out, n_comp), -7.0)
+    d_ptr = C.c_void_p(0)
+    ops.check(_lib.hip_lib().s3_host_register(C.c_void_p(host.ctypes.data), host.nbytes, C.byref(d_ptr)), "s3_host_register")
+    try:
+        ops.snapshot_major_rows(vals, n_comp, t, ops.to_device(rows), n_out, d_ptr.value)
+        ops.synchronize()
+    finally:
+        ops.check(_lib.hip_lib().s3_host_unregister(C.c_void_p(host.ctypes.data)), "s3_host_unregister")
+    want = np.full((t, n_out, n_comp), -7.0)
+    want[:, rows, :] = vals.cpu().numpy().reshape(n_mine, n_comp, t).transpose(2, 0, 1)
+    assert np.array_equal(host, want)
+
+
 def test_plan_weights_are_identified_by_the_tensor_not_its_address(ops):
     """a plan must not mistake a new weights tensor that the allocator placed at a freed tensor's address for the
     one it holds"""

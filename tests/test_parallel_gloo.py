@@ -162,6 +162,52 @@ def test_gather_to_root_and_profiles_gloo(tmp_path, world):
     assert pt.equal(res["prof"], pt.stack([pt.arange(5, dtype=pt.float64) * (r + 1) for r in range(world)]))
 
 
+def _shared_worker(rank, world, port, out):
+    for p in (ROOT,):
+        sys.path.insert(0, p) if p not in sys.path else None
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sparsespatialsampling_amd import parallel
+    comm = parallel.init("gloo")
+    assert comm.broadcast_bytes(b"from the root" if rank == 0 else None) == b"from the root"
+    # the hand-over of a sharded export batch: [T, n, n_comp] snapshot-major, every rank fills the rows of its targets
+    t, n, n_comp = 3, 17, 2
+    if world == 2:
+        mine = np.arange(n)[rank::2]                               # interleaved ids
+    else:
+        mine = [np.array([0, 1, 2, 8, 9]), np.array([], dtype=int), np.array([3, 4, 5, 6, 7] + list(range(10, n)))][rank]
+    names = set(os.listdir("/dev/shm"))
+    for batch in range(2):                                     # a second buffer: new segment, new name
+        shared = parallel.SharedHostArray(comm, t * n * n_comp * 8, register=False)
+        assert shared.device_ptr is None and shared.array.nbytes == t * n * n_comp * 8
+        view = shared.array.view(np.float64).reshape(t, n, n_comp)
+        for i in mine:
+            view[:, i, :] = 1000.0 * batch + 10.0 * i + np.arange(t)[:, None] + 0.5 * np.arange(n_comp)[None, :]
+        comm.barrier()                                          # everybody's rows are in
+        if rank == 0:
+            want = 1000.0 * batch + 10.0 * np.arange(n)[None, :, None] + np.arange(t)[:, None, None] + 0.5 * np.arange(n_comp)[None, None, :]
+            assert np.array_equal(view, want)
+        comm.barrier()
+        del view
+        shared.close()
+    leftover = sorted(set(os.listdir("/dev/shm")) - names)
+    if rank == 0:
+        pt.save(dict(leftover=[f for f in leftover if f.startswith("s3_")]), out)
+    comm.barrier()
+    parallel.shutdown()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_shared_batch_buffer_hand_over_gloo(tmp_path, world):
+    """the hand-over of a sharded export: the ranks map ONE host buffer (POSIX shared memory created by
+    the root, its name broadcast, unlinked as soon as everybody holds a mapping), every rank writes the rows of its cells --
+    interleaved ids, an empty shard -- and the root reads the whole batch in the file's order; no segment is left behind"""
+    out = str(tmp_path / "s.pt")
+    mp.spawn(_shared_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert pt.load(out, weights_only=False)["leftover"] == []
+
+
 def test_leaf_shard_cuts_balance_the_cost():
     """``LeafShards._cut``: equal-cost positions from per-stretch cumulative profiles (host logic, no GPU): a curve whose
     second half costs three times the first is cut at 2/3 of its length for two ranks; degenerate profiles keep every rank

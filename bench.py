@@ -387,7 +387,8 @@ def bench_svd(args, json_fd):
     1000 snapshots f64 resident in HBM, a step = one launch.  MFMA-bound: algorithmic flops N * T * (T + 1) (upper triangle)
     against AMD's datasheet peak for f64 matrix operations (78.6 TFLOP/s; the guide lists none) and against the rate a bare
     loop of the same instruction sustains on this pool (46 TFLOP/s, tools/mfma_f64_peak.hip).  Eigen-solve and mode GEMM of
-    compute_svd are vendor-library calls (rocSOLVER / rocBLAS through torch): timed in `compute_svd_s`, not in `value`."""
+    compute_svd: the eigen-solve of the T x T matrix is a vendor-library call (rocSOLVER through torch), the mode GEMM is
+    s3_centered_gemm on the same matrix cores (`mode_gemm`); the whole call is timed in `compute_svd_s`, not in `value`."""
     from sparsespatialsampling_amd import svd, metrics
     n, t = 461_130, args.t_batch or 1000
     gen = pt.Generator(device="cuda").manual_seed(7)
@@ -409,6 +410,15 @@ def bench_svd(args, json_fd):
     pt.cuda.synchronize()
     svd_s = time.perf_counter() - t1
     achieved = flops / (st["kernel_ms"] * 1e-3) / 1e12
+    # the tall GEMMs of the same SVD on the same matrix cores (s3_centered_gemm): the mode GEMM U = (X - mean) V S^-1 at the rank
+    # compute_svd was asked for (50 columns occupy half of a 128-column tile) and at full width (the shape of a deflation level)
+    gemm = {}
+    for r in (50, 128, t):
+        b = pt.empty((t, r), dtype=pt.float64, device="cuda").normal_(generator=gen)
+        gms = ms_stats(launch_times_ms(lambda: svd.centered_gemm(x, mean, b), max(3, args.steps // 4), 1))
+        tf = 2.0 * n * t * r / (gms["kernel_ms"] * 1e-3) / 1e12
+        gemm[f"r{r}"] = dict(columns=r, algorithmic_flops=2.0 * n * t * r, TFLOPs=tf, frac_of_sustained=tf / 46.0, frac_of_datasheet=tf / 78.6, **gms)
+        del b
     res = {"metric": "TFLOP/s weighted Gram matrix (f64 matrix cores)", "value": flops * args.steps / elapsed / 1e12, "unit": "TFLOP/s",
            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -420,8 +430,10 @@ def bench_svd(args, json_fd):
                         "sustained_instruction_rate": 46.0, "frac_of_sustained": achieved / 46.0,
                         "sustained_source": "bare v_mfma_f64_16x16x4_f64 loop, operands in registers (tools/mfma_f64_peak.hip, DESIGN 5.6)",
                         "kernel": "gram_block_kernel", "algorithmic_flops": flops, "traffic": None, **st},
+           "mode_gemm": dict(kernel="centered_gemm_kernel", shapes=gemm,
+                             note="C[N, r] = (X - mean 1^T) B, X [N, T] f64 as the interpolation left it, B [T, r]; flops 2 N T r"),
            "compute_svd_s": svd_s, "compute_svd_rank": int(len(s_)),
-           "compute_svd_note": "mean + Gram kernel + eigen-solve (rocSOLVER) + mode GEMM (rocBLAS), rank 50, first call of the process"}
+           "compute_svd_note": "mean + Gram kernel + eigen-solve (rocSOLVER, the one library call) + mode GEMM (s3_centered_gemm), rank 50, first call of the process"}
     os.write(json_fd, (json.dumps(res) + "\n").encode())
 
 

@@ -343,6 +343,14 @@ size_t s3_weighted_gram_scratch_bytes(int64_t n_rows, int64_t t);
 int s3_weighted_gram(const double *d_x, int64_t n_rows, int64_t t, int64_t in_stride, const double *d_mean,
                      const double *d_weight, double *d_gram /*[t,t]*/, void *d_scratch, s3_stream stream);
 
+/* the tall GEMMs of the same SVD, on the same matrix cores (rows of L may be pitched: the interpolated matrix as it stands):
+ *   d_e == NULL:  C = (L - lmean 1^T) B                    modes U = (X - mean) V S^-1 (utils.py:302-346 takes U from the SVD),
+ *                                                           coefficients A = (X - mean) V of the directions already found
+ *   d_e != NULL:  C = (E - emean 1^T) - (L - lmean 1^T) B   residual (X - mean) - A V^T of a deflation level, in row chunks
+ * L [m][k] row pitch l_stride, B [k][n] contiguous, E [m][n] row pitch e_stride, C [m][n] contiguous; means may be NULL. */
+int s3_centered_gemm(const double *d_l, int64_t m, int64_t k, int64_t l_stride, const double *d_lmean, const double *d_b,
+                     int64_t n, const double *d_e, int64_t e_stride, const double *d_emean, double *d_c, s3_stream stream);
+
 /* ---- device-resident topology of the sampling tree (a9-a11, a15) ------------------------------------------
  * Neighbour links, shared-node numbering, invalid-cell bookkeeping and the final renumbering of s_cube.py:904-1536,
  * 721-728, 734-772, 1695-1736 on tables that live in HBM.  Every update takes the ORDERED id list the host decided on

@@ -44,6 +44,7 @@ HIP_SIGNATURES = {
     "s3_download": (c_int, [c_vp, c_vp, C.c_size_t, c_vp]),
     "s3_row_moments": (c_int, [c_vp, c_int, c_i64, c_i64, c_i64, c_int, c_vp, c_vp, c_vp]),
     "s3_row_abs_moments": (c_int, [c_vp, c_int, c_i64, c_i64, c_i64, c_int, c_vp, c_vp, c_vp]),
+    "s3_centered_gemm": (c_int, [c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "s3_host_register": (c_int, [c_vp, C.c_size_t, C.POINTER(c_vp)]),
     "s3_host_unregister": (c_int, [c_vp]),
     "s3_snapshot_major_rows": (c_int, [c_vp, c_i64, c_int, c_i64, c_vp, c_i64, c_vp, c_vp]),

@@ -11,8 +11,8 @@ How it runs on the MI355X (method of snapshots; the snapshot count T is small ag
    (``v_mfma_f64_16x16x4_f64``, csrc/svd.hip); centring and weighting are fused into the operand staging, the data matrix
    is read as the interpolation kernel left it (f64, HBM resident);
 3. ``G = V diag(s^2) V^T`` -- symmetric eigenproblem of a T x T matrix: the vendor's dense solver (library call);
-4. modes ``U = (X - mean) V diag(1/s)`` -- one plain library GEMM (rocBLAS through torch) plus a rank-one correction for
-   the mean; the weights cancel: ``(sqrt(a) (X - mean) V / s) / sqrt(a)``.
+4. modes ``U = (X - mean) V diag(1/s)`` -- ``s3_centered_gemm`` on the same matrix cores, the centring fused into the operand
+   staging; the weights cancel: ``(sqrt(a) (X - mean) V / s) / sqrt(a)``.
 
 The reference delegates to ``flowtorch.analysis.SVD`` (absent here): ``rank=None`` selects the optimal hard threshold of
 Gavish & Donoho as flowtorch documents it (``opt_rank``); that selection rule is restated from the documentation, not pinned
@@ -23,10 +23,14 @@ relative error of eps * (s_max / s)^2: fine down to s / s_max ~ 1e-3 (1e-10), us
 ``write_svd_s_cube_to_file`` stores -- never get there, but the optimal-rank rule takes the MEDIAN of the spectrum, which for
 low-noise data lies far below.  Whenever a singular value that matters (all of them for ``rank=None``, the requested ones
 otherwise) falls under 1e-3 * s_max the spectrum is therefore refined by DEFLATION (``_spectrum``): the modes found so far
-are projected out of the data (one library GEMM), the Gram matrix of the residual -- whose largest singular value is now
-1e-3 of the previous level's -- is taken by the same kernel, and so on for up to three levels; the result has the absolute
-accuracy of a direct SVD (about eps * s_max; ``torch.linalg.svd`` of the float64 matrix is the checker,
-tests/test_gpu_kernels.py::test_compute_svd_small_singular_values).
+are projected out of the data, the Gram matrix of the residual -- whose largest singular value is now 1e-3 of the previous
+level's -- is taken by the same kernel, and so on for up to three levels; the result has the absolute accuracy of a direct
+SVD (about eps * s_max; ``torch.linalg.svd`` of the float64 matrix is the checker,
+tests/test_gpu_kernels.py::test_compute_svd_small_singular_values).  "Matters" is read narrowly (ADVICE r3): the optimal-rank
+rule needs the spectrum down to its MEDIAN only, and the direction the centring removed (eigenvalue ~0 by construction) is
+never waited for -- a full-rank noisy matrix takes ONE Gram pass.  The residual is never materialised as a second N x T
+matrix: the coefficients ``A = (X - mean) V`` [N, found] are kept, and ``(X - mean) - A V^T`` is formed in row chunks of
+``RESIDUAL_ROWS`` that go straight into the Gram kernel (both by ``s3_centered_gemm``).
 """
 import ctypes as C
 from typing import Tuple
@@ -66,27 +70,66 @@ def _eigh(g: pt.Tensor):
 
 LEVEL_RANGE = 1e-3          # singular values down to this fraction of a level's largest one are taken from that level's Gram matrix
 MAX_LEVELS = 4
+RESIDUAL_ROWS = 1 << 16     # rows of the residual that exist at a time (a chunk is formed, enters the Gram matrix and is dropped)
 
 
-def _spectrum(x2: pt.Tensor, mean: pt.Tensor, w: pt.Tensor, wanted):
-    """all singular values (descending, host) and right singular vectors [T, T] (host) of sqrt(w) * (x2 - mean): Gram matrix +
-    symmetric eigenproblem, refined by deflation where the values that matter (the first ``wanted``; all for None) reach
-    below ``LEVEL_RANGE`` of the largest one of a level (module docstring)"""
+def centered_gemm(left: pt.Tensor, left_mean, b: pt.Tensor, minus_from: pt.Tensor = None, minus_from_mean=None) -> pt.Tensor:
+    """``(left - left_mean 1^T) @ b`` or, with ``minus_from``, ``(minus_from - minus_from_mean 1^T) - (left - left_mean 1^T) @ b``
+    on the f64 matrix cores (s3_centered_gemm).  ``left`` [m, k] and ``minus_from`` [m, n] may be row-pitched device matrices
+    (unit inner stride), ``b`` [k, n]; means are device vectors [m] or None.  Returns a contiguous [m, n] device matrix."""
+    for name, a in (("left", left), ("b", b)) + ((("minus_from", minus_from),) if minus_from is not None else ()):
+        if not (a.is_cuda and a.dtype == pt.float64 and a.dim() == 2 and a.stride(1) == 1):
+            raise TypeError(f"centered_gemm: {name} has to be a 2-D float64 device matrix with unit inner stride")
+    m, k, n = int(left.shape[0]), int(left.shape[1]), int(b.shape[1])
+    b = b.contiguous()
+    if int(b.shape[0]) != k or (minus_from is not None and tuple(minus_from.shape) != (m, n)):
+        raise ValueError("centered_gemm: shapes do not match")
+    out = pt.empty((m, n), dtype=pt.float64, device=left.device)
+    if m == 0 or n == 0:
+        return out
+    if k == 0:
+        return out.zero_() if minus_from is None else out.copy_(minus_from if minus_from_mean is None else minus_from - minus_from_mean.reshape(-1, 1))
+    ptr = lambda a: C.c_void_p(a.data_ptr()) if a is not None else None
+    hipops.check(_lib.hip_lib().s3_centered_gemm(ptr(left), m, k, int(left.stride(0)), ptr(left_mean), ptr(b), n, ptr(minus_from),
+                                                 int(minus_from.stride(0)) if minus_from is not None else 0, ptr(minus_from_mean),
+                                                 ptr(out), hipops._stream()), "s3_centered_gemm")
+    return out
+
+
+def _residual_gram(x2: pt.Tensor, mean: pt.Tensor, w: pt.Tensor, basis: pt.Tensor) -> pt.Tensor:
+    """Gram matrix of ``sqrt(w) * ((x2 - mean 1^T) (I - basis basis^T))`` without a second N x T matrix: the coefficients
+    ``A = (x2 - mean) basis`` [N, found], then per chunk of rows the residual ``(x2 - mean) - A basis^T`` -> Gram kernel"""
     n, t = int(x2.shape[0]), int(x2.shape[1])
-    zeros = None
-    data, mu = x2, mean
+    coeff = centered_gemm(x2, mean, basis)                                        # [N, found]
+    basis_t = basis.T.contiguous()
+    gram = pt.zeros((t, t), dtype=pt.float64, device=x2.device)
+    zero_mean = pt.zeros(min(n, RESIDUAL_ROWS), dtype=pt.float64, device=x2.device)
+    for r0 in range(0, n, RESIDUAL_ROWS):
+        r1 = min(n, r0 + RESIDUAL_ROWS)
+        residual = centered_gemm(coeff[r0:r1], None, basis_t, minus_from=x2[r0:r1], minus_from_mean=mean[r0:r1])
+        gram += weighted_gram(residual, zero_mean[:r1 - r0], w[r0:r1])
+    return gram
+
+
+def _spectrum(x2: pt.Tensor, mean: pt.Tensor, w: pt.Tensor, wanted: int):
+    """all singular values (descending, host) and right singular vectors [T, T] (host) of sqrt(w) * (x2 - mean): Gram matrix +
+    symmetric eigenproblem, refined by deflation where the first ``wanted`` values reach below ``LEVEL_RANGE`` of the largest
+    one of a level (module docstring).  The last direction -- what the centring removed, eigenvalue ~0 -- is never waited for."""
+    t = int(x2.shape[1])
+    gram = weighted_gram(x2, mean, w)
     s_parts, v_parts, found = [], [], 0
     for level in range(MAX_LEVELS):
-        lam, vec = _eigh(weighted_gram(data, mu, w))              # ascending; T x T
+        lam, vec = _eigh(gram)                                    # ascending; T x T
         lam, vec = lam.flip(0).clamp_min(0.0), vec.flip(1)
         lam, vec = lam[:t - found], vec[:, :t - found]            # (the directions already found come out as ~0: dropped)
         if found:                                                 # keep the new vectors in the complement of the old ones
             basis = pt.cat(v_parts, dim=1)
-            vec = vec - basis @ (basis.T @ vec)
+            vec = vec - pt.matmul(basis, pt.matmul(basis.T, vec))     # (T x T host matrices)
             vec, _ = pt.linalg.qr(vec)
         s_level = lam.sqrt()
         good = int((lam >= lam[0] * LEVEL_RANGE ** 2).sum()) if float(lam[0]) > 0 else 0
-        need_more = good < len(lam) and (wanted is None or found + good < wanted) and level + 1 < MAX_LEVELS and good > 0
+        meaningful = len(lam) - 1                                 # the centring's null direction never passes the test above
+        need_more = good < meaningful and found + good < wanted and level + 1 < MAX_LEVELS and good > 0
         if not need_more:
             s_parts.append(s_level)
             v_parts.append(vec)
@@ -94,13 +137,7 @@ def _spectrum(x2: pt.Tensor, mean: pt.Tensor, w: pt.Tensor, wanted):
         s_parts.append(s_level[:good])
         v_parts.append(vec[:, :good])
         found += good
-        # the residual: (X - mean 1^T) (I - V V^T) as a matrix of its own (mean zero by construction)
-        basis = pt.cat(v_parts, dim=1).to(x2.device)              # [T, found]
-        proj = pt.eye(t, dtype=pt.float64, device=x2.device) - basis @ basis.T
-        data = x2 @ proj - mean.reshape(-1, 1) * proj.sum(0, keepdim=True)
-        if zeros is None:
-            zeros = pt.zeros(n, dtype=pt.float64, device=x2.device)
-        mu = zeros
+        gram = _residual_gram(x2, mean, w, pt.cat(v_parts, dim=1).to(x2.device))
     return pt.cat(s_parts), pt.cat(v_parts, dim=1)
 
 
@@ -139,13 +176,14 @@ def compute_svd(data_matrix: pt.Tensor, cell_area: pt.Tensor, rank: int = None) 
     else:
         x2, w = x, area
     mean = metrics.temporal_mean(x2)
-    s_all, vec = _spectrum(x2, mean, w, None if rank is None else min(int(rank), t))
+    # rank=None: the optimal-rank rule compares with the MEDIAN of the spectrum -- values below it need not be accurate
+    s_all, vec = _spectrum(x2, mean, w, t // 2 + 1 if rank is None else min(int(rank), t))
     r = optimal_rank(s_all, x2.shape[0], t) if rank is None else min(int(rank), t)
     keep = s_all[:r] > s_all[0] * 1e-14 if r else s_all[:0] > 0
     r = int(keep.sum()) if r else 0
     s, v = s_all[:r], vec[:, :r].contiguous()
     b = (v / s).to(x2.device)                                 # [T, r]
-    u = x2 @ b - mean.reshape(-1, 1) * b.sum(0, keepdim=True)     # (X - mean 1^T) B; the sqrt(area) factors cancel
+    u = centered_gemm(x2, mean, b)                            # (X - mean 1^T) B; the sqrt(area) factors cancel
     if len(shape) == 3:
         u = u.reshape(n_cells, shape[1], r)
     s, v = s.to(x2.device), v.to(x2.device)

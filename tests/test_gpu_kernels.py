@@ -773,6 +773,49 @@ def test_compute_svd_vs_torch(shape, rank):
     assert (recon - best).abs().max() <= 1e-8 * s_ref[0]
 
 
+@pytest.mark.parametrize("m,k,n,pitch", [(1000, 40, 7, 0), (3001, 130, 130, 6), (257, 5, 300, 3), (5000, 1000, 50, 0), (129, 17, 129, 0)])
+def test_centered_gemm_vs_torch(ops, m, k, n, pitch):
+    """s3_centered_gemm (f64 matrix cores): the mode GEMM (X - mean 1^T) B of compute_svd (reference utils.py:302-346 takes U from
+    the SVD) and the residual form (E - emean 1^T) - (L - lmean 1^T) B, pitched rows, ragged tiles -- against torch float64"""
+    from sparsespatialsampling_amd import svd
+    rng = np.random.default_rng(m + k + n)
+    lbuf = pt.from_numpy(rng.standard_normal((m, k + pitch)) + 3.0).cuda()
+    left, b = lbuf[:, :k], pt.from_numpy(rng.standard_normal((k, n))).cuda()
+    lmean = left.mean(1)
+    ref = (left - lmean[:, None]).cpu() @ b.cpu()
+    got = svd.centered_gemm(left, lmean, b)
+    assert got.shape == (m, n) and (got.cpu() - ref).abs().max() <= 1e-12 * max(1.0, float(ref.abs().max()))
+    assert (svd.centered_gemm(left, None, b).cpu() - left.cpu() @ b.cpu()).abs().max() <= 1e-12 * float((left.cpu() @ b.cpu()).abs().max())
+    ebuf = pt.from_numpy(rng.standard_normal((m, n + pitch)) * 10).cuda()
+    e, emean = ebuf[:, :n], pt.from_numpy(rng.standard_normal(m)).cuda()
+    res = svd.centered_gemm(left, lmean, b, minus_from=e, minus_from_mean=emean)
+    want = (e - emean[:, None]).cpu() - ref
+    assert (res.cpu() - want).abs().max() <= 1e-12 * float(want.abs().max())
+
+
+def test_compute_svd_takes_one_gram_pass_on_noisy_data(monkeypatch):
+    """with ``rank=None`` only the spectrum down to its median has to be accurate, and the direction the centring
+    removed is never waited for -- a full-rank noisy matrix must not enter the deflation levels (each one costs another pass of
+    the Gram kernel over the whole matrix)"""
+    from sparsespatialsampling_amd import svd
+    rng = np.random.default_rng(11)
+    n, t = 20000, 64
+    data = sum(np.outer(rng.standard_normal(n), np.sin((j + 1) * np.linspace(0, 3, t) + j)) * 2.0 ** (3 - j) for j in range(5))
+    data = pt.from_numpy(data + 0.05 * rng.standard_normal((n, t)) + 2.0)
+    area = pt.from_numpy(rng.random(n) * 0.5 + 0.05)
+    calls = []
+    real = svd.weighted_gram
+    monkeypatch.setattr(svd, "weighted_gram", lambda *a: (calls.append(1), real(*a))[1])
+    s, u, v = svd.compute_svd(data, area, None)
+    assert len(calls) == 1
+    xw = (data - data.mean(-1, keepdim=True)) * area.sqrt()[:, None]
+    s_ref = pt.linalg.svdvals(xw)
+    assert len(s) == svd.optimal_rank(s_ref, n, t) and pt.allclose(s, s_ref[:len(s)], rtol=1e-9)
+    calls.clear()
+    svd.compute_svd(data, area, 5)
+    assert len(calls) == 1
+
+
 def test_compute_svd_small_singular_values():
     """a spectrum that falls over nine decades: the Gram matrix alone returns noise below
     sqrt(eps) * s_max; with the deflation levels every singular value has the absolute accuracy of a direct SVD (compared

@@ -341,6 +341,30 @@ def batch_record(hipops, plan, w, used, n_points, nc, k, row_len, label, workloa
     return rec
 
 
+def numbering_follows_space(hipops, x, idx, used, w, centers, k, row_len, steps, warmup, gen):
+    """the same in-place launch on a mesh whose point NUMBERING follows space (the points renumbered along their Hilbert
+    curve -- what a block-structured or bandwidth-reduced CFD mesh looks like; the bench cloud is numbered at random, the
+    worst case for short dense rows: a 100-byte row starts anywhere in a 128-byte line and its neighbours in memory belong to
+    cells far away).  Same grid, same neighbour sets, same values per cell; only where the rows lie in the table changes."""
+    n = len(x)
+    order = hipops.spatial_order(x).long()                           # position -> point
+    new_id = pt.empty(n, dtype=pt.int32, device="cuda")
+    new_id[order] = pt.arange(n, dtype=pt.int32, device="cuda")
+    idx_new = new_id[used.long()[idx.long()]].contiguous()             # neighbour table in the new numbering (full table ids)
+    used2, remap2 = hipops.referenced_rows([idx_new], n, coords=None)
+    hipops.remap_indices(idx_new, remap2)
+    plan = hipops.InterpPlan(idx_new, int(used2.numel()), centers)
+    plan.set_weights(w)
+    plan.set_source_ids(used2.contiguous(), n)
+    table = pt.empty((n, row_len), dtype=pt.float32, device="cuda")
+    table.normal_(generator=gen)
+    out = pt.empty((len(centers), row_len), dtype=pt.float64, device="cuda")
+    st = ms_stats(launch_times_ms(lambda: plan.interp_src(table, out=out), steps, warmup))
+    b_alg = int(used2.numel()) * row_len * 4 + len(centers) * row_len * 8 + len(centers) * k * 12
+    plan.close()
+    return dict(frac=b_alg / (st["kernel_ms"] * 1e-3) / 8e12, note="points renumbered along their Hilbert curve", **st)
+
+
 def device_resident_input(x, centers, k, t_list, bare_ms):
     """a CUDA tensor [N, 1, T] fp32 as the reference hands batches over (export.py:128-167: every row of the CFD mesh, dense)
     -> ExportData: `interp_ms` = upload step + neighbour table on the device (HIP events; [Nc, T] f64 stays in HBM),
@@ -662,6 +686,9 @@ def main():
             res["roofline_batches"] = {name: batch_record(hipops, plan, w, used.contiguous(), len(x), nc, k, rl, label, f"{key}/{name}",
                                                            args.steps, args.warmup, gen)
                                        for name, rl, label in shapes if rl != row_len}
+            if "T25" in res["roofline_batches"]:
+                res["roofline_batches"]["T25"]["numbering_follows_space"] = numbering_follows_space(
+                    hipops, x, idx, used, w, my_centers, k, 25, args.steps, args.warmup, gen)
         if not args.no_cpu_baseline and world == 1:       # reported at N=1 only
             res["cpu_baseline"] = cpu_baseline(w, idx, data, k, used)
             bare = {t_b: kernel_ms}

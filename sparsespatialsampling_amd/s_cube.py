@@ -54,7 +54,9 @@ def _make_backend(vertices, target, k):
 
 
 def _ordered(ids):
-    """the elements of an ``IntSet`` / ``set`` in iteration order, int64"""
+    """the elements of an ``IntSet`` / ``set`` in iteration order, int64.  READ-ONLY for an ``IntSet``: the array is the set's
+    cached order, shared by every caller until the set changes (``IntSet.to_array``) -- index with it, pass it on, but take a
+    copy before sorting or assigning in place (numpy refuses to write to it)."""
     if isinstance(ids, (IntSet, RangeSet)):
         return ids.to_array()
     return np.fromiter(ids, dtype=np.int64, count=len(ids))

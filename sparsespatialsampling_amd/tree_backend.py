@@ -89,6 +89,9 @@ class HipTreeBackend:
         self.leaf[0] = 1
         # the root's own row of child_metric (the centre values of its children), so that the first batch already takes the
         # 8-query wavefront route: the root as a batch of one cell, its metric and gain (known from the host) written aside
+        # (the call looks the root's "centre value" up in child_metric[parent = 0][0] -- a row it is about to write: zeroed first,
+        # so that nothing uninitialised is read; the metric and gain it derives from it go aside and are dropped)
+        self.child_metric[0].zero_()
         aside = pt.zeros(2, dtype=pt.float64, device=self.dev)
         scratch = pt.empty((self.nch + 1) + 2 + self.nch, dtype=pt.float64, device=self.dev)
         hipops.child_gain_reuse(self.knn, self.k, self.center, self.level, 0, 1, float(self.width), self.level_factor,

@@ -215,7 +215,7 @@ def test_stream_kernel_equals_direct(ops, orc, monkeypatch, k, d, row_len, dtype
 
 
 @pytest.mark.parametrize("row_len,dtype", [(25, pt.float32), (75, pt.float32), (1000, pt.float32), (16, pt.float32),
-                                           (3, pt.float32), (33, pt.float64), (8, pt.float64)])
+                                           (3, pt.float32), (33, pt.float64), (8, pt.float64), (1001, pt.float32), (259, pt.float64)])
 def test_interp_src_reads_the_full_table_in_place(ops, orc, row_len, dtype):
     """a device-resident batch [N, L] is read where it lies through the plan's source ids (s3_interp_planned_src): same
     bits as the planned kernel on the gathered, pitched copy of the referenced rows and as the direct kernel on the table

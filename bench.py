@@ -158,7 +158,7 @@ def end_to_end(x, centers, k, batches=(25, 200)):
             ex._fit_data(coords, data, "f", 10 ** 9)         # download buffers of this size (they are used alternately)
         pt.cuda.synchronize()
         t0 = time.perf_counter()
-        reps = 3
+        reps = 6
         for _ in range(reps):
             ex._fit_data(coords, data, "f", 10 ** 9)
         pt.cuda.synchronize()
@@ -166,7 +166,7 @@ def end_to_end(x, centers, k, batches=(25, 200)):
         out[f"T{t}"] = dict(ms_per_batch=dt * 1e3, Gcells_snapshots_per_s=len(centers) * t / dt / 1e9)
         del data
     out["note"] = ("pageable host tensor [N,1,T] fp32 in, host f64 tensor out; only the source rows the grid references are "
-                   "uploaded; three batches back to back (steady state of an export: the download of a batch overlaps the upload "
+                   "uploaded; six batches back to back (steady state of an export: the download of a batch overlaps the upload "
                    "of the next one), all transfers finished before the clock stops")
     return out
 
@@ -308,9 +308,11 @@ def planned_kernel_name(t_elems, k, plan_tiles, pitch_elems=None):
         return ("interp_planned_short_quad_kernel<float,7>" if vecs == 4 and not os.environ.get("S3_SHORT_NO_QUAD")
                 else "interp_planned_short_reg_kernel<float,26>")
     chunks = (t_elems + 31) // 32
-    if chunks <= int(os.environ.get("S3_STREAM_MAX_CHUNKS", "8")) and k in (8, 26) and plan_tiles >= int(os.environ.get("S3_STREAM_MIN_TILES", "64")):
+    shift = pitch % 32 != 0 and os.environ.get("S3_INPLACE_SHIFT", "1") != "0"     # rows off the 128-byte grid: whole lines, phase undone in LDS
+    if (chunks <= int(os.environ.get("S3_STREAM_MAX_CHUNKS", "8")) and k in (8, 26) and plan_tiles >= int(os.environ.get("S3_STREAM_MIN_TILES", "64"))
+            and not (shift and chunks >= 5)):
         return f"interp_planned_stream_kernel<float,{k},true,{even}>"
-    if pitch % 32 and os.environ.get("S3_INPLACE_SHIFT", "1") != "0":  # rows off the 128-byte grid: whole lines, phase undone in LDS
+    if shift:
         return "interp_planned_shift_kernel<float>"
     return "interp_planned_kernel<float,64>"
 

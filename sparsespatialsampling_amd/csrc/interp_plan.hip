@@ -1114,8 +1114,14 @@ static int launch_planned(s3_interp_plan *p, const int32_t *rows, int64_t n_rows
     const int64_t tiles_per_xcd = (p->n_tiles + 7) / 8;
     const int64_t gx = tiles_per_xcd * 8;
     S3_REQUIRE(gx < ((int64_t)1 << 31), "s3_interp_planned: too many tiles");
+    // rows off the 128-byte grid (a dense batch read where it lies) with five or more chunks are better off with whole aligned
+    // lines (interp_planned_shift_kernel, below) than with the persistent kernel's straddling segments: 800-byte rows 0.850
+    // against 0.906 ms, 400-byte rows 0.526 / 0.530 (cylinder3D grid, interleaved in one process, tools/ab_inplace.py)
+    const bool off_line = reinterpret_cast<uintptr_t>(data) % PL_SEG != 0 || ((uint64_t)in_stride * sizeof(T)) % PL_SEG != 0;
+    const bool fits32 = (uint64_t)n_rows * (uint64_t)in_stride * sizeof(T) + 2 * PL_SEG < ((uint64_t)1 << 36);
+    const bool shift_ok = p->tc == 64 && fits32 && (off_line ? inplace_shift() >= 1 : inplace_shift() >= 2);
     if ((row_len + EPV - 1) / EPV > s3::short_row_vecs() && n_chunks <= stream_max_chunks() && stream_can_take(p) &&
-        p->n_tiles >= stream_min_tiles())
+        p->n_tiles >= stream_min_tiles() && !(off_line && shift_ok && n_chunks >= 5))
         return launch_stream<T, true>(p, rows, data, row_len, in_stride, out, st);
     if ((row_len + EPV - 1) / EPV <= s3::short_row_vecs() && p->tc == 64) {
         const int vpr = (int)((row_len + EPV - 1) / EPV);
@@ -1177,11 +1183,9 @@ static int launch_planned(s3_interp_plan *p, const int32_t *rows, int64_t n_rows
     const size_t lds = (size_t)p->ucap * PL_SEG + (size_t)p->k * p->tc * (sizeof(double) + sizeof(uint16_t));
     dim3 grid((unsigned)gx, (unsigned)gy);
     // rows that do not start on 128-byte boundaries (a dense batch read where it lies): whole aligned lines per load, the
-    // per-row phase undone on the way into LDS (S3_INPLACE_SHIFT=0: the kernel below with straddling segments, for A/B runs)
-    const bool off_line = reinterpret_cast<uintptr_t>(data) % PL_SEG != 0 || ((uint64_t)in_stride * sizeof(T)) % PL_SEG != 0;
-    // (the kernel addresses the table in 16-byte vectors with 32 bits: tables of up to 64 GiB)
-    const bool fits32 = (uint64_t)n_rows * (uint64_t)in_stride * sizeof(T) + 2 * PL_SEG < ((uint64_t)1 << 36);
-    if (p->tc == 64 && fits32 && (off_line ? inplace_shift() >= 1 : inplace_shift() >= 2)) {
+    // per-row phase undone on the way into LDS (S3_INPLACE_SHIFT=0: the kernel below with straddling segments, for A/B runs;
+    // the kernel addresses the table in 16-byte vectors with 32 bits: tables of up to 64 GiB)
+    if (shift_ok) {
         auto kern = interp_planned_shift_kernel<T>;
         S3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         kern<<<grid, 256, lds, st>>>(p->perm, p->tile_cell_begin, p->tile_row_begin, rows, p->loc, p->wp, p->k, p->ucap,

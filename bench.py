@@ -343,6 +343,41 @@ def batch_record(hipops, plan, w, used, n_points, nc, k, row_len, label, workloa
     return rec
 
 
+def export_to_file(x, metric, tree_out, k, t=25, n_batches=8):
+    """the whole product path with the file at its end: ExportData.export() of `n_batches` host batches of `t` snapshots of a
+    scalar field (the reference's loop, examples/s3_for_cylinder3D_Re3900.py:28-69 -> utils.py:204-226) into a real HDF5 +
+    XDMF pair in a temporary directory -- KNN cache, upload, interpolation, transpose, download, background writer, close.
+    `tree_out`: (centers, vertices, faces, levels, width) of the generated grid."""
+    import shutil
+    import tempfile
+    from sparsespatialsampling_amd.export import ExportData
+    centers, vertices, faces, levels, width = tree_out
+    d = tempfile.mkdtemp(prefix="s3_bench_")
+    try:
+        s = types.SimpleNamespace(n_dimensions=3, faces=faces, centers=centers, vertices=vertices, levels=levels,
+                                  metric=pt.from_numpy(metric), size_initial_cell=width, save_path=d, save_name="bench", grid_name="g")
+        ex = ExportData(s, write_times=[str(i) for i in range(t * n_batches)], n_neighbors=k)
+        coords = pt.from_numpy(x)
+        batches = [pt.empty((len(x), 1, t), dtype=pt.float32).normal_() for _ in range(2)]
+        t0 = time.perf_counter()
+        per = []
+        for b in range(n_batches):
+            tb = time.perf_counter()
+            ex.export(coords, batches[b % 2], "p", n_snapshots_total=t * n_batches)
+            per.append((time.perf_counter() - tb) * 1e3)
+        total = time.perf_counter() - t0                       # the last export() closes the file: every value is on disk
+        size = os.path.getsize(os.path.join(d, "bench.h5"))
+        steady = float(np.median(per[2:-1])) if n_batches > 4 else float(np.median(per))
+        return dict(t_batch=t, batches=n_batches, total_s=total, Gcells_snapshots_per_s=len(centers) * t * n_batches / total / 1e9,
+                    ms_per_export_call=[round(p, 2) for p in per], ms_per_export_call_steady=steady,
+                    Gcells_snapshots_per_s_steady=len(centers) * t / (steady * 1e-3) / 1e9,
+                    file_MB=size / 1e6, file_MB_per_s=size / total / 1e6, directory=os.path.dirname(d),
+                    note="first call builds the KNN cache and writes the grid, the last one waits for the writer and closes the file; "
+                         "steady = median of the calls in between")
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def numbering_follows_space(hipops, x, idx, used, w, centers, k, row_len, steps, warmup, gen):
     """the same in-place launch on a mesh whose point NUMBERING follows space (the points renumbered along their Hilbert
     curve -- what a block-structured or bandwidth-reduced CFD mesh looks like; the bench cloud is numbered at random, the
@@ -544,6 +579,7 @@ def main():
         pt.cuda.synchronize()
         timings.append((comm.allreduce_max(time.perf_counter() - t0), t_init))
         centers = tree.all_centers.numpy()
+        tree_out = (tree.all_centers, tree.all_nodes, tree.face_ids, tree.all_levels, float(tree.width))
         info = dict(tree.data_final_mesh)
         n_cells_total = tree._topo_engine.n_created
         tree.close()
@@ -702,6 +738,7 @@ def main():
                 res["device_resident_input"] = device_resident_input(x, centers, k, sorted({25, t_b}), bare)
                 pt.cuda.empty_cache()
                 res["end_to_end"] = end_to_end(x, centers, k)
+                res["end_to_end"]["export_to_file"] = export_to_file(x, metric, tree_out, k)
             rcb = refine_cpu_baseline(args.workload, x, metric, geos, tree_kw, nc_total)
             rcb.update(gpu_wall_s=refine_s, gpu_runs_s=[t[0] for t in timings[1:]], speedup=rcb["cpu_wall_s"] / refine_s)
             res["refine_cpu_baseline"] = rcb

@@ -18,14 +18,14 @@ def mask_box(vertices: Tensor, lower: list, upper: list) -> Tensor:
 
 
 class CubeGeometry(GeometryObject):
-    __short_description__ = "rectangles (2D) or cubes (3D)"
+    __short_description__ = "axis-aligned rectangles (2D) / boxes (3D)"
     _type = "cube"
 
     def __init__(self, name: str, keep_inside: bool, lower_bound: list, upper_bound: list, refine: bool = False,
                  min_refinement_level: int = None):
         super().__init__(name, keep_inside, refine, min_refinement_level)
         self._lower_bound, self._upper_bound = lower_bound, upper_bound
-        self._check_geometry()
+        self._validate()
         self._main_width, self._center = self._compute_main_width(), self._compute_center()
 
     def _argument_rules(self) -> tuple:

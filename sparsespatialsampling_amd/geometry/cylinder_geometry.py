@@ -8,7 +8,7 @@ predicate: lines 126-157).  The per-cell predicate of the refine loop is the dev
 from numbers import Real
 from typing import List, Union
 
-from torch import Tensor, cross, float64, tensor
+from torch import Tensor, as_tensor, cross, float32, float64
 
 from .geometry_base import GeometryObject
 
@@ -21,9 +21,9 @@ class CylinderGeometry3D(GeometryObject):
                  radius: Union[int, float, list, tuple], refine: bool = False, min_refinement_level: int = None):
         super().__init__(name, keep_inside, refine, min_refinement_level)
         self._position, self._radius = position, radius
-        self._check_geometry()
+        self._validate()
         # end points in float32 (what `tensor(...).float()` of the reference leaves), axis and its length in float64
-        self._position = tensor(self._position).float()
+        self._position = as_tensor(self._position, dtype=float32)
         self._axis = (self._position[1] - self._position[0]).type(float64)
         self._norm = self._axis.norm()
         self._main_width, self._center = self._compute_main_width(), self._compute_center()
@@ -75,4 +75,4 @@ class CylinderGeometry3D(GeometryObject):
         return max(widest, self._norm.item())
 
     def _compute_center(self) -> Tensor:
-        return self._position.mean(0)
+        return self._position.sum(0) / 2             # (midpoint of the two end points; float32 like them)

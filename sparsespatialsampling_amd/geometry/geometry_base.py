@@ -83,6 +83,11 @@ class GeometryObject(ABC):
         for holds, complaint in self._argument_rules():
             assert holds(), f"Geometry '{self._name}': {complaint()}"
 
+    def _validate(self) -> None:
+        """what a constructor calls once its arguments are stored (the reference's classes call ``_check_geometry`` there, a
+        name subclasses may still override)"""
+        self._check_geometry()
+
     @property
     @abstractmethod
     def type(self) -> str:

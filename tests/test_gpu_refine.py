@@ -529,6 +529,22 @@ def test_full_size_c3_properties():
         if row_len != 1000:                       # the whole batch against the direct gather kernel, bit for bit
             assert pt.equal(got, hipops.interp(w, idx_c, data.contiguous()))
         del data, got
+
+    # the layout bench.py times since round 4: the dense batch [N_points, T] of ALL points as interpolate_data
+    # receives it (export.py:446-468), read in place through the plan's source ids -- the WHOLE 1000-snapshot batch against the
+    # direct gather kernel on the same table (another kernel: no tiles, no LDS staging, no phase shifts) bit for bit, the
+    # oracle on the slice, and the reference's 25-snapshot batches the same way
+    plan.set_source_ids(used.contiguous(), len(x))
+    idx_full = used.long()[idx_c.long()].to(pt.int32).contiguous()
+    for row_len in (1000, 25):
+        table = pt.empty((len(x), row_len), dtype=pt.float32, device="cuda").normal_(generator=pt.Generator(device="cuda").manual_seed(7 + row_len))
+        got = plan.interp_src(table)
+        assert pt.equal(got, hipops.interp(w, idx_full, table))
+        sub = table[used.long()[pt.from_numpy(rows_sel).cuda().long()]].contiguous().cpu().numpy().reshape(len(rows_sel), 1, row_len)
+        ref = orc.interp(w_sel, inv.reshape(i_sel.shape), sub).reshape(len(sel), row_len)
+        out = got[pt.from_numpy(sel).cuda()].cpu().numpy()
+        assert np.abs(out - ref).max() <= 1e-13 * np.abs(ref).max()
+        del table, got
     plan.close()
 
 

@@ -192,6 +192,7 @@ def export_sharded(x, centers, k, comm, t=200, reps=3):
                               metric=pt.zeros(len(x), dtype=pt.float64), size_initial_cell=1.0, save_path=".", save_name="bench",
                               grid_name="g")
     ex = ExportData(s, write_times=[str(i) for i in range(100000)], n_neighbors=k)
+    ex._interpolated_metric = True       # (the one-time metric of the original grid is not part of a batch: no gather to the root here)
     coords = pt.from_numpy(x)
     data = pt.empty((len(x), 1, t), dtype=pt.float32, device="cuda").normal_(generator=pt.Generator(device="cuda").manual_seed(99))
     for _ in range(2):                                       # cache, plans, both shared buffers
@@ -664,7 +665,8 @@ def main():
 
     # N > 1: the product's export path with N ranks (every rank takes part; after the timed region of the headline)
     sharded_leg = None
-    if world > 1 and args.shard == "cells" and plan is not None and not cfg.get("kind") == "box":
+    if (world > 1 and args.shard == "cells" and plan is not None and not cfg.get("kind") == "box"
+            and os.environ.get("S3_BENCH_NO_EXPORT_LEG") != "1"):
         del data
         pt.cuda.empty_cache()
         sharded_leg = export_sharded(x, centers, k, comm)

@@ -11,6 +11,8 @@
 #include <thread>
 #include <vector>
 
+#include <emmintrin.h>
+
 namespace s3 {
 static thread_local char g_err[512] = "";
 
@@ -54,6 +56,63 @@ int upload_threads() {
         return std::max(1, std::min(n, UP_THREADS_MAX));
     }();
     return v;
+}
+
+// Rows appended back to back into a 64-byte aligned pinned buffer with NON-TEMPORAL stores: a plain memcpy into the staging
+// buffer first reads every destination line into the cache (write-allocate) and writes it back later, next to the DMA engine
+// that reads the same lines for the transfer -- four trips through the host's memory system per byte uploaded.  Streaming
+// stores skip the read and leave the caches to the source rows.
+struct StreamPacker {
+    static constexpr int BLOCK = 4096;               // flushed at a time; pieces of up to BLOCK bytes go through the bounce buffer
+    char *dst;
+    alignas(64) char bounce[2 * BLOCK];
+    int fill = 0;
+    explicit StreamPacker(char *d) : dst(d) {}
+    static void stream(char *d, const char *s, size_t n) {      // n = multiple of 64, d 64-byte aligned
+        for (size_t o = 0; o < n; o += 64) {
+            const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i *>(s + o)), b = _mm_loadu_si128(reinterpret_cast<const __m128i *>(s + o + 16)),
+                          c = _mm_loadu_si128(reinterpret_cast<const __m128i *>(s + o + 32)), e = _mm_loadu_si128(reinterpret_cast<const __m128i *>(s + o + 48));
+            _mm_stream_si128(reinterpret_cast<__m128i *>(d + o), a);
+            _mm_stream_si128(reinterpret_cast<__m128i *>(d + o + 16), b);
+            _mm_stream_si128(reinterpret_cast<__m128i *>(d + o + 32), c);
+            _mm_stream_si128(reinterpret_cast<__m128i *>(d + o + 48), e);
+        }
+    }
+    void append(const char *src, size_t n) {
+        while (n) {
+            if (fill == 0 && n >= BLOCK) {                       // long pieces: whole lines straight from the source
+                const size_t whole = n & ~(size_t)63;
+                stream(dst, src, whole);
+                dst += whole; src += whole; n -= whole;
+                continue;
+            }
+            const size_t m = std::min(n, (size_t)(2 * BLOCK - fill));
+            std::memcpy(bounce + fill, src, m);                  // short pieces gather in the (cache-resident) bounce buffer ...
+            fill += (int)m; src += m; n -= m;
+            if (fill >= BLOCK) {                                 // ... and leave it a block at a time
+                const int whole = fill & ~63;
+                stream(dst, bounce, (size_t)whole);
+                dst += whole;
+                std::memmove(bounce, bounce + whole, (size_t)(fill - whole));
+                fill -= whole;
+            }
+        }
+    }
+    void finish() {
+        const int whole = fill & ~63;
+        stream(dst, bounce, (size_t)whole);
+        if (fill > whole) std::memcpy(dst + whole, bounce + whole, (size_t)(fill - whole));
+        _mm_sfence();
+    }
+};
+
+// ... for LARGE uploads only: a small batch's staging lines are still in the last-level cache when the DMA engine comes for them
+// (16 buffers of 8 MB), and streaming them to DRAM first makes it slower.  MI355X host, batches back to back, download of the
+// previous batch running (tools/e2e_probe.py; streamed / cached): 243 MB (25 snapshots) 9.7 / 6.5-7.2 ms, 1.94 GB (200) 44.2 /
+// 45.7-53.0 ms, 9.7 GB (1000) 225 / 263-266 ms.  S3_UPLOAD_NT=0 / 1 forces one form.
+bool upload_streaming_stores(int64_t total_bytes) {
+    static const int v = [] { const char *e = getenv("S3_UPLOAD_NT"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+    return v < 0 ? total_bytes >= ((int64_t)1 << 30) : v == 1;
 }
 
 hipError_t upload_lane_init(UploadLane &l) {
@@ -140,6 +199,14 @@ static int upload_rows_impl(const void *h_src, const int32_t *h_rows, int64_t n_
                     // one is copied (ahead chosen so that ~4 KiB per thread are on their way)
                     const int64_t ahead = std::max<int64_t>(2, std::min<int64_t>(32, 4096 / std::max<int64_t>(64, row_bytes)));
                     auto row_of = [&](int64_t r) { return base + (int64_t)(h_rows ? h_rows[r0 + r] : r0 + r) * src_stride; };
+                    if (!pitched && upload_streaming_stores(n_rows * row_bytes)) {             // rows back to back: streamed out line by line
+                        StreamPacker pack(stage);
+                        for (int64_t r = 0; r < rows; ++r) {
+                            const char *src = row_of(r);
+                            for (int sgm = 0; sgm < n_seg; ++sgm) pack.append(src + sgm * seg_stride, (size_t)seg_bytes);
+                        }
+                        pack.finish();
+                    } else
                     for (int64_t r = 0; r < rows; ++r) {
                         if (r + ahead < rows) {
                             const char *nx = row_of(r + ahead);

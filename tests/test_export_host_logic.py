@@ -245,6 +245,48 @@ def test_async_batches_and_duplicates(tmp_path):
         assert np.array_equal(got[f"data/{t}/U_center"], v)
 
 
+@pytest.mark.parametrize("big", [False, True])
+def test_writer_waits_for_the_batch_to_land(tmp_path, monkeypatch, big):
+    """``write_snapshots(ready=(flag, value))`` (s3h5_write_snapshots_async_when): the batch is handed to the background writer
+    while its values are still on their way into the buffer -- ExportData queues the device-to-host copy and hands over at once
+    (reference export.py:233-319 writes after the interpolation returned) -- and nothing is read before the producer's word
+    says so.  Here a thread plays the copy: it fills the buffer late and raises the word; the file must hold the final values.
+    A word that never comes ends in an error at flush, not in a hang."""
+    import threading
+    import time
+    if h5io.native_lib() is None:
+        pytest.skip("needs the native sink")
+    t, n = 4, (300_000 if big else 500)                    # big: datasets of a megabyte or more take the raw-write path
+    path = str(tmp_path / "late.h5")
+    buf = np.full((t, n), -1.0)
+    flag = pt.zeros(1, dtype=pt.int32)
+    final = np.arange(t * n, dtype=np.float64).reshape(t, n)
+
+    def copy_arrives():
+        time.sleep(0.3)
+        buf[:] = final
+        flag[0] = 7
+
+    with h5io.open_h5(path, "w") as f:
+        worker = threading.Thread(target=copy_arrives)
+        worker.start()
+        f.write_snapshots([str(i) for i in range(t)], "p_center", buf, ready=(flag, 7))
+        assert f.flush() == 0
+        worker.join()
+    with h5io.open_h5(path, "r") as f:
+        for i in range(t):
+            assert np.array_equal(f.read(f"data/{i}/p_center"), final[i])
+    # the word never comes
+    monkeypatch.setenv("S3H5_READY_TIMEOUT_S", "0.5")
+    code = ("import sys, numpy as np, torch as pt; sys.path.insert(0, %r); from sparsespatialsampling_amd import h5io\n"
+            "f = h5io.open_h5(%r, 'w'); f.write_snapshots(['0'], 'p', np.zeros((1, 10)), ready=(pt.zeros(1, dtype=pt.int32), 1))\n"
+            "try:\n    f.flush(); print('no error')\nexcept h5io.H5Error as e:\n    print('error:', e)\n"
+            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path / "never.h5")))
+    import subprocess, sys
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=dict(os.environ, S3H5_READY_TIMEOUT_S="0.5"))
+    assert "error:" in out.stdout and "never arrived" in out.stdout, out.stdout + out.stderr
+
+
 def test_append_and_file_per_field(export_mod, tmp_path):
     """the export state machine's other modes on real files: ``append_existing`` adds a field to a finished file (grid and
     constants are not rewritten, reference export.py:86-92), ``write_new_file_for_each_field`` gives one file per field"""

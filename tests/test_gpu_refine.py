@@ -275,6 +275,17 @@ def test_export_fit_paths_gpu(tmp_path, t, ncomp, on_gpu, n, nc):
 @pytest.mark.parametrize("t,ncomp,on_gpu,n,chunk", [(200, 1, False, 120000, 100), (130, 3, False, 120000, 60), (96, 1, True, 120000, 100),
                                                     (257, 1, False, 20000, 100), (64, 2, False, 120000, 30), (101, 1, True, 20000, 100)])
 def test_export_pipeline_pieces_equal_the_single_piece_gpu(tmp_path, t, ncomp, on_gpu, n, chunk, monkeypatch):
+    _pipeline_pieces_case(tmp_path, t, ncomp, on_gpu, n, chunk, monkeypatch)
+
+
+def test_export_pipeline_pieces_through_the_gathered_copy_gpu(tmp_path, monkeypatch):
+    """the same with device-resident pieces gathered into the pitched copy first (S3_EXPORT_INPLACE=0: the path of plans that
+    cannot read a table where it lies)"""
+    monkeypatch.setenv("S3_EXPORT_INPLACE", "0")
+    _pipeline_pieces_case(tmp_path, 96, 1, True, 120000, 100, monkeypatch)
+
+
+def _pipeline_pieces_case(tmp_path, t, ncomp, on_gpu, n, chunk, monkeypatch):
     """one ``export()`` call pipelined over pieces of the snapshot axis (upload of piece j + 1 / kernel of piece j / download
     of piece j - 1 on three streams, ``chunk_size`` sets the piece length; reference export.py:128-167, 463-467) gives the
     bits of the one-piece sequence, for host and device-resident batches, scalar and vector fields, centres and vertices,

@@ -100,6 +100,38 @@ __device__ __forceinline__ void stage_tile_tables(const double *__restrict__ wp,
     }
 }
 
+// the same with the LDS image laid out [m][TC] (row pitch = the tile capacity, not the tile's cell count): the accumulate
+// loop then addresses weight / position m of its cell at a CONSTANT distance m * TC from those of neighbour 0 -- immediate offsets
+// of the LDS instructions instead of a vector add per access (two of the ~20 vector instructions per neighbour).  Four neighbours
+// per pass of the 256 threads; eight loads per lane in flight.
+template <int TC>
+__device__ __forceinline__ void stage_tile_tables_strided(const double *__restrict__ wp, const uint16_t *__restrict__ loc, int n_c, int k,
+                                                          double *__restrict__ s_w, uint16_t *__restrict__ s_loc) {
+    static_assert(TC == 64, "four rows of 64 cells per pass of 256 threads");
+    const int cl = threadIdx.x & 63, m0 = threadIdx.x >> 6;
+    const bool has = cl < n_c;
+    constexpr int UN = 8;
+    for (int base = 0; base < k; base += 4 * UN) {
+        double wr[UN];
+        uint16_t lr[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int m = base + 4 * u + m0;
+            const int i = has && m < k ? m * n_c + cl : 0;
+            wr[u] = wp[i];
+            lr[u] = loc[i];
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int m = base + 4 * u + m0;
+            if (has && m < k) {
+                s_w[m * TC + cl] = wr[u];
+                s_loc[m * TC + cl] = lr[u];
+            }
+        }
+    }
+}
+
 // weights of the caller's table [nc][k] -> plan order (one workgroup per tile)
 __global__ void __launch_bounds__(256)
 permute_weights_kernel(const int32_t *__restrict__ perm, const int32_t *__restrict__ tile_cell_begin,
@@ -370,6 +402,7 @@ interp_planned_kernel(const int32_t *__restrict__ perm, const int32_t *__restric
     const bool even_rows = (row_len & 1) == 0;                   // output rows 16-byte aligned -> double2 stores
 
     // the tile's weights and LDS row positions, [neighbour][cell] so that a wavefront reads consecutive words
+    // the tile's weights and LDS row positions, [neighbour][cell] so that a wavefront reads consecutive words
     stage_tile_tables(w + (int64_t)c_begin * k, loc + (int64_t)c_begin * k, n_c * k, s_w, s_loc, BLOCK);
 
     // this thread's cell: 4 lanes per cell, each lane two 16-byte vectors of the chunk (v0 and v0+4)
@@ -500,7 +533,9 @@ interp_planned_shift_kernel(const int32_t *__restrict__ perm, const int32_t *__r
     const int r_begin = tile_row_begin[tile], n_r = tile_row_begin[tile + 1] - r_begin;
     const bool even_rows = (row_len & 1) == 0;
 
-    stage_tile_tables(w + (int64_t)c_begin * k, loc + (int64_t)c_begin * k, n_c * k, s_w, s_loc, BLOCK);
+    // (tables at a constant pitch of TC entries: in THIS kernel -3 % per launch against the [m][n_c] layout of the kernel above,
+    // 3.478 / 3.584 ms interleaved in one process; in the kernel above the same change measured +0.4 % and was not kept)
+    stage_tile_tables_strided<TC>(w + (int64_t)c_begin * k, loc + (int64_t)c_begin * k, n_c, k, s_w, s_loc);
 
     const int cl = threadIdx.x >> 2, v0 = threadIdx.x & 3;
     const bool has_cell = cl < n_c;
@@ -575,8 +610,8 @@ interp_planned_shift_kernel(const int32_t *__restrict__ perm, const int32_t *__r
         for (int i = 0; i < EPV; ++i) acc0[i] = acc1[i] = 0.0;
 #pragma unroll 4
         for (int m = 0; m < k; ++m) {
-            const int pos = s_loc[m * n_c + cl];
-            const double wm = s_w[m * n_c + cl];
+            const int pos = s_loc[m * TC + cl];
+            const double wm = s_w[m * TC + cl];
             const V a = s_data[pos * 8 + v0];
             const V c = s_data[pos * 8 + v0 + 4];
             const T *ae = reinterpret_cast<const T *>(&a);

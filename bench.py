@@ -508,6 +508,8 @@ def main():
     ap.add_argument("--t-batch", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baselines, the device-resident and the end-to-end legs (profiling runs)")
     ap.add_argument("--no-batches", action="store_true", help="skip the roofline_batches sub-records")
+    ap.add_argument("--no-pitched-copy", action="store_true", help="skip the pitched_copy sub-record (profiling runs: its launches may "
+                    "carry the headline kernel's name -- 16-byte aligned rows of up to four chunks -- and would be averaged into its statistics)")
     ap.add_argument("--n-comp", type=int, default=1, help="components per snapshot: the row holds n_comp * t_batch values")
     ap.add_argument("--shard", choices=["cells", "snapshots"], default="cells",
                     help="N>1: every rank interpolates its contiguous range of the generated cells for the same snapshots "
@@ -654,7 +656,7 @@ def main():
     # the same launch on the pitched, compacted copy of the referenced rows (Hilbert order, whole 128-byte lines per row:
     # the layout ExportData uploads HOST batches into -- rounds 1-3 quoted the headline on it)
     pitched = None
-    if rank == 0 and world == 1 and plan is not None:
+    if rank == 0 and world == 1 and plan is not None and not args.no_pitched_copy:
         rows_p = hipops.gather_rows(data, used.contiguous(), hipops.padded_rows(n_rows, row_len, pt.float32, "cuda",
                                                                                int(os.environ.get("S3_BENCH_PITCH_EXTRA", "0"))))
         pms = launch_times_ms(lambda: plan.interp(w, rows_p, out=out), args.steps, args.warmup)

@@ -1028,6 +1028,10 @@ static int inplace_shift() {                 // 0: never (A/B runs), 1: rows off
     const char *e = getenv("S3_INPLACE_SHIFT");
     return e ? atoi(e) : 1;
 }
+static int shift_min_chunks() {
+    const char *e = getenv("S3_SHIFT_MIN_CHUNKS");
+    return e ? atoi(e) : 3;
+}
 static int stream_workgroups() {
     static const int v = [] {
         const char *e = getenv("S3_STREAM_WORKGROUPS");
@@ -1149,14 +1153,15 @@ static int launch_planned(s3_interp_plan *p, const int32_t *rows, int64_t n_rows
     const int64_t tiles_per_xcd = (p->n_tiles + 7) / 8;
     const int64_t gx = tiles_per_xcd * 8;
     S3_REQUIRE(gx < ((int64_t)1 << 31), "s3_interp_planned: too many tiles");
-    // rows off the 128-byte grid (a dense batch read where it lies) with five or more chunks are better off with whole aligned
+    // rows off the 128-byte grid (a dense batch read where it lies) with three or more chunks are better off with whole aligned
     // lines (interp_planned_shift_kernel, below) than with the persistent kernel's straddling segments: 800-byte rows 0.850
-    // against 0.906 ms, 400-byte rows 0.526 / 0.530 (cylinder3D grid, interleaved in one process, tools/ab_inplace.py)
+    // against 0.906 ms, 400-byte rows 0.529 / 0.553, 272-byte rows 0.414 / 0.424 (cylinder3D grid, interleaved in one process,
+    // tools/ab_inplace.py; S3_SHIFT_MIN_CHUNKS overrides)
     const bool off_line = reinterpret_cast<uintptr_t>(data) % PL_SEG != 0 || ((uint64_t)in_stride * sizeof(T)) % PL_SEG != 0;
     const bool fits32 = (uint64_t)n_rows * (uint64_t)in_stride * sizeof(T) + 2 * PL_SEG < ((uint64_t)1 << 36);
     const bool shift_ok = p->tc == 64 && fits32 && (off_line ? inplace_shift() >= 1 : inplace_shift() >= 2);
     if ((row_len + EPV - 1) / EPV > s3::short_row_vecs() && n_chunks <= stream_max_chunks() && stream_can_take(p) &&
-        p->n_tiles >= stream_min_tiles() && !(off_line && shift_ok && n_chunks >= 5))
+        p->n_tiles >= stream_min_tiles() && !(off_line && shift_ok && n_chunks >= shift_min_chunks()))
         return launch_stream<T, true>(p, rows, data, row_len, in_stride, out, st);
     if ((row_len + EPV - 1) / EPV <= s3::short_row_vecs() && p->tc == 64) {
         const int vpr = (int)((row_len + EPV - 1) / EPV);

@@ -40,7 +40,8 @@ for t in ts:
                 ("pitched compacted copy", {}, lambda: plan.interp(w, rows, out=out)),
                 ("pitched, shift kernel", {"S3_INPLACE_SHIFT": "2"}, lambda: plan.interp(w, rows, out=out))]
     if os.environ.get("AB_SHIFT_MID") == "1":          # mid-length rows: the shift kernel instead of the persistent kernel
-        variants.append(("in place, shift kernel", {"S3_INPLACE_SHIFT": "1", "S3_STREAM_MAX_CHUNKS": "2"}, lambda: plan.interp_src(table, out=out)))
+        variants.append(("in place, shift kernel", {"S3_INPLACE_SHIFT": "1", "S3_SHIFT_MIN_CHUNKS": "1"}, lambda: plan.interp_src(table, out=out)))
+        variants.append(("in place, persistent kernel", {"S3_INPLACE_SHIFT": "1", "S3_SHIFT_MIN_CHUNKS": "99"}, lambda: plan.interp_src(table, out=out)))
     if os.environ.get("AB_DENSE_COMPACT") == "1":       # the referenced rows only, dense (pitch = row length), Hilbert order
         dense = rows.contiguous()
         variants.append(("dense compacted copy", {}, lambda: plan.interp(w, dense, out=out)))

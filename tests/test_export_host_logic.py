@@ -287,6 +287,29 @@ def test_writer_waits_for_the_batch_to_land(tmp_path, monkeypatch, big):
     assert "error:" in out.stdout and "never arrived" in out.stdout, out.stdout + out.stderr
 
 
+def test_snapshot_pieces_follow_chunk_size(export_mod, tmp_path, monkeypatch):
+    """``chunk_size`` (which bounds the reference's [chunk, k, n_comp, T] temporary, export.py:463-467) sets the length of the
+    snapshot pieces a batch is pipelined in: about chunk_size * 256 output values each, at least 32 snapshots, multiples of 8,
+    covering the batch without gaps; host batches are cut on request only (S3_EXPORT_PIPELINE=host)"""
+    s = _scube(tmp_path, nc=400)
+    ex = export_mod.ExportData(s, write_times=["0"])
+    d = pt.zeros((10, 1, 200), dtype=pt.float32)
+    assert ex._snapshot_pieces(d, 1, 200) == [(0, 200)]                       # a host batch, default: one piece
+    monkeypatch.setenv("S3_EXPORT_PIPELINE", "host")
+    for chunk, t, ncomp in ((100, 200, 1), (100, 1000, 1), (50, 130, 3), (1000, 257, 1), (5, 64, 1), (100, 63, 1)):
+        ex._chunk_size = chunk
+        pieces = ex._snapshot_pieces(pt.zeros((10, ncomp, t), dtype=pt.float32), ncomp, t)
+        assert pieces[0][0] == 0 and pieces[-1][1] == t and all(a[1] == b[0] for a, b in zip(pieces, pieces[1:]))
+        want = max(32, chunk * 256 // (400 * ncomp) // 8 * 8)
+        if t < 64 or want >= t:
+            assert pieces == [(0, t)]
+        else:
+            lengths = [b - a for a, b in pieces]
+            assert all(n % 8 == 0 for n in lengths[:-1]) and max(lengths) <= want + 8 and len(pieces) == -(-t // want)
+    monkeypatch.setenv("S3_EXPORT_PIPELINE", "0")
+    assert ex._snapshot_pieces(pt.zeros((10, 1, 1000), dtype=pt.float32), 1, 1000) == [(0, 1000)]
+
+
 def test_append_and_file_per_field(export_mod, tmp_path):
     """the export state machine's other modes on real files: ``append_existing`` adds a field to a finished file (grid and
     constants are not rewritten, reference export.py:86-92), ``write_new_file_for_each_field`` gives one file per field"""

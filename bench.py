@@ -209,6 +209,7 @@ def export_sharded(x, centers, k, comm, t=200, reps=3):
     return dict(t_batch=t, ms_per_batch=dt * 1e3, Gcells_snapshots_per_s=len(centers) * t / dt / 1e9,
                 cells_on_this_rank=int(len(table.shard.mine)), rows_uploaded_by_this_rank=0, xgmi_bytes_per_batch=0,
                 host_bytes_written_by_this_rank=int(len(table.shard.mine)) * t * 8,
+                shared_host_buffer=ex._shared is not None,
                 direct_device_writes=bool(ex._shared and all(b.device_ptr is not None for b in ex._shared.values())),
                 note="dense device batch in -> the ranks' rows in ONE shared host buffer (snapshot-major, file order), "
                      "ready for the writer of rank 0; each rank over its own PCIe link")

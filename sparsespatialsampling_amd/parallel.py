@@ -286,6 +286,10 @@ class RcclComm(SoloComm):
             pass
 
 
+class SharedMemoryUnavailable(OSError):
+    """raised on EVERY rank when the node's shared-memory file system cannot hold a batch buffer (a container with a 64-MB /dev/shm)"""
+
+
 class SharedHostArray:
     """``n_bytes`` of host memory that every rank of the node maps (POSIX shared memory) and that every rank's GPU can write
     through its own PCIe link (``s3_host_register``): the snapshot-major batch buffer of the sharded export.  Collective:
@@ -299,7 +303,17 @@ class SharedHostArray:
         import mmap
         self.n_bytes = int(n_bytes)
         SharedHostArray._serial += 1
-        name = comm.broadcast_bytes(f"s3_{os.getpid()}_{SharedHostArray._serial}".encode() if comm.rank == 0 else None).decode()
+        proposal = None
+        if comm.rank == 0:
+            try:                                             # room for the buffer (tmpfs pages are committed when touched: a buffer
+                st = os.statvfs("/dev/shm")                  # that does not fit ends in SIGBUS, not in an error)
+                fits = st.f_bavail * st.f_frsize >= self.n_bytes + (64 << 20)
+            except OSError:
+                fits = False
+            proposal = f"s3_{os.getpid()}_{SharedHostArray._serial}".encode() if fits else b""
+        name = comm.broadcast_bytes(proposal).decode()
+        if not name:                                         # (decided by the root, learnt by everybody: all ranks take the same way)
+            raise SharedMemoryUnavailable(f"/dev/shm cannot hold a batch buffer of {self.n_bytes} bytes")
         path = os.path.join("/dev/shm", name)
         if comm.rank == 0:
             fd = os.open(path, os.O_CREAT | os.O_EXCL | os.O_RDWR, 0o600)

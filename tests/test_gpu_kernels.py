@@ -474,6 +474,22 @@ def test_knn_graded_cloud_two_level(ops, orc, d, k):
     knn.close()
 
 
+def test_knn_where_sklearn_uses_brute_force(ops):
+    """k >= N // 2: scikit-learn answers by brute force with expanded squared distances (tests/golden/gen_sklearn_brute.py); the
+    device search returns the same neighbours in the same order, distances to 1e-13 absolute, predictions to 1e-10 relative"""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sklearn_brute.npz"))
+    for i in range(int(z["n_cases"])):
+        x, y, q, k = z[f"x{i}"], z[f"y{i}"], z[f"q{i}"], int(z[f"k{i}"])
+        knn = ops.KnnIndex(x)
+        idx, dist = knn.query(q, k)
+        assert np.array_equal(idx.cpu().numpy(), z[f"idx{i}"])
+        np.testing.assert_allclose(dist.cpu().numpy(), z[f"dist{i}"], rtol=0, atol=1e-13)
+        knn.set_values(y)
+        np.testing.assert_allclose(knn.predict(q, k).cpu().numpy(), z[f"pred{i}"], rtol=1e-10, atol=0)
+        knn.close()
+
+
 def test_knn_ties_structured_grid(ops, orc):
     """structured grid queried at cell corners: many exactly equidistant neighbours -> (dist, idx) tie rule"""
     g = np.stack(np.meshgrid(np.arange(30.0), np.arange(30.0), indexing="ij"), -1).reshape(-1, 2)

@@ -226,3 +226,20 @@ def test_sum_orders():
         mine = np.array([orc.lib().s3o_torch_inner_sum(np.ascontiguousarray(r).ctypes.data_as(ctypes.c_void_p), n)
                          for r in a])
         assert np.array_equal(t, mine)
+
+
+def test_sklearn_brute_force_branch_is_matched_closely():
+    """scikit-learn leaves the kd-tree for brute force when k >= N // 2 (sklearn/neighbors/_base.py:625-633; only toy clouds get
+    there, e.g. the reference's 50-point unit tests): squared distances from |q|^2 + |p|^2 - 2 q.p through a BLAS product instead of
+    the sum of squared differences.  The exact search of this build (and of the oracle) is NOT that arithmetic; the fixture
+    (tests/golden/gen_sklearn_brute.py, generated with scikit-learn itself) pins how far apart they are: same neighbours in the same
+    order, distances equal to 1e-13 absolute on unit-sized clouds (the expansion cancels for close pairs: 3e-12 relative at a
+    distance of 0.0075), weights="distance" predictions to 1e-10 relative."""
+    z = np.load(os.path.join(G, "sklearn_brute.npz"))
+    for i in range(int(z["n_cases"])):
+        assert str(z[f"method{i}"]) == "brute"
+        x, y, q, k = z[f"x{i}"], z[f"y{i}"], z[f"q{i}"], int(z[f"k{i}"])
+        idx, dist = orc.knn(x, q, k)
+        assert np.array_equal(idx, z[f"idx{i}"])
+        np.testing.assert_allclose(dist, z[f"dist{i}"], rtol=0, atol=1e-13)       # (unit-sized clouds)
+        np.testing.assert_allclose(orc.idw_predict(x, y, q, k), z[f"pred{i}"], rtol=1e-10, atol=0)

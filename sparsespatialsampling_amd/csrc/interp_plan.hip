@@ -557,14 +557,15 @@ interp_planned_shift_kernel(const int32_t *__restrict__ perm, const int32_t *__r
     // per staging pass: address of this lane's vector of the row's line 0, its LDS slot, and whether the OLDER of the two
     // lines in the registers is the one this lane contributes to an image (v >= ph)
 #define S3H_DECL(P)                                                                                              \
-    uint32_t line##P; /* in 16-byte vectors from base128 (the launcher checks that the table ends below 2^32 of them) */ \
+    const char *ptr##P; /* this lane's vector of the row's line `chunk` (the loop's current image): advanced by two lines per   \
+                           iteration, so that the lines an iteration asks for sit at IMMEDIATE offsets 256 / 384 from it */  \
     uint32_t lds##P;  /* LDS byte address of this lane's slot of the row image */                                \
     bool old##P;      /* this lane takes its vector from the OLDER of the two lines in the registers */          \
     V preA##P, preB##P;                                                                                          \
     {                                                                                                            \
         const uintptr_t a_ = base + (uint64_t)(uint32_t)rows[r_begin + min(P * RPP + srow, n_r - 1)] * stride_bytes; \
         const int ph_ = (int)(a_ >> 4) & 7;                                                                      \
-        line##P = (uint32_t)(((a_ & ~(uintptr_t)127) - base128) >> 4) + (uint32_t)svec;                          \
+        ptr##P = data128 + (((a_ & ~(uintptr_t)127) - base128) + 16u * (unsigned)svec) + (int64_t)chunk0 * 128;   \
         old##P = svec >= ph_;                                                                                    \
         /* (passes beyond the tile's last row hold a copy of it and store that copy where the row itself goes) */  \
         lds##P = (uint32_t)(min(P * RPP + srow, n_r - 1) * 8 + ((svec - ph_) & 7)) * 16u;                         \
@@ -572,27 +573,31 @@ interp_planned_shift_kernel(const int32_t *__restrict__ perm, const int32_t *__r
     S3_REP16(S3H_DECL)
     // line J of every row of this lane's passes -> register set SET.  Past j_safe the lane's vector index counted from the row
     // start (J * 8 + svec - ph) is clamped to the row's last vector.
-#define S3H_LOAD_FAST(SET, P) pre##SET##P = *reinterpret_cast<const V *>(data128 + ((uint64_t)(line##P + jvec_) << 4));
+#define S3H_LOAD_FAST(SET, P) pre##SET##P = *reinterpret_cast<const V *>(ptr##P + off_);
 #define S3H_LOAD_SAFE(SET, P)                                                                                    \
     {                                                                                                            \
         const int s_ = (int)(lds##P >> 4) & 7;           /* (svec - ph) mod 8 */                                  \
         const int d_ = s_ <= svec ? s_ : s_ - 8;         /* svec - ph */                                          \
-        const int over_ = max(0, (int)jvec_ + d_ - last_vec);                                                    \
-        pre##SET##P = *reinterpret_cast<const V *>(data128 + ((uint64_t)(line##P + jvec_ - (uint32_t)over_) << 4)); \
+        const int over_ = max(0, (J_) * 8 + d_ - last_vec);                                                      \
+        pre##SET##P = *reinterpret_cast<const V *>(ptr##P + off_ - 16 * (int64_t)over_);                         \
     }
 #define S3H_LOAD_FAST_A(P) S3H_LOAD_FAST(A, P)
 #define S3H_LOAD_FAST_B(P) S3H_LOAD_FAST(B, P)
 #define S3H_LOAD_SAFE_A(P) S3H_LOAD_SAFE(A, P)
 #define S3H_LOAD_SAFE_B(P) S3H_LOAD_SAFE(B, P)
-#define S3H_ISSUE(SET, J)                                        \
+    // line J of every row of this lane's passes -> register set SET; AHEAD = J - (the loop's current image), a compile-time 0 .. 3.
+    // Past j_safe the lane's vector index counted from the row start (J * 8 + svec - ph) is clamped to the row's last vector.
+#define S3H_ISSUE(SET, J, AHEAD)                                 \
     do {                                                         \
-        const uint32_t jvec_ = (uint32_t)(J) * 8u;               \
-        if ((J) <= j_safe) {                                     \
+        constexpr int off_ = (AHEAD) * 128;                      \
+        const int J_ = (J);                                      \
+        if (J_ <= j_safe) {                                      \
             S3_REP16(S3H_LOAD_FAST_##SET)                        \
         } else {                                                 \
             S3_REP16(S3H_LOAD_SAFE_##SET)                        \
         }                                                        \
     } while (0)
+#define S3H_ADVANCE(P) ptr##P += 256;
     // image c from (older set = line c, newer set = line c + 1)
     // One LDS store per row and lane behind a select of the older / newer line's vector.  (Two stores under complementary
     // lane masks instead -- no v_cndmask -- were built and measured: 3.85 against 3.51 ms; the LDS write port costs more than
@@ -628,24 +633,26 @@ interp_planned_shift_kernel(const int32_t *__restrict__ perm, const int32_t *__r
     };
 
     if (chunk0 < chunk1) {
-        S3H_ISSUE(A, chunk0);
-        S3H_ISSUE(B, chunk0 + 1);
+        S3H_ISSUE(A, chunk0, 0);
+        S3H_ISSUE(B, chunk0 + 1, 1);
     }
     for (int chunk = chunk0; chunk < chunk1; chunk += 2) {
         S3_REP16(S3H_STORE_AB)
         S3H_STORES_DONE();
         __syncthreads();
-        if (chunk + 1 < chunk1) S3H_ISSUE(A, chunk + 2);
+        if (chunk + 1 < chunk1) S3H_ISSUE(A, chunk + 2, 2);
         accumulate(chunk);
         __syncthreads();
         if (chunk + 1 >= chunk1) break;
         S3_REP16(S3H_STORE_BA)
         S3H_STORES_DONE();
         __syncthreads();
-        if (chunk + 2 < chunk1) S3H_ISSUE(B, chunk + 3);
+        if (chunk + 2 < chunk1) S3H_ISSUE(B, chunk + 3, 3);
         accumulate(chunk + 1);
         __syncthreads();
+        S3_REP16(S3H_ADVANCE)
     }
+#undef S3H_ADVANCE
 #undef S3H_DECL
 #undef S3H_LOAD_FAST
 #undef S3H_LOAD_SAFE
@@ -1158,8 +1165,7 @@ static int launch_planned(s3_interp_plan *p, const int32_t *rows, int64_t n_rows
     // against 0.906 ms, 400-byte rows 0.529 / 0.553, 272-byte rows 0.414 / 0.424 (cylinder3D grid, interleaved in one process,
     // tools/ab_inplace.py; S3_SHIFT_MIN_CHUNKS overrides)
     const bool off_line = reinterpret_cast<uintptr_t>(data) % PL_SEG != 0 || ((uint64_t)in_stride * sizeof(T)) % PL_SEG != 0;
-    const bool fits32 = (uint64_t)n_rows * (uint64_t)in_stride * sizeof(T) + 2 * PL_SEG < ((uint64_t)1 << 36);
-    const bool shift_ok = p->tc == 64 && fits32 && (off_line ? inplace_shift() >= 1 : inplace_shift() >= 2);
+    const bool shift_ok = p->tc == 64 && (off_line ? inplace_shift() >= 1 : inplace_shift() >= 2);
     if ((row_len + EPV - 1) / EPV > s3::short_row_vecs() && n_chunks <= stream_max_chunks() && stream_can_take(p) &&
         p->n_tiles >= stream_min_tiles() && !(off_line && shift_ok && n_chunks >= shift_min_chunks()))
         return launch_stream<T, true>(p, rows, data, row_len, in_stride, out, st);
@@ -1223,8 +1229,7 @@ static int launch_planned(s3_interp_plan *p, const int32_t *rows, int64_t n_rows
     const size_t lds = (size_t)p->ucap * PL_SEG + (size_t)p->k * p->tc * (sizeof(double) + sizeof(uint16_t));
     dim3 grid((unsigned)gx, (unsigned)gy);
     // rows that do not start on 128-byte boundaries (a dense batch read where it lies): whole aligned lines per load, the
-    // per-row phase undone on the way into LDS (S3_INPLACE_SHIFT=0: the kernel below with straddling segments, for A/B runs;
-    // the kernel addresses the table in 16-byte vectors with 32 bits: tables of up to 64 GiB)
+    // per-row phase undone on the way into LDS (S3_INPLACE_SHIFT=0: the kernel below with straddling segments, for A/B runs)
     if (shift_ok) {
         auto kern = interp_planned_shift_kernel<T>;
         S3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

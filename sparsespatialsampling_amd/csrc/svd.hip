@@ -148,7 +148,7 @@ gram_reduce_kernel(const double *__restrict__ partial, const int2 *__restrict__ 
 // 128 x 128 block of C; per step 16 columns of L and 16 rows of B go through LDS -- the L tile transposed on the way so that
 // both MFMA operands are read like the Gram kernel reads its panels (sA[k][row], sB[k][column]) -- each wavefront owns a
 // 64 x 64 quarter = 4 x 4 tiles of v_mfma_f64_16x16x4_f64; the raw loads of step s + 1 are issued before the MFMAs of step s.
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)      // 198 VGPRs; without the second bound the compiler takes 316 = one wavefront per SIMD: 31 instead of 44 TFLOP/s
 centered_gemm_kernel(const double *__restrict__ l, int64_t m, int k, int64_t l_stride, const double *__restrict__ lmean,
                      const double *__restrict__ b, int n, const double *__restrict__ e, int64_t e_stride,
                      const double *__restrict__ emean, double *__restrict__ c) {

@@ -18,17 +18,15 @@ __global__ void __launch_bounds__(256) sweep(const float4 *__restrict__ data, co
     float acc = 0.f;
     const int n_chunks = row_bytes / SEG;
     for (int c = 0; c < n_chunks; ++c) {
-        float4 v[16];
+        for (int pb = 0; pb * 16 * RPP < rows_per_wg; ++pb) {          // (segments longer than 128 B: several blocks of 16 passes)
+            float4 v[16];
 #pragma unroll
-        for (int p = 0; p < 16; ++p) {
-            const int r = p * RPP + srow;
-            v[p] = r < rows_per_wg ? data[(long)my[r] * pitch16 + (long)c * LPS + sv] : make_float4(0, 0, 0, 0);
-            if (p * RPP >= rows_per_wg) break;
-        }
+            for (int p = 0; p < 16; ++p) {
+                const int r = (pb * 16 + p) * RPP + srow;
+                v[p] = r < rows_per_wg ? data[(long)my[r] * pitch16 + (long)c * LPS + sv] : make_float4(0, 0, 0, 0);
+            }
 #pragma unroll
-        for (int p = 0; p < 16; ++p) {
-            if (p * RPP >= rows_per_wg) break;
-            acc += v[p].x + v[p].w;
+            for (int p = 0; p < 16; ++p) acc += v[p].x + v[p].w;
         }
     }
     if (acc == 123.456f) sink[0] = acc;
@@ -50,9 +48,11 @@ int main() {
     hipMemcpy(r, h.data(), sizeof(int) * h.size(), hipMemcpyHostToDevice);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 3; ++rep)
-        for (int seg : {128, 64}) {
+        for (int seg : {128, 64, 256, 512}) {
             auto run = [&]() {
                 if (seg == 128) sweep<128><<<n_wg, 256>>>(d, r, rows_per_wg, pitch / 16, (int)row_bytes, sink);
+                else if (seg == 256) sweep<256><<<n_wg, 256>>>(d, r, rows_per_wg, pitch / 16, (int)row_bytes, sink);
+                else if (seg == 512) sweep<512><<<n_wg, 256>>>(d, r, rows_per_wg, pitch / 16, (int)row_bytes, sink);
                 else sweep<64><<<n_wg, 256>>>(d, r, rows_per_wg, pitch / 16, (int)row_bytes, sink);
             };
             run(); hipDeviceSynchronize();

@@ -69,6 +69,22 @@ def test_bench_two_ranks_share_one_gpu():
 
 
 @pytest.mark.gpu
+def test_bench_line_survives_a_failing_leg():
+    """the legs beside the headline (batch records, transport, file) must not cost the driver its JSON line: a leg that raises is
+    recorded as {"error": ...} in its place, the headline fields are those of a clean run"""
+    import json
+    env = dict(os.environ, S3_BENCH_FAIL_LEG="roofline_batches.T25")
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "cylinder3D_small", "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stderr[-2000:]
+    line = json.loads(run.stdout.strip().splitlines()[-1])
+    assert line["value"] > 0 and 0 < line["roofline"]["frac"] < 1 and "kernel_ms" in line["roofline"]["pitched_copy"]
+    assert "injected" in line["roofline_batches"]["T25"]["error"]
+    assert "kernel_ms" in line["roofline_batches"]["T100"], "the other legs still run"
+    assert "failure injected" in run.stderr
+
+
+@pytest.mark.gpu
 def test_sharded_export_matches_single_rank(tmp_path):
     """``ExportData`` with three ranks (leaf-cell shards: every rank interpolates its compact, cost-balanced share of the
     cells and of the vertices from the source rows that share references, one all-gather, rank 0 writes) produces the

@@ -148,22 +148,26 @@ gram_reduce_kernel(const double *__restrict__ partial, const int2 *__restrict__ 
 // 128 x 128 block of C; per step 16 columns of L and 16 rows of B go through LDS -- the L tile transposed on the way so that
 // both MFMA operands are read like the Gram kernel reads its panels (sA[k][row], sB[k][column]) -- each wavefront owns a
 // 64 x 64 quarter = 4 x 4 tiles of v_mfma_f64_16x16x4_f64; the raw loads of step s + 1 are issued before the MFMAs of step s.
-__global__ void __launch_bounds__(256, 2)      // 198 VGPRs; without the second bound the compiler takes 316 = one wavefront per SIMD: 31 instead of 44 TFLOP/s
+// NJ = 16-column tiles per wavefront and row of tiles: 4 -> a 128 x 128 block of C, 2 -> 128 x 64 (right-hand sides of up to 64
+// columns -- compute_svd(rank=50) -- would issue 128 columns' worth of MFMAs for 50 otherwise)
+template <int NJ>
+__global__ void __launch_bounds__(256, 2)      // 198 VGPRs at NJ = 4; without the second bound the compiler takes 316 = one wavefront per SIMD: 31 instead of 44 TFLOP/s
 centered_gemm_kernel(const double *__restrict__ l, int64_t m, int k, int64_t l_stride, const double *__restrict__ lmean,
                      const double *__restrict__ b, int n, const double *__restrict__ e, int64_t e_stride,
                      const double *__restrict__ emean, double *__restrict__ c) {
+    constexpr int BN = 32 * NJ;                      // columns of C per workgroup
     __shared__ double sA[2][GK][GLD];
     __shared__ double sB[2][GK][GLD];
     const int64_t m0 = (int64_t)blockIdx.x * GB;
-    const int n0 = blockIdx.y * GB;
+    const int n0 = blockIdx.y * BN;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wi = wave >> 1, wj = wave & 1;
 
-    double4_t acc[4][4];
+    double4_t acc[4][NJ];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[a][q] = double4_t{0.0, 0.0, 0.0, 0.0};
+        for (int q = 0; q < NJ; ++q) acc[a][q] = double4_t{0.0, 0.0, 0.0, 0.0};
 
     // staging roles.  L: two threads per row of the block, eight consecutive columns each (64 contiguous bytes), written
     // transposed; B: sixteen threads per row of the step, four pieces of two columns (like the Gram kernel's panels)
@@ -173,7 +177,7 @@ centered_gemm_kernel(const double *__restrict__ l, int64_t m, int k, int64_t l_s
     const double mu = row_ok && lmean ? lmean[row_l] : 0.0;
     const double *lr = l + (row_ok ? row_l : 0) * l_stride;
     const int brow = threadIdx.x >> 4, c2 = (threadIdx.x & 15) * 2;
-    double ra[8], rb[4][2];
+    double ra[8], rb[NJ][2];
     auto load = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -183,7 +187,7 @@ centered_gemm_kernel(const double *__restrict__ l, int64_t m, int k, int64_t l_s
         const int kb = k0 + brow;
         const double *br = b + (int64_t)(kb < k ? kb : 0) * n;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
+        for (int p = 0; p < NJ; ++p) {
             const int cb = n0 + c2 + 32 * p;
             rb[p][0] = kb < k && cb < n ? br[cb] : 0.0;
             rb[p][1] = kb < k && cb + 1 < n ? br[cb + 1] : 0.0;
@@ -193,7 +197,7 @@ centered_gemm_kernel(const double *__restrict__ l, int64_t m, int k, int64_t l_s
 #pragma unroll
         for (int i = 0; i < 8; ++i) sA[buf][lk + i][lrow] = ra[i];
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
+        for (int p = 0; p < NJ; ++p) {
             sB[buf][brow][c2 + 32 * p] = rb[p][0];
             sB[buf][brow][c2 + 32 * p + 1] = rb[p][1];
         }
@@ -211,16 +215,15 @@ centered_gemm_kernel(const double *__restrict__ l, int64_t m, int k, int64_t l_s
 #pragma unroll
         for (int k4 = 0; k4 < GK / 4; ++k4) {
             const int kr = k4 * 4 + (lane >> 4), cl = lane & 15;
-            double a[4], bb[4];
+            double a[4], bb[NJ];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                a[i] = pa[kr][wi * 64 + i * 16 + cl];
-                bb[i] = pb[kr][wj * 64 + i * 16 + cl];
-            }
+            for (int i = 0; i < 4; ++i) a[i] = pa[kr][wi * 64 + i * 16 + cl];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) bb[j] = pb[kr][wj * (16 * NJ) + j * 16 + cl];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bb[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bb[j], acc[i][j], 0, 0, 0);
         }
         if (more) store(buf ^ 1);
         __syncthreads();
@@ -236,8 +239,8 @@ centered_gemm_kernel(const double *__restrict__ l, int64_t m, int k, int64_t l_s
             if (gr >= m) continue;
             const double em = e && emean ? emean[gr] : 0.0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int gc = n0 + wj * 64 + j * 16 + (lane & 15);
+            for (int j = 0; j < NJ; ++j) {
+                const int gc = n0 + wj * (16 * NJ) + j * 16 + (lane & 15);
                 if (gc >= n) continue;
                 const double v = acc[i][j][r];
                 c[gr * n + gc] = e ? (e[gr * e_stride + gc] - em) - v : v;
@@ -256,10 +259,16 @@ int s3_centered_gemm(const double *d_l, int64_t m, int64_t k, int64_t l_stride, 
     S3_REQUIRE(d_l && d_b && d_c, "s3_centered_gemm: null array");
     S3_REQUIRE(m >= 1 && k >= 1 && n >= 1 && k < (1 << 24) && n < (1 << 24) && l_stride >= k && (d_e == nullptr || e_stride >= n),
                "s3_centered_gemm: bad sizes (m %lld, k %lld, n %lld)", (long long)m, (long long)k, (long long)n);
-    const int64_t gx = (m + GB - 1) / GB, gy = (n + GB - 1) / GB;
+    const bool narrow = n <= 64;                     // (one 64-column block: half the MFMAs of a 128-column one)
+    const int64_t bn = narrow ? 64 : GB;
+    const int64_t gx = (m + GB - 1) / GB, gy = (n + bn - 1) / bn;
     S3_REQUIRE(gx < ((int64_t)1 << 31) && gy <= 65535, "s3_centered_gemm: shape too large for one launch");
-    centered_gemm_kernel<<<dim3((unsigned)gx, (unsigned)gy), 256, 0, as_stream(stream)>>>(d_l, m, (int)k, l_stride, d_lmean, d_b,
-                                                                                         (int)n, d_e, e_stride, d_emean, d_c);
+    if (narrow)
+        centered_gemm_kernel<2><<<dim3((unsigned)gx, (unsigned)gy), 256, 0, as_stream(stream)>>>(d_l, m, (int)k, l_stride, d_lmean, d_b,
+                                                                                                (int)n, d_e, e_stride, d_emean, d_c);
+    else
+        centered_gemm_kernel<4><<<dim3((unsigned)gx, (unsigned)gy), 256, 0, as_stream(stream)>>>(d_l, m, (int)k, l_stride, d_lmean, d_b,
+                                                                                                (int)n, d_e, e_stride, d_emean, d_c);
     S3_LAUNCH_CHECK();
     return S3_OK;
 }

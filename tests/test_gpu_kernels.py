@@ -789,7 +789,8 @@ def test_compute_svd_vs_torch(shape, rank):
     assert (recon - best).abs().max() <= 1e-8 * s_ref[0]
 
 
-@pytest.mark.parametrize("m,k,n,pitch", [(1000, 40, 7, 0), (3001, 130, 130, 6), (257, 5, 300, 3), (5000, 1000, 50, 0), (129, 17, 129, 0)])
+@pytest.mark.parametrize("m,k,n,pitch", [(1000, 40, 7, 0), (3001, 130, 130, 6), (257, 5, 300, 3), (5000, 1000, 50, 0), (129, 17, 129, 0),
+                                         (700, 33, 64, 2), (700, 33, 65, 2), (130, 260, 33, 5), (64, 16, 1, 0)])
 def test_centered_gemm_vs_torch(ops, m, k, n, pitch):
     """s3_centered_gemm (f64 matrix cores): the mode GEMM (X - mean 1^T) B of compute_svd (reference utils.py:302-346 takes U from
     the SVD) and the residual form (E - emean 1^T) - (L - lmean 1^T) B, pitched rows, ragged tiles -- against torch float64"""

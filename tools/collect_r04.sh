@@ -22,4 +22,8 @@ if [ "$lease" = "1" ]; then
     python tools/e2e_probe.py 200 > $out/e2e_probe_T200.txt 2>&1
     python tools/e2e_probe.py 25 12 > $out/e2e_probe_T25.txt 2>&1
     python tools/transport_probe.py 1.0 > $out/transport_probe.txt 2>&1
+    python tools/svd_breakdown.py > $out/svd_breakdown.txt 2>&1
+    python tools/file_probe.py 25 16 > $out/file_probe.txt 2>&1
+    python tools/ab_plan.py "tc64:;tc128:S3_TILE_CELLS=128" 5 10 > $out/ab_tile_cells.txt 2>&1
+    hipcc --offload-arch=gfx950 -O3 -o /tmp/s3_gather_probe tools/gather_probe.hip > /dev/null 2>&1 && /tmp/s3_gather_probe > $out/gather_probe.txt 2>&1
 fi

@@ -22,6 +22,12 @@
 // HBM/L2 traffic per tile-chunk drops from n_cells*k segments to n_distinct segments (2.5-3x fewer on the cylinder3D
 // workload), which moves the kernel from the Infinity-Cache gather bound towards the HBM bound.
 #include "common.h"
+#ifdef S3_PROBE_STAMPS
+__device__ long long s3_probe_stamps[1024 * 4 * 8];
+#define S3_STAMP(V) const long long V = __builtin_amdgcn_s_memrealtime();
+#else
+#define S3_STAMP(V)
+#endif
 #include "plan_build.h"
 
 #include <algorithm>
@@ -41,6 +47,7 @@ struct s3_interp_plan : s3::PlanTables {
     int64_t n_table = 0;                 // rows of that table
     int32_t *sched_begin = nullptr;      // [sched_wgs + 1] tile lists of the persistent workgroups (plan_schedule)
     int32_t *sched_tiles = nullptr;      // [n_tiles]
+    int4 *sched_desc = nullptr;          // [n_tiles] in list order: {first row, rows, first cell, cells} of each scheduled tile
     int sched_wgs = 0;
 };
 
@@ -683,12 +690,19 @@ struct StreamLayoutUnaligned { static constexpr int CHUNK_VECS = 7, LP = 9, VOFF
 // chunk kernel above, two workgroups per CU each waiting for its own start-up, moves 3.1 TB/s.  Here the workgroups are
 // PERSISTENT (two per CU) and walk a flat sequence of (tile, chunk) steps with everything the next step needs already
 // on its way while the current one is accumulated:
-//   * row segments of step s+1: sixteen named registers per lane, issued right after the barrier of step s;
+//   * row segments of step s+1: sixteen named registers per lane, issued BETWEEN the neighbour pairs of step s's accumulate phase
+//     (r4; before: all sixteen right after the barrier.  A CU accepts only so many line requests at a time: the sixteen gathers of a
+//     lane took 2.4-3.7 us to issue, during which the wavefront -- in order -- could not start its conversions and FMAs; s_memrealtime
+//     stamps, tools/stream_phases.sh.  Spread over the phase the requests drain while the wavefront computes);
 //   * weights / positions of the next tile: in REGISTERS, shared by the four lanes of a cell (each lane loads every fourth
 //     entry of its cell, the DPP quad broadcasts them when the neighbour's turn comes) -- LDS holds row data only, so there
 //     is nothing to double-buffer there;
 //   * row ids of the tile after next: two coalesced loads per lane, handed to the staging lanes through 2 KiB of LDS when
-//     the issue pointer enters that tile.
+//     the issue pointer enters that tile;
+//   * (r4) what the kernel needs to know of the tiles ahead -- first row, rows, first cell, cells -- comes from a descriptor list
+//     in the workgroup's own order (plan_schedule), fetched a tile early with a VECTOR load: looked up through the tile id it was
+//     a chain of dependent scalar loads in front of the accumulate phase, and a scalar load in flight turns every LDS wait of
+//     that phase into lgkmcnt(0).
 // s_waitcnt vmcnt counts loads AND stores in issue order, and the compiler takes the smallest count over all paths that
 // reach a use: a step must therefore issue the same number of vector-memory instructions on every path, or the wait for
 // the next step's first row segment silently becomes a wait for this step's output stores (that version ran no faster
@@ -761,29 +775,33 @@ __device__ __forceinline__ void stream_fma_row(double wm, const double2 &a, cons
 
 // BOTH = false: the upper four vectors of the chunk lie beyond the end of the row (the last chunk of a ragged row) -- nobody
 // reads or accumulates them
-template <int M, int K, bool BOTH, typename T, typename LAY>
+// `issue(slot)`: the row-segment loads of the NEXT step that belong to neighbour pair `slot` -- the sixteen loads of a lane are spread
+// over the pairs of the accumulate phase instead of standing in front of it: a CU accepts only so many line requests at a time, the
+// issue of sixteen gathers per lane blocks for 2-4 us (s_memrealtime stamps, tools/stream_phases.sh) and the wavefront, in-order,
+// cannot start its conversions and FMAs behind it; between the pairs the requests drain while the wavefront computes.
+template <int M, int K, bool BOTH, typename T, typename LAY, typename ISSUE>
 __device__ __forceinline__ void stream_accumulate(const double (&wq)[(K + 3) / 4], const int (&pq)[(K + 3) / 4],
                                                   const typename Vec16<T>::type *__restrict__ s_data, int v0,
                                                   typename Vec16<T>::type (&cur)[4], typename Vec16<T>::type (&nxt)[4],
-                                                  double (&acc0)[Vec16<T>::N], double (&acc1)[Vec16<T>::N]) {
+                                                  double (&acc0)[Vec16<T>::N], double (&acc1)[Vec16<T>::N], ISSUE &issue) {
     if constexpr (M < K) {
         stream_read_pair<M + 2, K, BOTH, T, LAY>(pq, s_data, v0, nxt);
+        issue(std::integral_constant<int, M / 2>{});
         __builtin_amdgcn_sched_barrier(0);
         stream_fma_row<BOTH>(quad_bcast_f64<M % 4>(wq[M / 4]), cur[0], cur[1], acc0, acc1);
         if constexpr (M + 1 < K) stream_fma_row<BOTH>(quad_bcast_f64<(M + 1) % 4>(wq[(M + 1) / 4]), cur[2], cur[3], acc0, acc1);
         __builtin_amdgcn_sched_barrier(0);
-        stream_accumulate<M + 2, K, BOTH, T, LAY>(wq, pq, s_data, v0, nxt, cur, acc0, acc1);
+        stream_accumulate<M + 2, K, BOTH, T, LAY>(wq, pq, s_data, v0, nxt, cur, acc0, acc1, issue);
     }
 }
 
 template <typename T, int K, bool ALIGNED, bool EVEN>
 __global__ void __launch_bounds__(256, 2)
-interp_planned_stream_kernel(const int32_t *__restrict__ perm, const int32_t *__restrict__ tile_cell_begin,
-                             const int32_t *__restrict__ tile_row_begin, const int32_t *__restrict__ rows,
+interp_planned_stream_kernel(const int32_t *__restrict__ perm, const int32_t *__restrict__ rows,
                              const uint16_t *__restrict__ loc, const double *__restrict__ w /*plan order*/,
                              const T *__restrict__ data, int64_t row_len, int64_t in_stride, double *__restrict__ out,
                              double *__restrict__ dump, const int32_t *__restrict__ sched_begin,
-                             const int32_t *__restrict__ sched_tiles, int n_chunks) {
+                             const int4 *__restrict__ sched_desc, int n_chunks) {
     using V = typename Vec16<T>::type;
     using LAY = std::conditional_t<ALIGNED, StreamLayoutAligned, StreamLayoutUnaligned>;
     constexpr int EPV = Vec16<T>::N;
@@ -795,11 +813,16 @@ interp_planned_stream_kernel(const int32_t *__restrict__ perm, const int32_t *__
     int32_t *s_ids = reinterpret_cast<int32_t *>(lds_raw + (size_t)PL_NP * RPP * LAY::LP);  // [2 * BLOCK] row ids of the issue tile
 
     const int tid = threadIdx.x;
-    // this workgroup's tiles: sched_tiles[my_begin .. my_begin + n_my) (plan_schedule below)
+    // this workgroup's tiles: the descriptors sched_desc[my_begin .. my_begin + n_my) = {first row, rows, first cell, cells}
+    // (plan_schedule below)
     const int my_begin = sched_begin[blockIdx.x], n_my = sched_begin[blockIdx.x + 1] - my_begin;
     if (n_my <= 0) return;
-    const int32_t *const my_tiles = sched_tiles + my_begin;
-    const int64_t first = my_tiles[0];
+    const int4 *const my_desc = sched_desc + my_begin;
+    // descriptor j of the list (clamped), fetched with a VECTOR load: it is counted by vmcnt, in order, behind loads that are waited
+    // for anyway -- a scalar load would have every LDS wait of the accumulate phase wait for it (lgkmcnt, out of order)
+    int lane_zero;                                   // (a zero the compiler cannot see through: keeps the address in a VGPR)
+    asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
+    auto desc_at = [&](int j) { return my_desc[min(j, n_my - 1) + lane_zero]; };
     const int srow = tid >> 3, svec = tid & 7;       // staging role: 8 lanes per 128-byte segment
     const int qcl = tid >> 2, v0 = tid & 3;          // accumulate role: 4 lanes per cell, vectors v0 and v0 + 4
     double *const dump_lane = dump + ((int64_t)blockIdx.x * BLOCK + tid) * 2;
@@ -815,14 +838,12 @@ interp_planned_stream_kernel(const int32_t *__restrict__ perm, const int32_t *__
     int celln = 0;                                   // (kept as loaded: a conversion here would wait for the load)
     int nc_c = 0, nc_n = 0, nr_n = 0;                // cells of the compute tile; cells / rows of the issue tile
 
-    auto load_ids = [&](int64_t tile) {
-        const int rb = tile_row_begin[tile], nr = tile_row_begin[tile + 1] - rb;
+    auto load_ids = [&](int rb, int nr) {
         ida = rows[rb + min(tid, nr - 1)];
         idb = rows[rb + min(BLOCK + tid, nr - 1)];
     };
-    auto load_tables = [&](int64_t tile) {
-        const int cb = tile_cell_begin[tile];
-        nc_n = tile_cell_begin[tile + 1] - cb;
+    auto load_tables = [&](int cb, int nc) {
+        nc_n = nc;
         const int cl = min(qcl, nc_n - 1);
         const double *wt = w + (int64_t)cb * k + cl;
         const uint16_t *lt = loc + (int64_t)cb * k + cl;
@@ -840,7 +861,10 @@ interp_planned_stream_kernel(const int32_t *__restrict__ perm, const int32_t *__
     // first block -- where the block lies wholly behind the chunk's last valid byte).
 #define S3S_LOAD(P)                                                                                                          \
     do {                                                                                                                     \
-        const T *a_ = data + (uint64_t)(uint32_t)rid##P * stride32 + c0_;                                                    \
+        int r_ = rid##P;                                                                                                     \
+        asm volatile("" : "+v"(r_));      /* the address is formed HERE: hoisted in front of the accumulate phase the sixteen \
+                                             64-bit addresses would cost 32 registers */                                     \
+        const T *a_ = data + (uint64_t)(uint32_t)r_ * stride32 + c0_;                                                        \
         if constexpr (ALIGNED) {                                                                                             \
             pre##P = *reinterpret_cast<const V *>(a_ + (ok_ ? svec : 0) * EPV);                                              \
         } else {                                                                                                             \
@@ -851,6 +875,7 @@ interp_planned_stream_kernel(const int32_t *__restrict__ perm, const int32_t *__
             pre##P = *reinterpret_cast<const V *>(reinterpret_cast<const char *>(a_) + (off_ < (int)valid_bytes_ ? off_ : -mis_)); \
         }                                                                                                                    \
     } while (0);
+#define S3S_LOAD_IF(P) if constexpr ((P * NS) / 16 == S) { S3S_LOAD(P) }
 #define S3S_ISSUE(CH)                                                                    \
     do {                                                                                 \
         const int64_t c0_ = (int64_t)(CH) * EPC;                                         \
@@ -873,24 +898,34 @@ interp_planned_stream_kernel(const int32_t *__restrict__ perm, const int32_t *__
         }                                                                                                                    \
     } while (0);
 
-    // prologue: the first tile's ids are the one exposed round trip of the workgroup
-    load_ids(first);
-    s_ids[tid] = ida;
-    s_ids[BLOCK + tid] = idb;
-    nr_n = tile_row_begin[first + 1] - tile_row_begin[first];
-    __syncthreads();
-    S3_REP16(S3S_RID)
-    __syncthreads();                                 // (the first step may already refill s_ids)
-    S3S_ISSUE(0);
-    load_tables(first);
-    if (n_my > 1) load_ids(my_tiles[1]);
-    int t_n1 = n_my > 1 ? my_tiles[1] : 0, t_n2 = n_my > 2 ? my_tiles[2] : 0;       // the next two tiles of the list
+    // prologue: the first tile's descriptor and ids are the exposed round trips of the workgroup
+    int4 d_next;                                     // descriptor of the tile the issue pointer enters next
+    int2 d_after;                                    // rows of the tile after that one (its ids are fetched a tile early)
+    {
+        const int4 d0 = desc_at(0);
+        d_next = desc_at(1);
+        const int4 d2 = desc_at(2);
+        d_after = make_int2(d2.x, d2.y);
+        load_ids(d0.x, d0.y);
+        s_ids[tid] = ida;
+        s_ids[BLOCK + tid] = idb;
+        nr_n = d0.y;
+        __syncthreads();
+        S3_REP16(S3S_RID)
+        __syncthreads();                             // (the first step may already refill s_ids)
+        load_tables(d0.z, d0.w);
+        if (n_my > 1) load_ids(d_next.x, d_next.y);
+        S3S_ISSUE(0);
+    }
     // as many stores behind these loads as behind the loads of a step of the loop, or the count of the loop's first wait
     // (the smallest over all ways into the loop) would be that of this prologue: every step would wait for its own stores
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < 8; ++i) *reinterpret_cast<volatile double *>(dump_lane) = 0.0;
 
+#ifdef S3_PROBE_STAMPS
+    long long pr_sum[7] = {0, 0, 0, 0, 0, 0, 0};
+#endif
     for (int j = 0; j < n_my; ++j) {
         // the tile whose steps are accumulated now: its tables arrived behind its first row segments
 #pragma unroll
@@ -906,26 +941,39 @@ interp_planned_stream_kernel(const int32_t *__restrict__ perm, const int32_t *__
             const bool enter_next = last_chunk && j + 1 < n_my;      // the issue pointer moves on to this workgroup's next tile
             const int64_t store_c0_ = (int64_t)c * EPC;
             (void)store_c0_;
+            S3_STAMP(ts0)
             S3_REP16(S3S_STORE)
             if (enter_next) {
                 s_ids[tid] = ida;
                 s_ids[BLOCK + tid] = idb;
             }
+            S3_STAMP(ts1)
             __syncthreads();
+            S3_STAMP(ts2)
             // ONE issue site for the row segments (two would look to the compiler as if the second could overwrite registers
             // the first has loads pending for: it then waits for vmcnt(0), i.e. for the previous step's stores)
-            const int64_t tile_n = t_n1;
-            if (enter_next) {
-                nr_n = tile_row_begin[tile_n + 1] - tile_row_begin[tile_n];
+            if (enter_next) {                        // (older than the row segments: waiting for a table never waits for a segment)
+                nr_n = d_next.y;
                 S3_REP16(S3S_RID)
+                load_tables(d_next.z, d_next.w);
+                if (j + 2 < n_my) load_ids(d_after.x, d_after.y);
+                d_next = desc_at(j + 2);             // consumed when the issue pointer moves on again: a tile's worth of steps away
+                const int4 d3 = desc_at(j + 3);
+                d_after = make_int2(d3.x, d3.y);
             }
-            if (enter_next || !last_chunk) S3S_ISSUE(enter_next ? 0 : c + 1);
-            if (enter_next) {
-                load_tables(tile_n);
-                if (j + 2 < n_my) load_ids(t_n2);
-                t_n1 = t_n2;
-                t_n2 = j + 3 < n_my ? my_tiles[j + 3] : 0;
-            }
+            // the next step's row segments: issued between the neighbour pairs of the accumulate phase below
+            // (unconditional: a branch per pair would cut the phase into basic blocks; the workgroup's very last step has no next
+            // step and fetches chunk 0 of its own rows once more -- one step's lines in nineteen or more, fresh in the L2)
+            const int64_t c0_ = (int64_t)(last_chunk ? 0 : c + 1) * EPC;
+            const bool ok_ = c0_ + (int64_t)svec * EPV < row_len;
+            const uintptr_t valid_bytes_ = (uintptr_t)min((int64_t)EPC, row_len - c0_) * sizeof(T);
+            (void)ok_; (void)valid_bytes_;
+            auto issue = [&](auto slot) __attribute__((always_inline)) {
+                // (f64 input: the accumulate phase has no registers to spare -- all sixteen loads go with the first pair)
+                constexpr int S = decltype(slot)::value, NS = sizeof(T) == 4 ? (K + 1) / 2 : 1;
+                S3_REP16(S3S_LOAD_IF)
+            };
+            S3_STAMP(ts3)
             const int64_t col0 = (int64_t)c * EPC;
             double acc0[EPV], acc1[EPV];
 #pragma unroll
@@ -933,11 +981,13 @@ interp_planned_stream_kernel(const int32_t *__restrict__ perm, const int32_t *__
             V buf_a[4], buf_b[4];
             if (col0 + 4 * EPV < row_len) {          // (uniform) vectors 4 .. of the chunk exist
                 stream_read_pair<0, K, true, T, LAY>(pq, s_data, v0, buf_a);
-                stream_accumulate<0, K, true, T, LAY>(wq, pq, s_data, v0, buf_a, buf_b, acc0, acc1);
+                stream_accumulate<0, K, true, T, LAY>(wq, pq, s_data, v0, buf_a, buf_b, acc0, acc1, issue);
             } else {
                 stream_read_pair<0, K, false, T, LAY>(pq, s_data, v0, buf_a);
-                stream_accumulate<0, K, false, T, LAY>(wq, pq, s_data, v0, buf_a, buf_b, acc0, acc1);
+                stream_accumulate<0, K, false, T, LAY>(wq, pq, s_data, v0, buf_a, buf_b, acc0, acc1, issue);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            S3_STAMP(ts4)
             // the same number of stores on every path: what must not be written goes to this lane's dump slot.  Pairs of
             // doubles; rows of odd length start on 8-byte boundaries only (element-aligned 16-byte stores) and end in a
             // single element, which one lane of the cell stores separately.
@@ -974,13 +1024,26 @@ interp_planned_stream_kernel(const int32_t *__restrict__ perm, const int32_t *__
                 double *pt = live && mine ? orow + t : dump_lane;
                 *pt = tv;
             }
+            S3_STAMP(ts5)
             __syncthreads();
+#ifdef S3_PROBE_STAMPS
+            {
+                const long long ts6 = __builtin_amdgcn_s_memrealtime();
+                pr_sum[0] += ts1 - ts0; pr_sum[1] += ts2 - ts1; pr_sum[2] += ts3 - ts2; pr_sum[3] += ts4 - ts3; pr_sum[4] += ts5 - ts4; pr_sum[5] += ts6 - ts5;
+                pr_sum[6] += 1;
+            }
+#endif
         }
     }
+#ifdef S3_PROBE_STAMPS
+    if ((tid & 63) == 0 && blockIdx.x < 1024)
+        for (int i = 0; i < 8; ++i) s3_probe_stamps[(blockIdx.x * 4 + (tid >> 6)) * 8 + i] = i < 7 ? pr_sum[i] : 0;
+#endif
 #undef S3S_DECL
 #undef S3S_RID
 #undef S3S_LOAD
 #undef S3S_ISSUE
+#undef S3S_LOAD_IF
 #undef S3S_STORE
 }
 
@@ -1098,6 +1161,16 @@ static int plan_schedule(s3_interp_plan *p, hipStream_t st) {
     }
     S3_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&p->sched_tiles), sizeof(int32_t) * std::max<size_t>(nt, 1)));
     S3_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&p->sched_begin), sizeof(int32_t) * ((size_t)wgs + 1)));
+    // what the persistent kernel needs to know of a tile, in list order: the descriptors of the tiles ahead sit at known
+    // addresses and are fetched a whole step early (looked up through the tile id they were a chain of two dependent round trips
+    // per tile, in front of the accumulate phase)
+    std::vector<int4> desc(std::max<size_t>(nt, 1));
+    for (size_t i = 0; i < tiles.size(); ++i) {
+        const int32_t t = tiles[i];
+        desc[i] = make_int4(rb[t], rb[t + 1] - rb[t], cb[t], cb[t + 1] - cb[t]);
+    }
+    S3_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&p->sched_desc), sizeof(int4) * desc.size()));
+    S3_HIP_CHECK(hipMemcpyAsync(p->sched_desc, desc.data(), sizeof(int4) * desc.size(), hipMemcpyHostToDevice, st));
     S3_HIP_CHECK(hipMemcpyAsync(p->sched_tiles, tiles.data(), sizeof(int32_t) * nt, hipMemcpyHostToDevice, st));
     S3_HIP_CHECK(hipMemcpyAsync(p->sched_begin, begin.data(), sizeof(int32_t) * ((size_t)wgs + 1), hipMemcpyHostToDevice, st));
     S3_HIP_CHECK(hipStreamSynchronize(st));
@@ -1129,9 +1202,9 @@ static int launch_stream_e(s3_interp_plan *p, const int32_t *rows, const void *d
         auto kern = interp_planned_stream_kernel<T, K, ALIGNED, EVEN>;                                                             \
         S3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,   \
                                          (int)lds));                                                                          \
-        kern<<<dim3((unsigned)p->sched_wgs), 256, lds, st>>>(p->perm, p->tile_cell_begin, p->tile_row_begin, rows, p->loc,    \
+        kern<<<dim3((unsigned)p->sched_wgs), 256, lds, st>>>(p->perm, rows, p->loc,                                           \
                                                             p->wp, static_cast<const T *>(data), row_len, in_stride,           \
-                                                            out, p->dump, p->sched_begin, p->sched_tiles, n_chunks);          \
+                                                            out, p->dump, p->sched_begin, p->sched_desc, n_chunks);           \
     } while (0)
     if (p->k == 8) S3_LAUNCH_STREAM(8);
     else S3_LAUNCH_STREAM(26);
@@ -1258,6 +1331,10 @@ static int launch_planned(s3_interp_plan *p, const int32_t *rows, int64_t n_rows
 
 extern "C" {
 
+#ifdef S3_PROBE_STAMPS
+int s3_probe_read(long long *h, int n) { return (int)hipMemcpyFromSymbol(h, HIP_SYMBOL(s3_probe_stamps), sizeof(long long) * n); }
+#endif
+
 void s3_interp_plan_destroy(s3_interp_plan *p) {
     if (!p) return;
     if (p->perm) (void)hipFree(p->perm);
@@ -1270,6 +1347,7 @@ void s3_interp_plan_destroy(s3_interp_plan *p) {
     if (p->rows_src) (void)hipFree(p->rows_src);
     if (p->sched_begin) (void)hipFree(p->sched_begin);
     if (p->sched_tiles) (void)hipFree(p->sched_tiles);
+    if (p->sched_desc) (void)hipFree(p->sched_desc);
     delete p;
 }
 

@@ -311,8 +311,8 @@ def planned_kernel_name(t_elems, k, plan_tiles, pitch_elems=None):
                 else "interp_planned_short_reg_kernel<float,26>")
     chunks = (t_elems + 31) // 32
     shift = pitch % 32 != 0 and os.environ.get("S3_INPLACE_SHIFT", "1") != "0"     # rows off the 128-byte grid: whole lines, phase undone in LDS
-    if (chunks <= int(os.environ.get("S3_STREAM_MAX_CHUNKS", "8")) and k in (8, 26) and plan_tiles >= int(os.environ.get("S3_STREAM_MIN_TILES", "64"))
-            and not (shift and chunks >= int(os.environ.get("S3_SHIFT_MIN_CHUNKS", "3")))):
+    if (chunks <= int(os.environ.get("S3_STREAM_MAX_CHUNKS", "24")) and k in (8, 26) and plan_tiles >= int(os.environ.get("S3_STREAM_MIN_TILES", "64"))
+            and not (shift and chunks >= int(os.environ.get("S3_SHIFT_MIN_CHUNKS", "6")))):
         return f"interp_planned_stream_kernel<float,{k},true,{even}>"
     if shift:
         return "interp_planned_shift_kernel<float>"

@@ -1085,10 +1085,13 @@ static int plan_ucap(int k, int tc) {
 using namespace s3;
 
 // the persistent kernel (interp_planned_stream_kernel) takes batches of up to this many 128-byte column chunks per row
-// (S3_STREAM_MAX_CHUNKS overrides; 0 switches it off) on plans with at least S3_STREAM_MIN_TILES tiles
+// (S3_STREAM_MAX_CHUNKS overrides; 0 switches it off) on plans with at least S3_STREAM_MIN_TILES tiles.  24 (r4; 8 before the
+// segment loads were spread over its accumulate phase): rows on the line grid, cylinder3D plan, one process -- 288 / 320 / 384 /
+// 512 / 768 snapshots 1.049 / 1.046 / 1.259 / 1.767 / 2.478 ms against 1.117 / 1.090 / 1.307 / 1.841 / 2.608 with the chunk kernel;
+// 1000 snapshots (32 chunks) 3.689 against 3.529: the long sweeps stay with the chunk kernel's two chunks of prefetch
 static int stream_max_chunks() {
     const char *e = getenv("S3_STREAM_MAX_CHUNKS");
-    return e ? atoi(e) : 8;
+    return e ? atoi(e) : 24;
 }
 static int64_t stream_min_tiles() {
     const char *e = getenv("S3_STREAM_MIN_TILES");
@@ -1098,9 +1101,12 @@ static int inplace_shift() {                 // 0: never (A/B runs), 1: rows off
     const char *e = getenv("S3_INPLACE_SHIFT");
     return e ? atoi(e) : 1;
 }
+// rows OFF the line grid of at least this many chunks take the shift kernel (whole aligned lines), shorter ones the persistent
+// kernel with straddling segments.  6 (r4; 3 before): dense rows of 68 / 100 / 136 / 200 / 300 / 600 snapshots (3 / 4 / 5 / 7 / 10 /
+// 19 chunks), one process: shift 0.409 / 0.535 / 0.618 / 0.842 / 1.214 / 2.176 ms, persistent 0.372 / 0.535 / 0.605 / 0.862 / 1.362 / 2.531
 static int shift_min_chunks() {
     const char *e = getenv("S3_SHIFT_MIN_CHUNKS");
-    return e ? atoi(e) : 3;
+    return e ? atoi(e) : 6;
 }
 static int stream_workgroups() {
     static const int v = [] {

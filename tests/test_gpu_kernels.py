@@ -257,6 +257,8 @@ def test_interp_src_reads_the_full_table_in_place(ops, orc, row_len, dtype):
     (1000, pt.float32, "dense"),        # 4000-byte rows: starts 0 / 32 / 64 / 96 bytes into a line (the bench's batch)
     (1004, pt.float32, "dense"),        # 4016-byte rows: every phase 0 .. 7
     (300, pt.float32, "dense"),         # ten chunks, the last one a 48-byte tail
+    (200, pt.float32, "dense"),         # seven chunks: the shortest rows that take the shift kernel (S3_SHIFT_MIN_CHUNKS = 6) ...
+    (152, pt.float32, "dense"),         # ... and five: the persistent kernel with straddling segments
     (1001, pt.float32, "pitch+3"),      # ragged rows in a 16-byte pitch
     (514, pt.float64, "dense"),         # f64: 4112-byte rows
     (1000, pt.float32, "offset16"),     # the table starts 16 bytes into a line

@@ -48,6 +48,8 @@ struct s3_interp_plan : s3::PlanTables {
     int32_t *sched_begin = nullptr;      // [sched_wgs + 1] tile lists of the persistent workgroups (plan_schedule)
     int32_t *sched_tiles = nullptr;      // [n_tiles]
     int4 *sched_desc = nullptr;          // [n_tiles] in list order: {first row, rows, first cell, cells} of each scheduled tile
+    double *wl = nullptr;                // the weights and
+    uint16_t *pl = nullptr;              // positions again, in the order the persistent kernel's LANES take them (lane_tables_*)
     int sched_wgs = 0;
 };
 
@@ -147,6 +149,36 @@ permute_weights_kernel(const int32_t *__restrict__ perm, const int32_t *__restri
     for (int i = threadIdx.x; i < n_c * k; i += 256) {
         const int m = i / n_c, j = i - m * n_c;
         wp[(int64_t)c_begin * k + i] = w[(int64_t)perm[c_begin + j] * k + m];
+    }
+}
+
+// The persistent kernel keeps a tile's tables in registers: lane (cell, v0) of a cell's DPP quad holds the entries m = 4 i + v0.  Read
+// from the [m][cell] layout above that is 2 * ceil(k / 4) loads of 8 and 2 bytes per lane and tile -- fourteen vector-memory
+// instructions at k = 26, as many as the tile's row segments take when a row is one chunk long, and the number of those a CU has
+// accepted is what paces a step.  Second copy in LANE order: per tile and lane the weights as ceil(KQ / 2) 16-byte
+// vectors ([vector][lane]: a wavefront's load is one contiguous KiB) and the positions as ONE vector of eight 16-bit entries.
+//   wl: tile offset c_begin * 4 * NV * 2 doubles, then [j < NV][lane < 4 n_c][2];  pl: c_begin * 32 entries, then [lane][8]
+__global__ void __launch_bounds__(256)
+lane_weights_kernel(const int32_t *__restrict__ tile_cell_begin, const double *__restrict__ wp, int k, double *__restrict__ wl) {
+    const int c_begin = tile_cell_begin[blockIdx.x], n_c = tile_cell_begin[blockIdx.x + 1] - c_begin;
+    const int kq = (k + 3) / 4, nv = (kq + 1) / 2, lanes = n_c * 4;
+    const double *src = wp + (int64_t)c_begin * k;
+    double *dst = wl + (int64_t)c_begin * 4 * nv * 2;
+    for (int e = threadIdx.x; e < lanes * nv * 2; e += 256) {
+        const int j = e / (lanes * 2), r = e - j * lanes * 2, lane = r >> 1, i = 2 * j + (r & 1);
+        const int m = i * 4 + (lane & 3);
+        dst[e] = i < kq ? src[(m < k ? m : 0) * n_c + (lane >> 2)] : 0.0;          // (entries beyond k: entry 0, as the kernel clamps)
+    }
+}
+__global__ void __launch_bounds__(256)
+lane_positions_kernel(const int32_t *__restrict__ tile_cell_begin, const uint16_t *__restrict__ loc, int k, uint16_t *__restrict__ pl) {
+    const int c_begin = tile_cell_begin[blockIdx.x], n_c = tile_cell_begin[blockIdx.x + 1] - c_begin;
+    const int kq = (k + 3) / 4;
+    const uint16_t *src = loc + (int64_t)c_begin * k;
+    uint16_t *dst = pl + (int64_t)c_begin * 32;
+    for (int e = threadIdx.x; e < n_c * 32; e += 256) {
+        const int lane = e >> 3, i = e & 7, m = i * 4 + (lane & 3);
+        dst[e] = i < kq ? src[(m < k ? m : 0) * n_c + (lane >> 2)] : (uint16_t)0;
     }
 }
 
@@ -798,7 +830,7 @@ __device__ __forceinline__ void stream_accumulate(const double (&wq)[(K + 3) / 4
 template <typename T, int K, bool ALIGNED, bool EVEN>
 __global__ void __launch_bounds__(256, 2)
 interp_planned_stream_kernel(const int32_t *__restrict__ perm, const int32_t *__restrict__ rows,
-                             const uint16_t *__restrict__ loc, const double *__restrict__ w /*plan order*/,
+                             const uint16_t *__restrict__ pl, const double *__restrict__ wl /*lane order: lane_weights_kernel*/,
                              const T *__restrict__ data, int64_t row_len, int64_t in_stride, double *__restrict__ out,
                              double *__restrict__ dump, const int32_t *__restrict__ sched_begin,
                              const int4 *__restrict__ sched_desc, int n_chunks) {
@@ -833,7 +865,8 @@ interp_planned_stream_kernel(const int32_t *__restrict__ perm, const int32_t *__
     static_assert(PL_NP == 16, "S3_REP16 expands PL_NP staging passes");
     int ida = 0, idb = 0;                            // row ids of the tile after the issue tile (coalesced image)
     double wq[KQ], wqn[KQ];
-    int pq[KQ], pqn[KQ];
+    int pq[KQ];
+    uint4 pqn_raw;                                   // the next tile's positions as loaded: eight 16-bit entries
     int64_t cell = 0;
     int celln = 0;                                   // (kept as loaded: a conversion here would wait for the load)
     int nc_c = 0, nc_n = 0, nr_n = 0;                // cells of the compute tile; cells / rows of the issue tile
@@ -842,17 +875,19 @@ interp_planned_stream_kernel(const int32_t *__restrict__ perm, const int32_t *__
         ida = rows[rb + min(tid, nr - 1)];
         idb = rows[rb + min(BLOCK + tid, nr - 1)];
     };
+    constexpr int NV = (KQ + 1) / 2;                 // 16-byte vectors of weights per lane
+    typedef double wpair_t __attribute__((ext_vector_type(2)));
     auto load_tables = [&](int cb, int nc) {
         nc_n = nc;
-        const int cl = min(qcl, nc_n - 1);
-        const double *wt = w + (int64_t)cb * k + cl;
-        const uint16_t *lt = loc + (int64_t)cb * k + cl;
+        const int cl = min(qcl, nc_n - 1), lane4 = cl * 4 + v0, lanes = nc_n * 4;
+        const wpair_t *wv = reinterpret_cast<const wpair_t *>(wl + (int64_t)cb * (4 * NV * 2)) + lane4;
 #pragma unroll
-        for (int i = 0; i < KQ; ++i) {
-            const int m = i * 4 + v0, mm = m < k ? m : 0;
-            wqn[i] = wt[(int64_t)mm * nc_n];
-            pqn[i] = lt[(int64_t)mm * nc_n];
+        for (int j = 0; j < NV; ++j) {
+            const wpair_t two = wv[j * lanes];
+            wqn[2 * j] = two.x;
+            if (2 * j + 1 < KQ) wqn[2 * j + 1] = two.y;
         }
+        pqn_raw = reinterpret_cast<const uint4 *>(pl + (int64_t)cb * 32)[lane4];
         celln = perm[cb + cl];
     };
 #define S3S_RID(P) rid##P = s_ids[min(P * RPP + srow, nr_n - 1)];
@@ -931,7 +966,8 @@ interp_planned_stream_kernel(const int32_t *__restrict__ perm, const int32_t *__
 #pragma unroll
         for (int i = 0; i < KQ; ++i) {
             wq[i] = wqn[i];
-            pq[i] = pqn[i];
+            const uint32_t two = i < 2 ? pqn_raw.x : i < 4 ? pqn_raw.y : i < 6 ? pqn_raw.z : pqn_raw.w;
+            pq[i] = (int)((i & 1) ? two >> 16 : two & 0xffffu);
         }
         cell = celln;
         nc_c = nc_n;
@@ -1175,6 +1211,9 @@ static int plan_schedule(s3_interp_plan *p, hipStream_t st) {
         const int32_t t = tiles[i];
         desc[i] = make_int4(rb[t], rb[t + 1] - rb[t], cb[t], cb[t + 1] - cb[t]);
     }
+    S3_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&p->pl), sizeof(uint16_t) * (size_t)p->nc * 32));
+    lane_positions_kernel<<<(unsigned)p->n_tiles, 256, 0, st>>>(p->tile_cell_begin, p->loc, p->k, p->pl);
+    S3_LAUNCH_CHECK();
     S3_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&p->sched_desc), sizeof(int4) * desc.size()));
     S3_HIP_CHECK(hipMemcpyAsync(p->sched_desc, desc.data(), sizeof(int4) * desc.size(), hipMemcpyHostToDevice, st));
     S3_HIP_CHECK(hipMemcpyAsync(p->sched_tiles, tiles.data(), sizeof(int32_t) * nt, hipMemcpyHostToDevice, st));
@@ -1208,8 +1247,8 @@ static int launch_stream_e(s3_interp_plan *p, const int32_t *rows, const void *d
         auto kern = interp_planned_stream_kernel<T, K, ALIGNED, EVEN>;                                                             \
         S3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,   \
                                          (int)lds));                                                                          \
-        kern<<<dim3((unsigned)p->sched_wgs), 256, lds, st>>>(p->perm, rows, p->loc,                                           \
-                                                            p->wp, static_cast<const T *>(data), row_len, in_stride,           \
+        kern<<<dim3((unsigned)p->sched_wgs), 256, lds, st>>>(p->perm, rows, p->pl,                                            \
+                                                            p->wl, static_cast<const T *>(data), row_len, in_stride,           \
                                                             out, p->dump, p->sched_begin, p->sched_desc, n_chunks);           \
     } while (0)
     if (p->k == 8) S3_LAUNCH_STREAM(8);
@@ -1354,6 +1393,8 @@ void s3_interp_plan_destroy(s3_interp_plan *p) {
     if (p->sched_begin) (void)hipFree(p->sched_begin);
     if (p->sched_tiles) (void)hipFree(p->sched_tiles);
     if (p->sched_desc) (void)hipFree(p->sched_desc);
+    if (p->wl) (void)hipFree(p->wl);
+    if (p->pl) (void)hipFree(p->pl);
     delete p;
 }
 
@@ -1484,6 +1525,19 @@ int s3_interp_plan_set_weights(s3_interp_plan *p, const double *d_w, s3_stream s
     }
     permute_weights_kernel<<<(unsigned)p->n_tiles, 256, 0, as_stream(stream)>>>(p->perm, p->tile_cell_begin, d_w, p->k, p->wp);
     S3_LAUNCH_CHECK();
+    if (stream_can_take(p)) {                // the persistent kernel's copy, in lane order
+        const int nv = ((p->k + 3) / 4 + 1) / 2;
+        if (!p->wl) {
+            const hipError_t e = hipMalloc(reinterpret_cast<void **>(&p->wl), sizeof(double) * (size_t)p->nc * 4 * nv * 2);
+            if (e != hipSuccess) {
+                p->wl = nullptr;
+                s3::set_error("s3_interp_plan_set_weights: hipMalloc failed: %s", hipGetErrorString(e));
+                return e == hipErrorOutOfMemory ? S3_ENOMEM : S3_EHIP;
+            }
+        }
+        lane_weights_kernel<<<(unsigned)p->n_tiles, 256, 0, as_stream(stream)>>>(p->tile_cell_begin, p->wp, p->k, p->wl);
+        S3_LAUNCH_CHECK();
+    }
     p->has_weights = true;
     return S3_OK;
 }

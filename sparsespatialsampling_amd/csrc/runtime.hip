@@ -12,6 +12,10 @@
 #include <vector>
 
 #include <emmintrin.h>
+#include <pthread.h>
+#include <sched.h>
+#include <cstdio>
+#include <string>
 
 namespace s3 {
 static thread_local char g_err[512] = "";
@@ -115,6 +119,86 @@ bool upload_streaming_stores(int64_t total_bytes) {
     return v < 0 ? total_bytes >= ((int64_t)1 << 30) : v == 1;
 }
 
+// The host cores next to the GPU.  On a two-socket host a transfer thread on the far socket packs into pinned memory the DMA engine
+// reads across the socket link, and the Linux scheduler puts a process's threads on either socket as it likes: 25-snapshot batches
+// through ExportData took 7.6-8.2 ms per batch with the threads anywhere (or on the far socket) and 5.7-6.8 ms on the GPU's socket
+// (MI355X box, 2 x EPYC 9575F; tools/e2e_probe.py under taskset).  So the packing / draining threads of an upload or a download
+// -- and the calling thread for the duration of the call -- run on the CPUs of the GPU's NUMA node (PCI bus id ->
+// /sys/bus/pci/devices/<id>/numa_node -> /sys/devices/system/node/node<N>/cpulist), within the affinity mask the process was
+// given; the pinned staging buffers, allocated by such a thread, land on that node.  S3_NUMA_PIN=0 switches it off; anything
+// unreadable (no sysfs, one node, an empty intersection) leaves the threads alone.
+struct NodeCpus {
+    bool known = false;
+    cpu_set_t set;
+};
+const NodeCpus &gpu_node_cpus(int dev) {
+    static NodeCpus table[16];
+    static std::mutex m;
+    static bool tried[16] = {};
+    static const NodeCpus none{};
+    if (dev < 0 || dev >= 16) return none;
+    std::lock_guard<std::mutex> g(m);
+    if (tried[dev]) return table[dev];
+    tried[dev] = true;
+    const char *sw = getenv("S3_NUMA_PIN");
+    if (sw && sw[0] == '0') return table[dev];
+    char bus[64] = "";
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), dev) != hipSuccess) return table[dev];
+    for (char *c = bus; *c; ++c) *c = (char)tolower(*c);
+    int node = -1;
+    if (FILE *f = fopen((std::string("/sys/bus/pci/devices/") + bus + "/numa_node").c_str(), "r")) {
+        if (fscanf(f, "%d", &node) != 1) node = -1;
+        fclose(f);
+    }
+    if (node < 0) return table[dev];
+    char list[4096] = "";
+    if (FILE *f = fopen(("/sys/devices/system/node/node" + std::to_string(node) + "/cpulist").c_str(), "r")) {
+        if (!fgets(list, (int)sizeof(list), f)) list[0] = 0;
+        fclose(f);
+    }
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    int n_set = 0;
+    for (const char *c = list; *c;) {                        // "0-63,128-191"
+        char *end = nullptr;
+        const long a = strtol(c, &end, 10);
+        if (end == c) break;
+        long b = a;
+        c = end;
+        if (*c == '-') {
+            b = strtol(c + 1, &end, 10);
+            c = end;
+        }
+        for (long i = a; i <= b && i < CPU_SETSIZE; ++i) {
+            CPU_SET((int)i, &set);
+            ++n_set;
+        }
+        if (*c == ',') ++c;
+        else break;
+    }
+    if (n_set > 0) {
+        table[dev].set = set;
+        table[dev].known = true;
+    }
+    return table[dev];
+}
+// this thread onto the GPU's node (within its present mask); restores the mask when it goes out of scope if `restore`
+struct OnGpuNode {
+    cpu_set_t before;
+    bool changed = false, restore;
+    OnGpuNode(int dev, bool restore_) : restore(restore_) {
+        const NodeCpus &nc = gpu_node_cpus(dev);
+        if (!nc.known || pthread_getaffinity_np(pthread_self(), sizeof(before), &before) != 0) return;
+        cpu_set_t want;
+        CPU_AND(&want, &before, &nc.set);
+        if (CPU_COUNT(&want) == 0 || CPU_EQUAL(&want, &before)) return;
+        changed = pthread_setaffinity_np(pthread_self(), sizeof(want), &want) == 0;
+    }
+    ~OnGpuNode() {
+        if (changed && restore) (void)pthread_setaffinity_np(pthread_self(), sizeof(before), &before);
+    }
+};
+
 hipError_t upload_lane_init(UploadLane &l) {
     for (int b = 0; b < UP_BUFS; ++b) {
         if (!l.pinned[b]) {
@@ -153,6 +237,7 @@ static int upload_rows_impl(const void *h_src, const int32_t *h_rows, int64_t n_
     std::lock_guard<std::mutex> guard(g_upload_mutex);
     int dev = 0;
     S3_HIP_CHECK(hipGetDevice(&dev));
+    OnGpuNode caller_near(dev, true);                // (also while the lanes' pinned buffers are allocated: first touch)
     // chunk = what one thread packs before its transfer is queued.  No transfer can start before somebody's first chunk is
     // packed (~0.4 ms per MB and thread), so the first round of chunks is small and the rounds double up to 8 MB: the 243 MB of
     // a 25-snapshot batch used to be thirty 8-MB chunks packed side by side and THEN sent (7.5 ms where the link needs 4.3).
@@ -174,6 +259,7 @@ static int upload_rows_impl(const void *h_src, const int32_t *h_rows, int64_t n_
     std::atomic<int64_t> next{0};
     std::atomic<int> first_error{(int)hipSuccess};
     auto work = [&](int t) {
+        OnGpuNode near(dev, false);
         if (hipSetDevice(dev) != hipSuccess) { first_error = (int)hipErrorInvalidDevice; return; }
         UploadLane &l = g_lanes[t];
         int b = l.next;
@@ -292,6 +378,7 @@ int s3_download(void *h_dst, const void *d_src, size_t bytes, s3_stream stream) 
     std::lock_guard<std::mutex> guard(g_upload_mutex);
     int dev = 0;
     S3_HIP_CHECK(hipGetDevice(&dev));
+    OnGpuNode caller_near(dev, true);
     S3_HIP_CHECK(hipStreamSynchronize(st));                              // the source is complete; lanes use their own order
     const int64_t n_chunks = (int64_t)((bytes + UP_CHUNK_BYTES - 1) / UP_CHUNK_BYTES);
     const int n_thr = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)8, (int64_t)upload_threads(), n_chunks / 2}));
@@ -299,6 +386,7 @@ int s3_download(void *h_dst, const void *d_src, size_t bytes, s3_stream stream) 
     std::atomic<int64_t> next{0};
     std::atomic<int> first_error{(int)hipSuccess};
     auto work = [&](int t) {
+        OnGpuNode near(dev, false);
         if (hipSetDevice(dev) != hipSuccess) { first_error = (int)hipErrorInvalidDevice; return; }
         UploadLane &l = g_lanes[t];
         hipStream_t own = nullptr;

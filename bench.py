@@ -298,14 +298,17 @@ def ms_stats(ms):
                 kernel_ms_max=float(np.max(ms)), launches=len(ms))
 
 
-def planned_kernel_name(t_elems, k, plan_tiles, pitch_elems=None):
+def planned_kernel_name(t_elems, k, plan_tiles, pitch_elems=None, table_bytes=0):
     """the kernel s3_interp_planned / s3_interp_planned_src dispatches a batch of fp32 rows of t_elems elements with a row pitch
     of pitch_elems elements to (csrc/interp_plan.hip: planned_dispatch / launch_planned); None: whole 128-byte lines"""
     pitch = pitch_elems if pitch_elems is not None else (t_elems + 31) // 32 * 32
     even = "true" if t_elems % 2 == 0 else "false"
     if pitch % 4:                                                    # rows on element boundaries only: the persistent kernel
-        return f"interp_planned_stream_kernel<float,{k},false,{even}>"
+        return f"interp_planned_stream_kernel<float,{k},false,{even},false>"
     vecs = (t_elems + 3) // 4
+    if (2 <= vecs <= 4 and k in (8, 26) and plan_tiles >= int(os.environ.get("S3_STREAM_MIN_TILES", "64"))
+            and os.environ.get("S3_SHORT_STREAM", "1" if table_bytes <= 1 << 30 else "0") == "1"):
+        return f"interp_planned_stream_kernel<float,{k},true,{even},true>"       # the persistent kernel's narrow layout
     if vecs <= 4:
         return ("interp_planned_short_quad_kernel<float,7>" if vecs == 4 and not os.environ.get("S3_SHORT_NO_QUAD")
                 else "interp_planned_short_reg_kernel<float,26>")
@@ -313,7 +316,7 @@ def planned_kernel_name(t_elems, k, plan_tiles, pitch_elems=None):
     shift = pitch % 32 != 0 and os.environ.get("S3_INPLACE_SHIFT", "1") != "0"     # rows off the 128-byte grid: whole lines, phase undone in LDS
     if (chunks <= int(os.environ.get("S3_STREAM_MAX_CHUNKS", "24")) and k in (8, 26) and plan_tiles >= int(os.environ.get("S3_STREAM_MIN_TILES", "64"))
             and not (shift and chunks >= int(os.environ.get("S3_SHIFT_MIN_CHUNKS", "6")))):
-        return f"interp_planned_stream_kernel<float,{k},true,{even}>"
+        return f"interp_planned_stream_kernel<float,{k},true,{even},false>"
     if shift:
         return "interp_planned_shift_kernel<float>"
     return "interp_planned_kernel<float,64>"
@@ -331,7 +334,7 @@ def batch_record(hipops, plan, w, used, n_points, nc, k, row_len, label, workloa
     st = ms_stats(ms)
     traffic, src, stale = recorded_traffic(workload_key + "/inplace")
     rec = dict(rows=label + ", dense [N, L] batch of all points read in place", row_bytes=row_len * 4, pitch_bytes=row_len * 4,
-               kernel=planned_kernel_name(row_len, k, plan.n_tiles, row_len),
+               kernel=planned_kernel_name(row_len, k, plan.n_tiles, row_len, table_bytes=n_points * row_len * 4),
                algorithmic_bytes=b_alg, achieved=b_alg / (st["kernel_ms"] * 1e-3) / 1e9, unit="GB/s",
                frac=b_alg / (st["kernel_ms"] * 1e-3) / 8e12, frac_best_launch=b_alg / (st["kernel_ms_min"] * 1e-3) / 8e12,
                Gcells_snapshots_per_s=nc * row_len / (st["kernel_ms"] * 1e-3) / 1e9, traffic=traffic,
@@ -735,7 +738,7 @@ def main():
                          "copy_kernel_GBs": copy_bw, "frac_of_copy_kernel": achieved / copy_bw,
                          "traffic": traffic, "traffic_source": None if traffic is None else f"recorded, not measured in this run: {traffic_src}",
                          "traffic_stale": traffic_stale,
-                         "kernel": "interp_kernel<float,4>" if plan is None else planned_kernel_name(row_len, k, plan.n_tiles, row_len),
+                         "kernel": "interp_kernel<float,4>" if plan is None else planned_kernel_name(row_len, k, plan.n_tiles, row_len, table_bytes=len(x) * row_len * 4),
                          "staged_rows_per_launch": None if plan is None else plan.total_rows, **ms_stats(launch_ms),
                          "frac_best_launch": b_alg / (min(launch_ms) * 1e-3) / 8e12,
                          "algorithmic_bytes": b_alg, "resident_source_rows": n_rows, "cells_on_this_rank": nc,

@@ -713,8 +713,12 @@ interp_planned_shift_kernel(const int32_t *__restrict__ perm, const int32_t *__r
 // is undone on the way into LDS: four ds_write_b32 per lane at shifted positions (as cheap as the one ds_write_b128 they
 // replace) into a row image of 9 vectors, one vector of slack in front.  Nothing outside the 16-byte blocks that hold the
 // row's own bytes is read (aligned blocks never straddle a page).
-struct StreamLayoutAligned   { static constexpr int CHUNK_VECS = 8, LP = PL_LP, VOFF = 0; };
-struct StreamLayoutUnaligned { static constexpr int CHUNK_VECS = 7, LP = 9, VOFF = 1; };
+// LPR lanes stage a row (one 16-byte vector each), NPASS passes of 256 / LPR rows cover a tile's <= 512 rows
+struct StreamLayoutAligned   { static constexpr int CHUNK_VECS = 8, LP = PL_LP, VOFF = 0, LPR = 8, NPASS = 16; };
+struct StreamLayoutUnaligned { static constexpr int CHUNK_VECS = 7, LP = 9, VOFF = 1, LPR = 8, NPASS = 16; };
+// rows of at most four vectors (16 fp32 snapshots: SURVEY C4's batches): four lanes per row, eight passes -- half the gathers per
+// lane and step of the eight-vector layout, whose upper four lanes would fetch a dummy vector each
+struct StreamLayoutNarrow    { static constexpr int CHUNK_VECS = 4, LP = 4, VOFF = 0, LPR = 4, NPASS = 8; };
 
 // Short and medium batches (the reference exports cylinder3D in batches of 25 snapshots, examples/s3_for_cylinder3D_Re3900.py:
 // 28-69 -> utils.py:204: rows of 100 or 300 bytes): a tile has one to a few column chunks, so the start-up of a tile --
@@ -827,7 +831,7 @@ __device__ __forceinline__ void stream_accumulate(const double (&wq)[(K + 3) / 4
     }
 }
 
-template <typename T, int K, bool ALIGNED, bool EVEN>
+template <typename T, int K, bool ALIGNED, bool EVEN, bool NARROW = false>
 __global__ void __launch_bounds__(256, 2)
 interp_planned_stream_kernel(const int32_t *__restrict__ perm, const int32_t *__restrict__ rows,
                              const uint16_t *__restrict__ pl, const double *__restrict__ wl /*lane order: lane_weights_kernel*/,
@@ -835,14 +839,15 @@ interp_planned_stream_kernel(const int32_t *__restrict__ perm, const int32_t *__
                              double *__restrict__ dump, const int32_t *__restrict__ sched_begin,
                              const int4 *__restrict__ sched_desc, int n_chunks) {
     using V = typename Vec16<T>::type;
-    using LAY = std::conditional_t<ALIGNED, StreamLayoutAligned, StreamLayoutUnaligned>;
+    static_assert(!NARROW || ALIGNED, "the narrow layout takes rows on 16-byte boundaries");
+    using LAY = std::conditional_t<NARROW, StreamLayoutNarrow, std::conditional_t<ALIGNED, StreamLayoutAligned, StreamLayoutUnaligned>>;
     constexpr int EPV = Vec16<T>::N;
     constexpr int EPC = LAY::CHUNK_VECS * EPV;       // elements of a row per step
-    constexpr int BLOCK = 256, RPP = BLOCK / 8;
+    constexpr int BLOCK = 256, RPP = BLOCK / LAY::LPR, NPASS = LAY::NPASS;
     constexpr int KQ = (K + 3) / 4, k = K;           // every lane of a quad holds KQ entries of its cell's tables
     extern __shared__ float4 lds_raw[];
-    V *s_data = reinterpret_cast<V *>(lds_raw);                                           // [PL_NP * RPP][LP] 16-byte vectors
-    int32_t *s_ids = reinterpret_cast<int32_t *>(lds_raw + (size_t)PL_NP * RPP * LAY::LP);  // [2 * BLOCK] row ids of the issue tile
+    V *s_data = reinterpret_cast<V *>(lds_raw);                                           // [NPASS * RPP][LP] 16-byte vectors
+    int32_t *s_ids = reinterpret_cast<int32_t *>(lds_raw + (size_t)NPASS * RPP * LAY::LP);  // [2 * BLOCK] row ids of the issue tile
 
     const int tid = threadIdx.x;
     // this workgroup's tiles: the descriptors sched_desc[my_begin .. my_begin + n_my) = {first row, rows, first cell, cells}
@@ -855,7 +860,7 @@ interp_planned_stream_kernel(const int32_t *__restrict__ perm, const int32_t *__
     int lane_zero;                                   // (a zero the compiler cannot see through: keeps the address in a VGPR)
     asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
     auto desc_at = [&](int j) { return my_desc[min(j, n_my - 1) + lane_zero]; };
-    const int srow = tid >> 3, svec = tid & 7;       // staging role: 8 lanes per 128-byte segment
+    const int srow = tid / LAY::LPR, svec = tid % LAY::LPR;      // staging role: LPR lanes per row segment
     const int qcl = tid >> 2, v0 = tid & 3;          // accumulate role: 4 lanes per cell, vectors v0 and v0 + 4
     double *const dump_lane = dump + ((int64_t)blockIdx.x * BLOCK + tid) * 2;
     const uint32_t stride32 = (uint32_t)in_stride;   // (row pitch in elements < 2^31: one v_mad_u64_u32 per row address)
@@ -890,12 +895,12 @@ interp_planned_stream_kernel(const int32_t *__restrict__ perm, const int32_t *__
         pqn_raw = reinterpret_cast<const uint4 *>(pl + (int64_t)cb * 32)[lane4];
         celln = perm[cb + cl];
     };
-#define S3S_RID(P) rid##P = s_ids[min(P * RPP + srow, nr_n - 1)];
+#define S3S_RID(P) if constexpr (P < NPASS) rid##P = s_ids[min(P * RPP + srow, nr_n - 1)];
     // ALIGNED: lane svec loads vector svec of the chunk (a dummy -- the chunk's first vector -- beyond the end of the row).
     // Otherwise: the aligned 16-byte block number svec counted from the block that holds the chunk's first byte (a dummy -- that
     // first block -- where the block lies wholly behind the chunk's last valid byte).
 #define S3S_LOAD(P)                                                                                                          \
-    do {                                                                                                                     \
+    if constexpr (P < NPASS) {                                                                                               \
         int r_ = rid##P;                                                                                                     \
         asm volatile("" : "+v"(r_));      /* the address is formed HERE: hoisted in front of the accumulate phase the sixteen \
                                              64-bit addresses would cost 32 registers */                                     \
@@ -909,8 +914,8 @@ interp_planned_stream_kernel(const int32_t *__restrict__ perm, const int32_t *__
             const int off_ = 16 * svec - mis_;                                                                               \
             pre##P = *reinterpret_cast<const V *>(reinterpret_cast<const char *>(a_) + (off_ < (int)valid_bytes_ ? off_ : -mis_)); \
         }                                                                                                                    \
-    } while (0);
-#define S3S_LOAD_IF(P) if constexpr ((P * NS) / 16 == S) { S3S_LOAD(P) }
+    }
+#define S3S_LOAD_IF(P) if constexpr (P < NPASS && (P * NS) / NPASS == S) { S3S_LOAD(P) }
 #define S3S_ISSUE(CH)                                                                    \
     do {                                                                                 \
         const int64_t c0_ = (int64_t)(CH) * EPC;                                         \
@@ -921,7 +926,7 @@ interp_planned_stream_kernel(const int32_t *__restrict__ perm, const int32_t *__
     } while (0)
     // (the row ids in rid* are those the segments in pre* were loaded with: ids and segments are renewed together)
 #define S3S_STORE(P)                                                                                                         \
-    do {                                                                                                                     \
+    if constexpr (P < NPASS) {                                                                                               \
         if constexpr (ALIGNED) {                                                                                             \
             s_data[(P * RPP + srow) * LAY::LP + svec] = pre##P;                                                              \
         } else {                                                                                                             \
@@ -931,7 +936,7 @@ interp_planned_stream_kernel(const int32_t *__restrict__ perm, const int32_t *__
             const uint32_t *w_ = reinterpret_cast<const uint32_t *>(&pre##P);                                                \
             row_[0] = w_[0]; row_[1] = w_[1]; row_[2] = w_[2]; row_[3] = w_[3];                                              \
         }                                                                                                                    \
-    } while (0);
+    }
 
     // prologue: the first tile's descriptor and ids are the exposed round trips of the workgroup
     int4 d_next;                                     // descriptor of the tile the issue pointer enters next
@@ -1015,9 +1020,13 @@ interp_planned_stream_kernel(const int32_t *__restrict__ perm, const int32_t *__
 #pragma unroll
             for (int i = 0; i < EPV; ++i) acc0[i] = acc1[i] = 0.0;
             V buf_a[4], buf_b[4];
-            if (col0 + 4 * EPV < row_len) {          // (uniform) vectors 4 .. of the chunk exist
-                stream_read_pair<0, K, true, T, LAY>(pq, s_data, v0, buf_a);
-                stream_accumulate<0, K, true, T, LAY>(wq, pq, s_data, v0, buf_a, buf_b, acc0, acc1, issue);
+            bool upper = false;                      // (uniform) vectors 4 .. of the chunk exist
+            if constexpr (LAY::CHUNK_VECS > 4) upper = col0 + 4 * EPV < row_len;
+            if (upper) {
+                if constexpr (LAY::CHUNK_VECS > 4) {
+                    stream_read_pair<0, K, true, T, LAY>(pq, s_data, v0, buf_a);
+                    stream_accumulate<0, K, true, T, LAY>(wq, pq, s_data, v0, buf_a, buf_b, acc0, acc1, issue);
+                }
             } else {
                 stream_read_pair<0, K, false, T, LAY>(pq, s_data, v0, buf_a);
                 stream_accumulate<0, K, false, T, LAY>(wq, pq, s_data, v0, buf_a, buf_b, acc0, acc1, issue);
@@ -1037,11 +1046,13 @@ interp_planned_stream_kernel(const int32_t *__restrict__ perm, const int32_t *__
                 pair_t v = {acc0[i], acc0[i + 1]};
                 *reinterpret_cast<pair_t *>(p0) = v;
             }
+            if constexpr (LAY::CHUNK_VECS > 4) {
 #pragma unroll
-            for (int i = 0; i < EPV; i += 2) {
-                double *p1 = live && second && e1 + i + 1 < row_len ? orow + e1 + i : dump_lane;
-                pair_t v = {acc1[i], acc1[i + 1]};
-                *reinterpret_cast<pair_t *>(p1) = v;
+                for (int i = 0; i < EPV; i += 2) {
+                    double *p1 = live && second && e1 + i + 1 < row_len ? orow + e1 + i : dump_lane;
+                    pair_t v = {acc1[i], acc1[i + 1]};
+                    *reinterpret_cast<pair_t *>(p1) = v;
+                }
             }
             if constexpr (!EVEN) {
                 const int64_t t = row_len - 1;       // even: the last element of the row is the first of a pair
@@ -1223,17 +1234,17 @@ static int plan_schedule(s3_interp_plan *p, hipStream_t st) {
     return S3_OK;
 }
 
-template <typename T, bool ALIGNED, bool EVEN>
+template <typename T, bool ALIGNED, bool EVEN, bool NARROW = false>
 static int launch_stream_e(s3_interp_plan *p, const int32_t *rows, const void *data, int64_t row_len, int64_t in_stride,
                            double *out, hipStream_t st) {
-    using LAY = std::conditional_t<ALIGNED, StreamLayoutAligned, StreamLayoutUnaligned>;
+    using LAY = std::conditional_t<NARROW, StreamLayoutNarrow, std::conditional_t<ALIGNED, StreamLayoutAligned, StreamLayoutUnaligned>>;
     constexpr int EPC = LAY::CHUNK_VECS * 16 / (int)sizeof(T);
     const int n_chunks = (int)((row_len + EPC - 1) / EPC);
     if (!p->sched_begin) {
         const int rc = plan_schedule(p, st);
         if (rc != S3_OK) return rc;
     }
-    const size_t lds = (size_t)PL_NP * 32 * LAY::LP * 16 + 2 * 256 * sizeof(int32_t);
+    const size_t lds = (size_t)LAY::NPASS * (256 / LAY::LPR) * LAY::LP * 16 + 2 * 256 * sizeof(int32_t);
     const size_t dump_doubles = (size_t)p->sched_wgs * 256 * 2;        // one 16-byte slot per lane of the launch
     if (p->dump_doubles < dump_doubles) {
         if (p->dump) (void)hipFree(p->dump);
@@ -1244,7 +1255,7 @@ static int launch_stream_e(s3_interp_plan *p, const int32_t *rows, const void *d
     }
 #define S3_LAUNCH_STREAM(K)                                                                                                   \
     do {                                                                                                                      \
-        auto kern = interp_planned_stream_kernel<T, K, ALIGNED, EVEN>;                                                             \
+        auto kern = interp_planned_stream_kernel<T, K, ALIGNED, EVEN, NARROW>;                                                           \
         S3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,   \
                                          (int)lds));                                                                          \
         kern<<<dim3((unsigned)p->sched_wgs), 256, lds, st>>>(p->perm, rows, p->pl,                                            \
@@ -1258,11 +1269,11 @@ static int launch_stream_e(s3_interp_plan *p, const int32_t *rows, const void *d
     return S3_OK;
 }
 
-template <typename T, bool ALIGNED>
+template <typename T, bool ALIGNED, bool NARROW = false>
 static int launch_stream(s3_interp_plan *p, const int32_t *rows, const void *data, int64_t row_len, int64_t in_stride,
                          double *out, hipStream_t st) {
-    if (row_len & 1) return launch_stream_e<T, ALIGNED, false>(p, rows, data, row_len, in_stride, out, st);
-    return launch_stream_e<T, ALIGNED, true>(p, rows, data, row_len, in_stride, out, st);
+    if (row_len & 1) return launch_stream_e<T, ALIGNED, false, NARROW>(p, rows, data, row_len, in_stride, out, st);
+    return launch_stream_e<T, ALIGNED, true, NARROW>(p, rows, data, row_len, in_stride, out, st);
 }
 
 template <typename T>
@@ -1287,6 +1298,22 @@ static int launch_planned(s3_interp_plan *p, const int32_t *rows, int64_t n_rows
     if ((row_len + EPV - 1) / EPV > s3::short_row_vecs() && n_chunks <= stream_max_chunks() && stream_can_take(p) &&
         p->n_tiles >= stream_min_tiles() && !(off_line && shift_ok && n_chunks >= shift_min_chunks()))
         return launch_stream<T, true>(p, rows, data, row_len, in_stride, out, st);
+    // (r4) rows of two to four vectors (5 .. 16 fp32 snapshots): the persistent kernel in its narrow layout -- four lanes per row,
+    // eight gathers per lane and step -- unless the table is a large one read in place.  Measured, one box each: cylinder3D, 16 / 12
+    // snapshots, pitched copy 0.089 / 0.088 ms against 0.105 / 0.117 with the short-row kernels, read in place (320-MB table) 0.100 /
+    // 0.116 against 0.112 / 0.121; box5e7 (10 M cells, 16 snapshots) pitched copy 1.745 against 1.786 ms, but its 3.2-GB table read in
+    // place 2.363 against 2.208: there five short-lived workgroups per CU hide the page-table walks of a scattered table better
+    // than two persistent ones.  Rows of one vector stay with the short-row kernels (0.096 against 0.078 ms).  S3_SHORT_STREAM=0 / 1:
+    // never / always, for A/B runs.
+    {
+        const int vpr_ = (int)((row_len + EPV - 1) / EPV);
+        const char *sw = getenv("S3_SHORT_STREAM");
+        const bool in_place = rows != p->rows;
+        const bool big_table = in_place && (uint64_t)n_rows * (uint64_t)in_stride * sizeof(T) > ((uint64_t)1 << 30);
+        const bool want = sw ? sw[0] == '1' : !big_table;
+        if (vpr_ >= 2 && vpr_ <= 4 && want && stream_can_take(p) && p->n_tiles >= stream_min_tiles())
+            return launch_stream<T, true, true>(p, rows, data, row_len, in_stride, out, st);
+    }
     if ((row_len + EPV - 1) / EPV <= s3::short_row_vecs() && p->tc == 64) {
         const int vpr = (int)((row_len + EPV - 1) / EPV);
         if (vpr == 4 && p->ucap * vpr <= 256 * 8 && p->k <= 32 && !getenv("S3_SHORT_NO_QUAD") && !getenv("S3_SHORT_LDS_WEIGHTS")) {

@@ -185,7 +185,10 @@ def test_interp_planned_short_and_ragged_rows(ops, orc, row_len, dtype):
                                                  (75, pt.float32, True), (75, pt.float32, False), (100, pt.float32, True),
                                                  (131, pt.float32, True), (256, pt.float32, False), (17, pt.float64, True),
                                                  (9, pt.float64, False), (64, pt.float64, True), (5, pt.float32, True),
-                                                 (4, pt.float32, True), (2, pt.float64, True), (300, pt.float32, True)])
+                                                 (4, pt.float32, True), (2, pt.float64, True), (300, pt.float32, True),
+                                                 # two to four vectors per row: the narrow layout (four lanes per row, eight passes)
+                                                 (16, pt.float32, False), (16, pt.float32, True), (12, pt.float32, True), (13, pt.float32, False),
+                                                 (8, pt.float64, False), (6, pt.float64, True), (7, pt.float32, True)])
 def test_stream_kernel_equals_direct(ops, orc, monkeypatch, k, d, row_len, dtype, dense):
     """the persistent kernel (interp_planned_stream_kernel: the reference's neighbour counts, rows of more than four 16-byte
     vectors -- the 25-snapshot batches of examples/s3_for_cylinder3D_Re3900.py:28-69 as scalar (100 B) and 3-component

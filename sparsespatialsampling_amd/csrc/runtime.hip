@@ -40,6 +40,8 @@ constexpr size_t UP_CHUNK_BYTES = (size_t)8 << 20;   // per buffer
 struct UploadLane {
     void *pinned[UP_BUFS] = {nullptr, nullptr};
     hipEvent_t ev[UP_BUFS] = {nullptr, nullptr};
+    hipStream_t down = nullptr;                      // the lane's own stream for downloads (kept: creating and destroying one per
+                                                     // call and thread cost a download ~2.5 ms -- 100 MB took 10.9 ms)
     int next = 0;                                    // buffer the lane's next chunk goes through (rotates ACROSS calls: a small
                                                      // upload must not wait for the previous small upload's copy)
 };
@@ -389,8 +391,16 @@ int s3_download(void *h_dst, const void *d_src, size_t bytes, s3_stream stream) 
         OnGpuNode near(dev, false);
         if (hipSetDevice(dev) != hipSuccess) { first_error = (int)hipErrorInvalidDevice; return; }
         UploadLane &l = g_lanes[t];
-        hipStream_t own = nullptr;
-        if (hipStreamCreateWithFlags(&own, hipStreamNonBlocking) != hipSuccess) { first_error = (int)hipErrorUnknown; return; }
+        static const bool keep = [] { const char *e = getenv("S3_DOWNLOAD_KEEP_STREAMS"); return !(e && e[0] == '0'); }();
+        hipStream_t fresh = nullptr;
+        if (!keep) {
+            if (hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) != hipSuccess) { first_error = (int)hipErrorUnknown; return; }
+        } else if (!l.down && hipStreamCreateWithFlags(&l.down, hipStreamNonBlocking) != hipSuccess) {
+            l.down = nullptr;
+            first_error = (int)hipErrorUnknown;
+            return;
+        }
+        const hipStream_t own = keep ? l.down : fresh;
         int64_t pending[UP_BUFS] = {-1, -1};                              // chunk sitting in each pinned buffer
         auto drain = [&](int b) {
             if (pending[b] < 0) return hipSuccess;
@@ -417,7 +427,7 @@ int s3_download(void *h_dst, const void *d_src, size_t bytes, s3_stream stream) 
         }
         for (int k = 0; k < UP_BUFS && e == hipSuccess; ++k) e = drain((b + k) % UP_BUFS);
         (void)hipStreamSynchronize(own);
-        (void)hipStreamDestroy(own);
+        if (fresh) (void)hipStreamDestroy(fresh);
         if (e != hipSuccess) first_error = (int)e;
     };
     std::vector<std::thread> workers;

@@ -15,6 +15,7 @@
 
 #include <emmintrin.h>
 #include <pthread.h>
+#include <unistd.h>
 #include <sched.h>
 #include <cstdio>
 #include <string>
@@ -207,7 +208,8 @@ struct OnGpuNode {
 // batch).  run(n, fn): fn(0) on the caller, fn(1 .. n-1) on the pool's threads; returns when all are done.  One job at a time (the
 // callers hold g_upload_mutex).  S3_LANE_POOL=0: a fresh thread per lane and call, as before (A/B runs).
 class LanePool {
-    std::vector<std::thread> threads;
+    int n_threads = 0;                   // (detached: nothing of the pool is torn down at process exit -- a blocked thread there is
+    pid_t owner = 0;                     //  the kernel's to end; a forked child starts its own)
     std::mutex m;
     std::condition_variable cv_go, cv_done;
     const std::function<void(int)> *job = nullptr;
@@ -215,8 +217,7 @@ class LanePool {
     uint64_t generation = 0;
     bool stop = false;
 
-    void loop(int t) {
-        uint64_t seen = 0;
+    void loop(int t, uint64_t seen) {
         while (true) {
             const std::function<void(int)> *fn = nullptr;
             {
@@ -245,9 +246,15 @@ public:
         }
         {
             std::lock_guard<std::mutex> lk(m);
-            while ((int)threads.size() < n - 1) {
-                const int t = (int)threads.size() + 1;
-                threads.emplace_back([this, t] { loop(t); });
+            if (owner != getpid()) {                         // first use, or the threads belong to the process this one was forked from
+                owner = getpid();
+                n_threads = 0;
+                generation = 0;
+            }
+            while (n_threads < n - 1) {
+                const int t = ++n_threads;
+                const uint64_t start = generation;           // (a thread born now must not take a job that was finished before it)
+                std::thread([this, t, start] { loop(t, start); }).detach();
             }
             job = &fn;
             n_active = n;
@@ -260,16 +267,8 @@ public:
         cv_done.wait(lk, [&] { return remaining == 0; });
         job = nullptr;
     }
-    ~LanePool() {
-        {
-            std::lock_guard<std::mutex> lk(m);
-            stop = true;
-        }
-        cv_go.notify_all();
-        for (auto &w : threads) w.join();
-    }
 };
-LanePool g_pool;
+LanePool &g_pool = *new LanePool();      // (never destroyed: see above)
 
 hipError_t upload_lane_init(UploadLane &l) {
     for (int b = 0; b < UP_BUFS; ++b) {

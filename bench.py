@@ -795,7 +795,7 @@ def main():
             if "kernel_ms" in res.get("roofline_batches", {}).get("T25", {}):
                 bare[25] = res["roofline_batches"]["T25"]["kernel_ms"]
             # the transport legs BEFORE the CPU baselines: the download buffers of a 1000-snapshot batch (2 x 3.7 GB of page-locked
-            # memory) allocated after the baseline's arrays had churned the host's memory came down at 31 GB/s instead of 57 -- on
+            # memory) allocated after the CPU baseline had run came down at 31 GB/s instead of 57 (cause not isolated) -- on
             # every box tried, whatever the threads' placement (device_resident_input.T1000.fit_data_ms 118 ms against 66 in a process
             # that does only that)
             if not cfg.get("kind") == "box":

@@ -15,9 +15,13 @@ The grid comes from `SamplingTree.refine()` run on the GPU(s) before the timed r
 `refine_wall_s` in the same JSON line (second of two runs; the first one of a process, which also pays for the device
 allocations, is `refine_first_run_wall_s`).
 
-Multi-GPU (one process per GPU, launched by torch.distributed.run; the collectives run inside libs3hip.so on RCCL):
-* refine: every rank evaluates the KNN metric / gain of its 1/N slice of each batch of new cells, one grouped all-gather
-  per batch, block-wise captured-metric sums gathered per iteration (bit-identical for any N);
+Multi-GPU (one process per GPU; the collectives run inside libs3hip.so on RCCL).  Under `torch.distributed.run` (WORLD_SIZE ==
+--gpus) every rank runs main(); WITHOUT a launcher `python bench.py --gpus N` becomes the parent of N fresh ranks itself
+(launch_ranks: the parent never touches the GPU, watches the ranks, kills a wedged attempt, retries once on gloo, and prints an
+"error" JSON line + exit status 1 if that fails too):
+* refine: every rank evaluates the KNN metric / gain of its 1/N slice of each batch of new cells, ONE grouped all-gather
+  per batch -- the only exchange of a refinement step: the captured metric is reduced from the replicated arrays on every rank
+  in a fixed block order (bit-identical for any N);
 * interpolation (default `--shard cells`): the generated leaf cells are split into N spatially compact shards of equal
   cost (runs of the Hilbert-ordered tile plan, balanced by the bytes a shard moves per snapshot), every rank holds the
   KNN cache / plan of its shard and only the source rows that shard references, and interpolates the same snapshot
@@ -98,16 +102,38 @@ def build_case(name, cfg, geometry):
 
 
 # ---- CPU baselines (rank 0, N = 1 only; the oracle is the checker of the tests, used here as the timed CPU port) --------
-def cpu_baseline(w, idx, data, k, used, seconds=10.0, n_cells=100_000):
-    """the CPU oracle (C + OpenMP restatement of export.py:446-468) on a slice of THIS workload: the first `n_cells` cells of
-    the bench's own neighbour table, the source rows they reference, ALL snapshots of the bench's batch"""
+def host_cpu_counts():
+    """what the host has, what this container may use, and (filled in by the caller) what the baseline ran on: a 256-thread host
+    whose container is capped at 16 CPUs' worth of time is a 16-core baseline, whatever os.cpu_count() says"""
+    quota = None
+    try:                                                              # cgroup v2, then v1
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        quota = None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            quota = q / per if q > 0 else None
+        except (OSError, ValueError):
+            pass
+    return dict(host_cpus=os.cpu_count(), affinity_cpus=len(os.sched_getaffinity(0)), cgroup_cpus=quota)
+
+
+def cpu_baseline(w, idx, data, k, used, seconds=10.0, n_sweep=100_000):
+    """the CPU oracle (C + OpenMP restatement of export.py:446-468) on THIS workload: the bench's own neighbour table, the source
+    rows it references, all snapshots of the bench's batch -- ALL cells, at the thread count a sweep over the first `n_sweep`
+    cells found fastest (S3_BENCH_CPU_CELLS caps the cell count on hosts short of memory: the rows cost 4 * T bytes each)"""
     from oracle import s3_oracle as orc
-    nc = min(int(w.shape[0]), n_cells)
-    i_s, w_s = idx[:nc].cpu().numpy(), w[:nc].cpu().numpy()
-    rows, inv = np.unique(i_s, return_inverse=True)
     t = int(data.shape[1])
-    sub = data[used.long()[pt.from_numpy(rows).to(data.device).long()]].contiguous().cpu().numpy().reshape(len(rows), 1, t)   # (`idx` holds positions in `used`)
-    inv = inv.reshape(i_s.shape)
+
+    def slice_of(nc):
+        i_s, w_s = idx[:nc].cpu().numpy(), w[:nc].cpu().numpy()
+        rows, inv = np.unique(i_s, return_inverse=True)
+        sub = data[used.long()[pt.from_numpy(rows).to(data.device).long()]].contiguous().cpu().numpy().reshape(len(rows), 1, t)   # (`idx` holds positions in `used`)
+        return w_s, inv.reshape(i_s.shape), sub, len(rows)
+
+    nc_all = min(int(w.shape[0]), int(os.environ.get("S3_BENCH_CPU_CELLS", str(1 << 62))))
+    w_s, inv, sub, _ = slice_of(min(nc_all, n_sweep))
     orc.interp(w_s, inv, sub)                  # warm
     # the baseline at ITS best thread count: under a container's CPU quota (16 CPUs' worth on the pool's 256-thread hosts) all
     # hardware threads are not the fastest choice -- 64 threads gave 700 M/s where 128 gave 450 and 16 gave 560
@@ -118,23 +144,43 @@ def cpu_baseline(w, idx, data, k, used, seconds=10.0, n_cells=100_000):
         c0 = time.perf_counter()
         for _ in range(2):
             orc.interp(w_s, inv, sub)
-        tried[n] = nc * t * 2 / (time.perf_counter() - c0) / 1e6
+        tried[n] = len(w_s) * t * 2 / (time.perf_counter() - c0) / 1e6
     best = max(tried, key=tried.get)
     orc.set_num_threads(best)
+    del w_s, inv, sub
+    w_s, inv, sub, n_rows = slice_of(nc_all)
+    orc.interp(w_s, inv, sub)                  # warm (first touch of the output)
     reps, t0 = 0, time.perf_counter()
     while time.perf_counter() - t0 < seconds or reps < 2:
         orc.interp(w_s, inv, sub)
         reps += 1
     dt = time.perf_counter() - t0
     orc.set_num_threads(all_threads)
-    return dict(value=nc * t * reps / dt / 1e6, unit="Mcells*snapshots/s", cores=best, kind="port",
+    counts = host_cpu_counts()
+    return dict(value=nc_all * t * reps / dt / 1e6, unit="Mcells*snapshots/s", cores=best, threads_used=best, kind="port", **counts,
+                cells=nc_all, all_cells=bool(nc_all == int(w.shape[0])),
                 threads_tried={str(n): round(v, 1) for n, v in tried.items()},
-                sample=f"oracle/s3_oracle.c s3o_interp (OpenMP, {best} threads: the fastest of {sorted(tried)}) on the bench's own "
-                       f"table: first {nc} cells, the {len(rows)} source rows they reference, all {t} snapshots of the batch, "
-                       f"{reps} passes, k={k}, fp32 in / f64 out")
+                sample=f"oracle/s3_oracle.c s3o_interp (OpenMP, {best} threads: the fastest of {sorted(tried)} on the first "
+                       f"{min(nc_all, n_sweep)} cells) on the bench's own table: {nc_all} cells"
+                       f"{' = all of them' if nc_all == int(w.shape[0]) else ''}, the {n_rows} source rows they reference, all {t} "
+                       f"snapshots of the batch, {reps} passes, k={k}, fp32 in / f64 out; host: {counts['host_cpus']} hardware threads, "
+                       f"cgroup quota {counts['cgroup_cpus']} CPUs")
 
 
-def refine_cpu_baseline(name, x, metric, geos, kw, n_leaf_gpu):
+def grid_sha(centers, levels, faces, nodes):
+    """SHA-256 over the finished grid as refine() hands it over: cell centres, levels, face ids and node coordinates, each as
+    contiguous little-endian bytes in the reference's dtypes (s_cube.py:734-772) -- two backends that print the same digest have
+    built the same grid cell for cell, bit for bit"""
+    import hashlib
+    h = hashlib.sha256()
+    for a in (centers, levels, faces, nodes):
+        a = a.detach().cpu().numpy() if hasattr(a, "detach") else np.asarray(a)
+        h.update(str(a.dtype).encode() + str(a.shape).encode())
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+def refine_cpu_baseline(name, x, metric, geos, kw, n_leaf_gpu, sha_gpu):
     """`SamplingTree.refine()` of THIS workload at full size with the CPU oracle's kernels (tests/oracle_backend.py; the
     neighbour queries through the oracle's bucket grid, its stand-in for the reference's kd-tree: identical results to
     brute force, pinned by the same goldens) and the same host logic: the CPU port's grid-generation wall-clock"""
@@ -153,6 +199,7 @@ def refine_cpu_baseline(name, x, metric, geos, kw, n_leaf_gpu):
             tree.refine()
             tried[n] = time.perf_counter() - t0
             n_leaf = len(tree.all_centers)
+            sha = grid_sha(tree.all_centers, tree.all_levels, tree.face_ids, tree.all_nodes)
             tree.close()
     finally:
         s_cube._make_backend = product
@@ -160,7 +207,10 @@ def refine_cpu_baseline(name, x, metric, geos, kw, n_leaf_gpu):
     best = min(tried, key=tried.get)
     return dict(workload=f"{name} at full size: {len(x)} points -> {n_leaf} leaf cells", cpu_wall_s=tried[best],
                 cores=best, threads_tried={str(n): round(v, 3) for n, v in tried.items()}, kind="port",
-                knn="bucket grid (oracle/s3_oracle.c s3o_grid_*)", same_grid_size=bool(n_leaf == n_leaf_gpu))
+                knn="bucket grid (oracle/s3_oracle.c s3o_grid_*)", same_grid_size=bool(n_leaf == n_leaf_gpu),
+                # full-size parity in the driver's own run: centres, levels, faces and nodes of the CPU port's grid hashed
+                # against the HIP backend's (the reference itself cannot finish this size: BASELINE.md)
+                grid_sha256_cpu_port=sha, grid_sha256_gpu=sha_gpu, same_grid_sha=bool(sha == sha_gpu))
 
 
 def end_to_end(x, centers, k, batches=(25, 200)):
@@ -220,15 +270,17 @@ def export_sharded(x, centers, k, comm, t=200, reps=3):
         ex._fit_data(coords, data, "f", 10 ** 9)
     pt.cuda.synchronize()
     comm.barrier()
+    c0 = comm.n_collectives
     t0 = time.perf_counter()
     for _ in range(reps):
         ex._fit_data(coords, data, "f", 10 ** 9)
     pt.cuda.synchronize()
     comm.barrier()
     dt = comm.allreduce_max(time.perf_counter() - t0) / reps
+    collectives = (comm.n_collectives - c0) / reps              # counted by the communicator: all-gathers + gathers to the root
     table = ex._table_centers
     return dict(t_batch=t, ms_per_batch=dt * 1e3, Gcells_snapshots_per_s=len(centers) * t / dt / 1e9,
-                cells_on_this_rank=int(len(table.shard.mine)), rows_uploaded_by_this_rank=0, xgmi_bytes_per_batch=0,
+                cells_on_this_rank=int(len(table.shard.mine)), data_path_collectives_per_batch=collectives,
                 host_bytes_written_by_this_rank=int(len(table.shard.mine)) * t * 8,
                 shared_host_buffer=ex._shared is not None,
                 direct_device_writes=bool(ex._shared and all(b.device_ptr is not None for b in ex._shared.values())),
@@ -555,6 +607,141 @@ def bench_svd(args, json_fd):
     os.write(json_fd, (json.dumps(res) + "\n").encode())
 
 
+# ---- N > 1 without a launcher: this process becomes the PARENT of N fresh ranks ---------------------------------------------
+# `python bench.py --gpus N` with no WORLD_SIZE in the environment (the way the driver runs `--gpus 1`) must still print its one
+# JSON line.  The parent parses the arguments and NEVER touches the GPU (it imports torch, which does not initialise HIP; every HIP
+# call happens in the children): it starts N children (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, each in a process group of its
+# own), relays rank 0's line, and is their WATCHDOG -- `ncclCommInitRank` has no timeout and nothing inside a rank can see that
+# another rank is wedged.  Children report two milestones through files in a scratch directory ("alive": imports done and device
+# selected; "boot": communicator created); if the bootstrap takes longer than S3_BENCH_BOOT_TIMEOUT_S (120) after all ranks were
+# alive, if a rank exits with an error, or if the run exceeds S3_BENCH_RUN_TIMEOUT_S (1500), ALL children are killed (their process
+# groups: SIGTERM, then SIGKILL) and N FRESH children are started ONCE with S3_DIST_BACKEND=gloo (the exchange steps through a
+# gloo group; no process that has initialised the GPU is ever re-exec'ed).  If that attempt fails too the parent prints a JSON
+# line with an "error" field and exits with status 1.
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _mark(stage):
+    """child side of the watchdog protocol: milestone `stage` of this rank reached"""
+    d = os.environ.get("S3_BENCH_WATCH_DIR")
+    if d:
+        open(os.path.join(d, f"{stage}_{os.environ.get('RANK', '0')}"), "w").close()
+    # test hook, S3_BENCH_HANG=<rank|*>:<stage>:<backend|any>: that rank (every rank) stops (sleeps) when it reaches the stage on that backend
+    hang = os.environ.get("S3_BENCH_HANG", "").split(":")
+    if len(hang) == 3 and hang[0] in ("*", os.environ.get("RANK", "0")) and hang[1] == stage:
+        backend = "gloo" if os.environ.get("S3_DIST_BACKEND") == "gloo" else "rccl"
+        if hang[2] in ("any", backend):
+            print(f"[bench] rank {os.environ.get('RANK', '0')}: S3_BENCH_HANG -- sleeping at stage '{stage}'", file=sys.stderr, flush=True)
+            while True:
+                time.sleep(3600)
+
+
+def _kill_ranks(procs):
+    import signal
+    for sig, grace in ((signal.SIGTERM, 5.0), (signal.SIGKILL, 5.0)):
+        alive = [q for q in procs if q.poll() is None]
+        if not alive:
+            return
+        for q in alive:
+            try:
+                os.killpg(q.pid, sig)                      # (start_new_session: the child leads a group of its own)
+            except (ProcessLookupError, PermissionError):
+                pass
+        t_end = time.monotonic() + grace
+        while time.monotonic() < t_end and any(q.poll() is None for q in procs):
+            time.sleep(0.05)
+
+
+def _run_ranks(n, argv, extra_env, boot_timeout, run_timeout, start_timeout):
+    """one attempt: N fresh children -> (rank 0's JSON line or None, reason of the failure or None, seconds)"""
+    import shutil
+    import subprocess
+    import tempfile
+    watch = tempfile.mkdtemp(prefix="s3_bench_watch_")
+    port = _free_port()
+    procs, reason = [], None
+    t0 = time.monotonic()
+    try:
+        out0 = open(os.path.join(watch, "rank0.stdout"), "wb")
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port), S3_BENCH_WATCH_DIR=watch, S3_BENCH_CHILD="1", **extra_env)
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdin=subprocess.DEVNULL,
+                                          stdout=out0 if r == 0 else sys.stderr, start_new_session=True))
+        out0.close()
+        t_alive = None
+        while True:
+            codes = [q.poll() for q in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                reason = "rank %d exited with status %d" % bad[0]
+                break
+            if all(c == 0 for c in codes):
+                break
+            now = time.monotonic()
+            if not all(os.path.exists(os.path.join(watch, f"boot_{r}")) for r in range(n)):
+                if t_alive is None and all(os.path.exists(os.path.join(watch, f"alive_{r}")) for r in range(n)):
+                    t_alive = now
+                if t_alive is not None and now - t_alive > boot_timeout:
+                    late = [r for r in range(n) if not os.path.exists(os.path.join(watch, f"boot_{r}"))]
+                    reason = f"communicator bootstrap not finished {boot_timeout:.0f} s after all ranks were up (waiting for rank(s) {late})"
+                    break
+                if t_alive is None and now - t0 > start_timeout:
+                    late = [r for r in range(n) if not os.path.exists(os.path.join(watch, f"alive_{r}"))]
+                    reason = f"rank(s) {late} not up after {start_timeout:.0f} s"
+                    break
+            if now - t0 > run_timeout:
+                reason = f"run not finished after {run_timeout:.0f} s"
+                break
+            time.sleep(0.1)
+        if reason is not None:
+            _kill_ranks(procs)
+        line = None
+        if reason is None:
+            lines = [ln for ln in open(os.path.join(watch, "rank0.stdout"), "rb").read().decode(errors="replace").splitlines() if ln.startswith("{")]
+            if lines:
+                line = lines[-1]
+            else:
+                reason = "rank 0 finished without a JSON line"
+        return line, reason, time.monotonic() - t0
+    finally:
+        _kill_ranks(procs)
+        shutil.rmtree(watch, ignore_errors=True)
+
+
+def launch_ranks(args, argv):
+    """parent of a self-launched multi-rank run (never initialises the GPU); returns the exit status"""
+    boot_timeout = float(os.environ.get("S3_BENCH_BOOT_TIMEOUT_S", "120"))
+    run_timeout = float(os.environ.get("S3_BENCH_RUN_TIMEOUT_S", "1500"))
+    start_timeout = float(os.environ.get("S3_BENCH_START_TIMEOUT_S", "400"))     # (the first `import torch` of a fresh box: 1-2 minutes)
+    attempts = []
+    plans = [dict()] if os.environ.get("S3_DIST_BACKEND") == "gloo" else [dict(), dict(S3_DIST_BACKEND="gloo")]
+    for extra in plans:
+        backend = extra.get("S3_DIST_BACKEND", os.environ.get("S3_DIST_BACKEND", "rccl"))
+        line, reason, secs = _run_ranks(args.gpus, argv, extra, boot_timeout, run_timeout, start_timeout)
+        attempts.append(dict(backend=backend, seconds=round(secs, 1), ok=reason is None, **({} if reason is None else {"failure": reason})))
+        if reason is None:
+            try:
+                res = json.loads(line)
+                res["launcher"] = dict(self_launched=True, ranks=args.gpus, attempts=attempts,
+                                       note="bench.py --gpus N without WORLD_SIZE: a parent that never touches the GPU starts N fresh "
+                                            "ranks and watches them")
+                line = json.dumps(res)
+            except ValueError:
+                pass
+            print(line, flush=True)
+            return 0
+        print(f"[bench] attempt on {backend} failed: {reason}; all ranks killed", file=sys.stderr, flush=True)
+    print(json.dumps({"metric": "Mcells*snapshots/s interpolated", "value": None, "unit": "Mcells*snapshots/s", "n_gpus": args.gpus,
+                      "steps": args.steps, "warmup": args.warmup, "error": "; ".join(f"{a['backend']}: {a.get('failure')}" for a in attempts),
+                      "launcher": dict(self_launched=True, ranks=args.gpus, attempts=attempts)}), flush=True)
+    return 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -574,12 +761,15 @@ def main():
                     "planned LDS-tiled kernel (s3_interp_planned)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args, sys.argv[1:]))            # no launcher around us: start (and watch) the N ranks ourselves
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        ap.error(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N ranks with `python -m torch.distributed.run --nnodes=1 "
-                 f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port P bench.py --gpus {args.gpus} ...`")
+        ap.error(f"--gpus {args.gpus} but WORLD_SIZE={world}: either start `python bench.py --gpus {args.gpus}` without a launcher (it "
+                 f"starts its own ranks) or launch N ranks with `python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} "
+                 f"--master-addr 127.0.0.1 --master-port P bench.py --gpus {args.gpus} ...`")
 
     # stdout carries exactly one JSON line: libraries that print there (the RCCL version banner at communicator
     # creation) are sent to stderr for the whole run, the result goes to the saved descriptor at the end
@@ -587,6 +777,7 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
+    _mark("start")                         # (watchdog protocol of a self-launched run: nothing has touched the GPU yet)
     if rank == 0:
         query_rocm_smi()                   # (before anything initialises the GPU)
     # S3_BENCH_SHARE_GPU=1 + S3_DIST_BACKEND=gloo: rehearsal of the N>1 code path on a box with a single GPU
@@ -594,10 +785,12 @@ def main():
     pt.cuda.set_device(0 if share else local_rank)
     from sparsespatialsampling_amd import geometry, hipops, parallel
     from sparsespatialsampling_amd.s_cube import SamplingTree
+    _mark("alive")                         # (watchdog protocol of a self-launched run; no-ops otherwise)
     if os.environ.get("S3_DIST_BACKEND") == "gloo" and world > 1:
         import torch.distributed as dist
         dist.init_process_group("gloo")
     comm = parallel.init()                 # RCCL communicator inside libs3hip.so when world > 1
+    _mark("boot")
     import logging
     logging.getLogger().setLevel(logging.WARNING)
     if args.workload == "svd":             # the downstream consumer: its own line, its own roofline
@@ -639,6 +832,7 @@ def main():
         timings.append((comm.allreduce_max(time.perf_counter() - t0), t_init))
         centers = tree.all_centers.numpy()
         tree_out = (tree.all_centers, tree.all_nodes, tree.face_ids, tree.all_levels, float(tree.width))
+        sha_gpu = grid_sha(tree.all_centers, tree.all_levels, tree.face_ids, tree.all_nodes) if attempt == 3 else None
         info = dict(tree.data_final_mesh)
         n_cells_total = tree._topo_engine.n_created
         tree.close()
@@ -693,6 +887,7 @@ def main():
         else:
             hipops.interp(w, idx_full, data, out=out)
 
+    _mark("run")
     for _ in range(args.warmup):
         step()
     pt.cuda.synchronize()
@@ -724,11 +919,12 @@ def main():
 
     # N > 1: the product's export path with N ranks (every rank takes part; after the timed region of the headline)
     sharded_leg = None
-    if (world > 1 and args.shard == "cells" and plan is not None and not cfg.get("kind") == "box"
-            and os.environ.get("S3_BENCH_NO_EXPORT_LEG") != "1"):
+    if world > 1 and args.shard == "cells" and plan is not None and os.environ.get("S3_BENCH_NO_EXPORT_LEG") != "1":
         del data
         pt.cuda.empty_cache()
-        sharded_leg = optional_leg("export_sharded", lambda: export_sharded(x, centers, k, comm))    # (a failure on ALL ranks: no line lost)
+        # (the box workload in ITS batches: 16 snapshots per field and batch)
+        t_leg = 16 if cfg.get("kind") == "box" else 200
+        sharded_leg = optional_leg("export_sharded", lambda: export_sharded(x, centers, k, comm, t=t_leg))    # (a failure on ALL ranks: no line lost)
         data = None
 
     copy_bw = copy_bandwidth_gbs() if rank == 0 else None
@@ -759,7 +955,7 @@ def main():
             "refine_runs_s": [t[0] for t in timings],
             "refine_iterations": info["iterations"],
             "refine_cells_created": n_cells_total, "refine_leaves_per_s": nc_total / refine_s, "knn_cache_s": knn_cache_s,
-            "captured_metric": info["metric_per_iter"][-1],
+            "captured_metric": info["metric_per_iter"][-1], "grid_sha256": sha_gpu,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "copy_kernel_GBs": copy_bw, "frac_of_copy_kernel": achieved / copy_bw,
                          "traffic": traffic, "traffic_source": None if traffic is None else f"recorded, not measured in this run: {traffic_src}",
@@ -808,7 +1004,7 @@ def main():
             pt.cuda.empty_cache()
 
             def refine_leg():
-                rcb = refine_cpu_baseline(args.workload, x, metric, geos, tree_kw, nc_total)
+                rcb = refine_cpu_baseline(args.workload, x, metric, geos, tree_kw, nc_total, sha_gpu)
                 rcb.update(gpu_wall_s=refine_s, gpu_runs_s=[t[0] for t in timings[1:]], speedup=rcb["cpu_wall_s"] / refine_s)
                 return rcb
             res["refine_cpu_baseline"] = optional_leg("refine_cpu_baseline", refine_leg)

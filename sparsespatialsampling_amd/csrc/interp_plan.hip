@@ -416,13 +416,28 @@ interp_planned_short_quad_kernel(const int32_t *__restrict__ perm, const int32_t
     store_piece<EPV>(out + cell * row_len + col, acc, row_len - col, even_rows);
 }
 
+// Dispatch order of the chunk kernels (one workgroup per (tile, run of column chunks); a 1-D grid, workgroup b on XCD b % 8).
+// XCD x owns the x-th eighth of the Hilbert-ordered tiles; its share is walked in BRICKS of `brick` consecutive tiles, and inside
+// a brick run-major: all tiles of the brick for chunk run 0, then for run 1, ... -- the workgroups resident on an XCD at the same
+// time then stage the same columns of rows that neighbouring tiles share (the halo) within a few steps of each other.
+// brick >= tiles_per_xcd: run-major over the whole share (the order of a 2-D grid); n_split = 1: tile order.
+__device__ __forceinline__ void brick_map(int64_t b, int64_t tiles_per_xcd, int brick, int n_split, int64_t &tile, int &run) {
+    const int64_t i = b >> 3;
+    const int64_t per = (int64_t)brick * n_split;
+    const int64_t bk = i / per, rem = i - bk * per;
+    const int64_t left = tiles_per_xcd - bk * brick;
+    const int64_t bl = left < brick ? left : (int64_t)brick;
+    run = (int)(rem / bl);
+    tile = (b & 7) * tiles_per_xcd + bk * brick + (rem - (int64_t)run * bl);
+}
+
 template <typename T, int TC>
 __global__ void __launch_bounds__(TC * 4, 2)  // 226 VGPRs: two waves per SIMD
 interp_planned_kernel(const int32_t *__restrict__ perm, const int32_t *__restrict__ tile_cell_begin,
                       const int32_t *__restrict__ tile_row_begin, const int32_t *__restrict__ rows,
                       const uint16_t *__restrict__ loc, const double *__restrict__ w /*plan order*/, int k, int ucap,
                       const T *__restrict__ data, int64_t row_len, int64_t in_stride, double *__restrict__ out,
-                      int64_t n_tiles, int64_t tiles_per_xcd, int chunks_per_block, int n_chunks) {
+                      int64_t n_tiles, int64_t tiles_per_xcd, int chunks_per_block, int n_chunks, int brick, int n_split) {
     using V = typename Vec16<T>::type;
     constexpr int EPV = Vec16<T>::N;                 // elements per 16-byte vector
     constexpr int EPC = PL_SEG / (int)sizeof(T);     // elements per chunk
@@ -433,8 +448,9 @@ interp_planned_kernel(const int32_t *__restrict__ perm, const int32_t *__restric
     double *s_w = reinterpret_cast<double *>(lds_raw + (size_t)ucap * 8);        // [k][TC]
     uint16_t *s_loc = reinterpret_cast<uint16_t *>(s_w + (size_t)k * TC);        // [k][TC]
 
-    const int64_t b = blockIdx.x;
-    const int64_t tile = (b & 7) * tiles_per_xcd + (b >> 3);     // XCD-aware (speed only)
+    int64_t tile;
+    int run;
+    brick_map(blockIdx.x, tiles_per_xcd, brick, n_split, tile, run);     // XCD-aware (speed only)
     if (tile >= n_tiles) return;
     const int c_begin = tile_cell_begin[tile], n_c = tile_cell_begin[tile + 1] - c_begin;
     const int r_begin = tile_row_begin[tile], n_r = tile_row_begin[tile + 1] - r_begin;
@@ -449,7 +465,7 @@ interp_planned_kernel(const int32_t *__restrict__ perm, const int32_t *__restric
     const bool has_cell = cl < n_c;
     const int64_t cell = has_cell ? perm[c_begin + cl] : 0;
 
-    const int chunk0 = blockIdx.y * chunks_per_block;
+    const int chunk0 = run * chunks_per_block;
     const int chunk1 = min(n_chunks, chunk0 + chunks_per_block);
 
     // staging role: 8 lanes per 128-B row segment, 32 rows per pass, <= PL_NP passes.  The row ids of this lane's passes
@@ -553,7 +569,7 @@ interp_planned_shift_kernel(const int32_t *__restrict__ perm, const int32_t *__r
                             const int32_t *__restrict__ tile_row_begin, const int32_t *__restrict__ rows,
                             const uint16_t *__restrict__ loc, const double *__restrict__ w /*plan order*/, int k, int ucap,
                             const T *__restrict__ data, int64_t row_len, int64_t in_stride, double *__restrict__ out,
-                            int64_t n_tiles, int64_t tiles_per_xcd, int chunks_per_block, int n_chunks) {
+                            int64_t n_tiles, int64_t tiles_per_xcd, int chunks_per_block, int n_chunks, int brick, int n_split) {
     using V = typename Vec16<T>::type;
     constexpr int TC = 64;
     constexpr int EPV = Vec16<T>::N;
@@ -565,8 +581,9 @@ interp_planned_shift_kernel(const int32_t *__restrict__ perm, const int32_t *__r
     double *s_w = reinterpret_cast<double *>(lds_raw + (size_t)ucap * 8);        // [k][TC]
     uint16_t *s_loc = reinterpret_cast<uint16_t *>(s_w + (size_t)k * TC);        // [k][TC]
 
-    const int64_t b = blockIdx.x;
-    const int64_t tile = (b & 7) * tiles_per_xcd + (b >> 3);     // XCD-aware (speed only)
+    int64_t tile;
+    int run;
+    brick_map(blockIdx.x, tiles_per_xcd, brick, n_split, tile, run);     // XCD-aware (speed only)
     if (tile >= n_tiles) return;
     const int c_begin = tile_cell_begin[tile], n_c = tile_cell_begin[tile + 1] - c_begin;
     const int r_begin = tile_row_begin[tile], n_r = tile_row_begin[tile + 1] - r_begin;
@@ -580,7 +597,7 @@ interp_planned_shift_kernel(const int32_t *__restrict__ perm, const int32_t *__r
     const bool has_cell = cl < n_c;
     const int64_t cell = has_cell ? perm[c_begin + cl] : 0;
 
-    const int chunk0 = blockIdx.y * chunks_per_block;
+    const int chunk0 = run * chunks_per_block;
     const int chunk1 = min(n_chunks, chunk0 + chunks_per_block);
 
     const int srow = threadIdx.x >> 3, svec = threadIdx.x & 7;
@@ -1112,11 +1129,8 @@ static int short_row_vecs() {
 // fewest workgroups a launch of the chunk kernel should have before the column chunks are split over blockIdx.y
 // (S3_PLAN_MIN_BLOCKS overrides, for A/B runs)
 static int64_t min_blocks() {
-    static const int64_t v = [] {
-        const char *e = getenv("S3_PLAN_MIN_BLOCKS");
-        return e ? atoll(e) : 2048ll;
-    }();
-    return v;
+    const char *e = getenv("S3_PLAN_MIN_BLOCKS");
+    return e ? atoll(e) : 2048ll;
 }
 
 static int plan_ucap(int k, int tc) {
@@ -1361,18 +1375,22 @@ static int launch_planned(s3_interp_plan *p, const int32_t *rows, int64_t n_rows
         S3_LAUNCH_CHECK();
         return S3_OK;
     }
-    // the column chunks are split over blockIdx.y (x = tile runs fastest in dispatch order) only when there are too few
-    // tiles to fill the chip: one workgroup per tile over ALL chunks is fastest (MI355X, cylinder3D workload: 3.7 ms vs
-    // 4.4 ms with 4 chunks per workgroup)
+    // The column chunks of a tile are split into runs over several workgroups when there are too few tiles to fill the chip
+    // (S3_PLAN_MIN_BLOCKS), or on request (S3_PLAN_SPLIT = runs per tile, S3_PLAN_BRICK = tiles per XCD and brick; brick_map above).
+    // One workgroup per tile over ALL chunks was fastest in round 1 (MI355X, cylinder3D workload: 3.7 ms vs 4.4 ms with 4 chunks per
+    // workgroup, runs in 2-D grid order)
     int gy = 1;
     while (gx * gy < s3::min_blocks() && gy < n_chunks) gy *= 2;
+    if (const char *e = getenv("S3_PLAN_SPLIT")) gy = atoi(e);
     if (gy > n_chunks) gy = n_chunks;
     if (gy < 1) gy = 1;
     const int chunks_per_block = (n_chunks + gy - 1) / gy;
     gy = (n_chunks + chunks_per_block - 1) / chunks_per_block;
-    S3_REQUIRE(gx < ((int64_t)1 << 31), "s3_interp_planned: too many tiles");
+    int brick = (int)std::min<int64_t>(tiles_per_xcd, 1 << 30);
+    if (const char *e = getenv("S3_PLAN_BRICK")) brick = std::max(1, std::min(brick, atoi(e)));
+    S3_REQUIRE(gx * gy < ((int64_t)1 << 31), "s3_interp_planned: too many workgroups");
     const size_t lds = (size_t)p->ucap * PL_SEG + (size_t)p->k * p->tc * (sizeof(double) + sizeof(uint16_t));
-    dim3 grid((unsigned)gx, (unsigned)gy);
+    dim3 grid((unsigned)(gx * gy));
     // rows that do not start on 128-byte boundaries (a dense batch read where it lies): whole aligned lines per load, the
     // per-row phase undone on the way into LDS (S3_INPLACE_SHIFT=0: the kernel below with straddling segments, for A/B runs)
     if (shift_ok) {
@@ -1380,7 +1398,7 @@ static int launch_planned(s3_interp_plan *p, const int32_t *rows, int64_t n_rows
         S3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         kern<<<grid, 256, lds, st>>>(p->perm, p->tile_cell_begin, p->tile_row_begin, rows, p->loc, p->wp, p->k, p->ucap,
                                      static_cast<const T *>(data), row_len, in_stride, out, p->n_tiles, tiles_per_xcd,
-                                     chunks_per_block, n_chunks);
+                                     chunks_per_block, n_chunks, brick, gy);
         S3_LAUNCH_CHECK();
         return S3_OK;
     }
@@ -1389,13 +1407,13 @@ static int launch_planned(s3_interp_plan *p, const int32_t *rows, int64_t n_rows
         S3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         kern<<<grid, 512, lds, st>>>(p->perm, p->tile_cell_begin, p->tile_row_begin, rows, p->loc, p->wp, p->k, p->ucap,
                                      static_cast<const T *>(data), row_len, in_stride, out, p->n_tiles, tiles_per_xcd,
-                                     chunks_per_block, n_chunks);
+                                     chunks_per_block, n_chunks, brick, gy);
     } else {
         auto kern = interp_planned_kernel<T, 64>;
         S3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         kern<<<grid, 256, lds, st>>>(p->perm, p->tile_cell_begin, p->tile_row_begin, rows, p->loc, p->wp, p->k, p->ucap,
                                      static_cast<const T *>(data), row_len, in_stride, out, p->n_tiles, tiles_per_xcd,
-                                     chunks_per_block, n_chunks);
+                                     chunks_per_block, n_chunks, brick, gy);
     }
     S3_LAUNCH_CHECK();
     return S3_OK;

@@ -121,6 +121,7 @@ def batch_slice(n, rank, world_size):
 
 class SoloComm:
     rank, world, name = 0, 1, "solo"
+    n_collectives = 0            # data-path collectives issued through this communicator (all-gathers, gathers to the root)
 
     def allgather_inplace(self, arrays, counts):
         pass
@@ -155,6 +156,7 @@ class GlooComm(SoloComm):
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
 
     def allgather_inplace(self, arrays, counts):
+        self.n_collectives += 1
         for a, cnt in zip(arrays, counts):
             if cnt == 0:
                 continue
@@ -167,6 +169,7 @@ class GlooComm(SoloComm):
             flat.copy_(out)
 
     def gather_to_root(self, send, recv, counts, root=0):
+        self.n_collectives += 1
         if self.rank != root:
             if counts[self.rank]:
                 self._dist.send(send.cpu().contiguous(), dst=root)
@@ -231,6 +234,7 @@ class RcclComm(SoloComm):
         """``arrays[i]`` is a contiguous device tensor whose first ``world * counts[i]`` elements are gathered in place:
         rank r contributes elements [r * counts[i], (r + 1) * counts[i]).  One RCCL group for all arrays."""
         n = len(arrays)
+        self.n_collectives += 1
         ptrs = (C.c_void_p * n)(*[a.data_ptr() for a in arrays])
         sizes = (C.c_size_t * n)(*[int(c) * a.element_size() for a, c in zip(arrays, counts)])
         for a, c in zip(arrays, counts):
@@ -242,6 +246,7 @@ class RcclComm(SoloComm):
     def gather_to_root(self, send, recv, counts, root=0):
         """device tensors: ``send`` [counts[rank], L] contiguous, ``recv`` [sum(counts), L] contiguous on ``root`` (None elsewhere);
         grouped ncclSend / ncclRecv inside the library -- every byte crosses xGMI once"""
+        self.n_collectives += 1
         row = int(np.prod(send.shape[1:])) * send.element_size() if send is not None else int(np.prod(recv.shape[1:])) * recv.element_size()
         sizes = (C.c_size_t * self.world)(*[int(c) * row for c in counts])
         if send is not None and not (send.is_cuda and send.is_contiguous() and send.shape[0] == counts[self.rank]):

@@ -74,7 +74,7 @@ class HipTreeBackend:
             setattr(self, name, t)
         self.cap = cap
         n_blocks = -(-cap // parallel.SUMSQ_BLOCK)
-        self._sumsq_partial = pt.zeros(n_blocks + self.comm.world, dtype=pt.float64, device=self.dev)
+        self._sumsq_partial = pt.zeros(n_blocks, dtype=pt.float64, device=self.dev)
         self._sumsq_out = pt.empty(1, dtype=pt.float64, device=self.dev)
 
     def start(self, root_center, width, gain0, root_metric, root_gain):
@@ -178,13 +178,13 @@ class HipTreeBackend:
                             self._last_invalid if use_invalid else None)
 
     def sumsq(self, n_cells):
-        """sum of metric^2 over the leaves: partial sums of fixed 1024-cell blocks (every rank a share of the blocks,
-        gathered), added in block order -- the same bits for any number of ranks"""
+        """sum of metric^2 over the leaves: partial sums of fixed 1024-cell blocks added in block order (a fixed tree, so the
+        bits do not depend on who computes them).  ``metric`` and ``leaf`` are replicated -- the grouped all-gather of
+        ``refine_batch`` has handed every rank all slices, ``commit`` runs on every rank -- so every rank reduces ALL blocks
+        itself (9 MB at cylinder3D's size, 100 MB at 5*10^7 points: microseconds) and no second collective per iteration is
+        needed: the all-gather of the batch is the one exchange of a refinement step (reference s_cube.py:317-336)"""
         n_blocks = -(-n_cells // parallel.SUMSQ_BLOCK)
-        chunk, b, e = parallel.batch_slice(n_blocks, self.comm.rank, self.comm.world)
-        hipops.sumsq_blocks(self.metric, self.leaf, n_cells, b, e, self._sumsq_partial)
-        if self.comm.world > 1:
-            self.comm.allgather_inplace([self._sumsq_partial], [chunk])
+        hipops.sumsq_blocks(self.metric, self.leaf, n_cells, 0, n_blocks, self._sumsq_partial)
         hipops.sum_ordered(self._sumsq_partial, n_blocks, self._sumsq_out)
         return float(self._sumsq_out.item())
 

@@ -70,6 +70,7 @@ class OracleTreeBackend:
         if self.comm.world > 1:
             self.comm.allgather_inplace([self.metric[first:], self.gain[first:]], [chunk, chunk])
         self._parents = parents
+        self.n_batches = getattr(self, "n_batches", 0) + 1
         return n_new
 
     def mask(self, geometries, refine_mode, cells=None, first=0, n=None):
@@ -109,19 +110,14 @@ class OracleTreeBackend:
         self.gain[first:first + n_new][bad] = 0.0
 
     def sumsq(self, n_cells):
-        """partial sums of fixed 1024-cell blocks (this rank's share), gathered, added in block order"""
+        """partial sums of fixed 1024-cell blocks added in block order; metric / leaf are replicated (the all-gather of
+        refine_batch), so every rank reduces all blocks itself -- no second collective per iteration (tree_backend.sumsq)"""
         blk = parallel.SUMSQ_BLOCK
         n_blocks = -(-n_cells // blk)
-        chunk, b, e = parallel.batch_slice(n_blocks, self.comm.rank, self.comm.world)
-        partial = np.zeros(chunk * self.comm.world)
-        for j in range(b, e):
-            sl = slice(j * blk, min((j + 1) * blk, n_cells))
-            partial[j] = orc.sumsq(self.metric[sl][self.leaf[sl]])
-        if self.comm.world > 1:
-            self.comm.allgather_inplace([partial], [chunk])
         total = 0.0
-        for v in partial[:n_blocks].tolist():
-            total += v
+        for j in range(n_blocks):
+            sl = slice(j * blk, min((j + 1) * blk, n_cells))
+            total += orc.sumsq(self.metric[sl][self.leaf[sl]])
         return total
 
     def topn(self, n_cells, n_top):

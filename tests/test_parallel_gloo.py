@@ -35,8 +35,11 @@ def _worker(rank, world, port, out):
     assert parallel.world() == (rank, world)
     x, y, geos, kw = refine_inputs("refine_2d_delta", geometry)
     tree = s_cube.SamplingTree(pt.from_numpy(x), pt.from_numpy(y), geometry_obj=geos, **kw)
-    tree.refine()            # every batch: split KNN work + all-gather; every captured metric: gathered block sums
+    before = tree._backend.comm.n_collectives
+    tree.refine()            # every batch: split KNN work + ONE grouped all-gather; the captured metric needs no exchange
     assert tree._backend.comm.world == world and tree._backend.comm.name == "gloo"
+    # SURVEY 8(e) / north_star: one exchange per refinement step -- the all-gather of the batch and nothing else
+    assert tree._backend.comm.n_collectives - before == tree._backend.n_batches > 10
     res = dict(metric=np.array(tree._metric), centers=tree.all_centers.numpy(), levels=tree.all_levels.numpy(),
                shard=parallel.shard_range(1001))
     gathered = [None] * world
@@ -239,3 +242,42 @@ def test_leaf_shard_cuts_balance_the_cost():
     heavy_head = np.zeros((4, LeafShards.PROFILE + 1)); heavy_head[0] = 10.0 * s
     cuts = sh._cut(heavy_head, first)
     assert cuts[0] == 0 and cuts[-1] == 5 and all(b > a for a, b in zip(cuts, cuts[1:]))
+
+
+def _self_launch(extra_env, args=(), timeout=300):
+    import json
+    import subprocess
+    env = dict(os.environ, **extra_env)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "cylinder3D_small", "--steps", "2",
+                          "--warmup", "1", "--no-cpu-baseline"] + list(args), cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+    return run, [json.loads(ln) for ln in lines]
+
+
+def test_self_launched_bench_reports_wedged_ranks_as_an_error_line():
+    """`python bench.py --gpus 2` with no launcher around it: the parent starts the two ranks itself and is their watchdog.  The ranks
+    are made to stop before they have touched the GPU, on every backend: the parent kills the attempt, retries once on gloo with FRESH ranks,
+    and then prints exactly one JSON line with an `error` field and exits with status 1 -- never a hang, never no line.  (No GPU needed:
+    the ranks are stopped before their first HIP call.)"""
+    import time
+    t0 = time.time()
+    run, lines = _self_launch(dict(S3_BENCH_HANG="*:start:any", S3_BENCH_START_TIMEOUT_S="4", S3_BENCH_RUN_TIMEOUT_S="60"))
+    assert run.returncode == 1, run.stderr[-2000:]
+    assert len(lines) == 1 and lines[0]["value"] is None and lines[0]["n_gpus"] == 2
+    att = lines[0]["launcher"]["attempts"]
+    assert [a["backend"] for a in att] == ["rccl", "gloo"] and not any(a["ok"] for a in att)
+    assert "rank(s) [0, 1] not up" in lines[0]["error"] and "S3_BENCH_HANG" in run.stderr
+    assert time.time() - t0 < 120
+    assert run.stderr.count("sleeping at stage 'start'") == 4 and run.stderr.count("all ranks killed") == 2      # two attempts x two ranks
+
+
+def test_self_launch_is_not_taken_under_a_launcher(monkeypatch):
+    """with WORLD_SIZE in the environment (torch.distributed.run) bench.py must not start ranks of its own; a mismatch is an
+    argument error as before"""
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], cwd=ROOT, env=env, capture_output=True, text=True,
+                         timeout=300)
+    assert run.returncode == 2 and "starts its own ranks" in run.stderr and not run.stdout.strip()

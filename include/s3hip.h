@@ -40,7 +40,7 @@ extern "C" {
 
 /* what s3_abi_version() of a library built from this header returns; the bindings refuse a library that reports another
  * number (a stale build) with the command that rebuilds it */
-#define S3_ABI_VERSION 4
+#define S3_ABI_VERSION 5
 
 typedef struct s3_knn s3_knn; /* opaque: grid-sorted copy of the original point cloud, resident in HBM */
 typedef void *s3_stream;
@@ -48,6 +48,9 @@ typedef void *s3_stream;
 /* ---- runtime / plumbing ------------------------------------------------------------------------------------ */
 const char *s3_last_error(void);
 int s3_abi_version(void);
+/* stop and join the library's own host threads (transfer lanes); returns their number.  Call once at process exit, before the
+ * HIP runtime goes away (the Python bindings register it with atexit); safe at any time -- later calls start new lanes. */
+int s3_shutdown(void);
 int s3_device_count(int *h_count);
 int s3_set_device(int device);
 int s3_malloc(void **d_ptr, size_t bytes);

@@ -13,7 +13,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_SO = os.path.join(_HERE, "libs3hip.so")
-TOPO_SO = os.path.join(_HERE, "libs3topo.so")
+TOPO_SO = os.environ.get("S3_TOPO_SO") or os.path.join(_HERE, "libs3topo.so")      # (S3_TOPO_SO: the sanitizer build of the CPU test job)
 
 
 class HipUnavailableError(RuntimeError):
@@ -26,7 +26,7 @@ class S3HipError(RuntimeError):
 
 _hip = None
 _topo = None
-ABI_VERSION = 4          # S3_ABI_VERSION of include/s3hip.h this file was written against
+ABI_VERSION = 5          # S3_ABI_VERSION of include/s3hip.h this file was written against
 _REBUILD = "python -c 'import __graft_entry__ as g; g.build()'"
 
 c_i64, c_i32, c_int, c_dbl, c_vp = C.c_int64, C.c_int32, C.c_int, C.c_double, C.c_void_p
@@ -35,6 +35,7 @@ c_i64, c_i32, c_int, c_dbl, c_vp = C.c_int64, C.c_int32, C.c_int, C.c_double, C.
 HIP_SIGNATURES = {
     "s3_last_error": (C.c_char_p, []),
     "s3_abi_version": (c_int, []),
+    "s3_shutdown": (c_int, []),
     "s3_device_count": (c_int, [C.POINTER(c_int)]),
     "s3_set_device": (c_int, [c_int]),
     "s3_malloc": (c_int, [C.POINTER(c_vp), C.c_size_t]),
@@ -196,7 +197,19 @@ def hip_lib():
             raise HipUnavailableError(f"{HIP_SO} reports ABI version {lib.s3_abi_version()}, these bindings need "
                                       f"{ABI_VERSION}: stale build -- rebuild it with `{_REBUILD}`.")
         _hip = lib
+        # the library's transfer lanes are joined before the interpreter and the HIP runtime go down.  atexit runs its hooks in
+        # reverse order of registration and torch (imported above) has registered its own already: this one runs before them.
+        import atexit
+        atexit.register(_shutdown)
     return _hip
+
+
+def _shutdown():
+    if _hip is not None:
+        try:
+            _hip.s3_shutdown()
+        except Exception:       # interpreter already half gone
+            pass
 
 
 def topo_lib():

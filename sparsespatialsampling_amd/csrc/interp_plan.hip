@@ -569,7 +569,7 @@ interp_planned_shift_kernel(const int32_t *__restrict__ perm, const int32_t *__r
                             const int32_t *__restrict__ tile_row_begin, const int32_t *__restrict__ rows,
                             const uint16_t *__restrict__ loc, const double *__restrict__ w /*plan order*/, int k, int ucap,
                             const T *__restrict__ data, int64_t row_len, int64_t in_stride, double *__restrict__ out,
-                            int64_t n_tiles, int64_t tiles_per_xcd, int chunks_per_block, int n_chunks, int brick, int n_split) {
+                            int64_t n_tiles, int64_t tiles_per_xcd, int chunks_per_block, int n_chunks, int brick, int n_split, int hold, int pace) {
     using V = typename Vec16<T>::type;
     constexpr int TC = 64;
     constexpr int EPV = Vec16<T>::N;
@@ -621,7 +621,7 @@ interp_planned_shift_kernel(const int32_t *__restrict__ perm, const int32_t *__r
     {                                                                                                            \
         const uintptr_t a_ = base + (uint64_t)(uint32_t)rows[r_begin + min(P * RPP + srow, n_r - 1)] * stride_bytes; \
         const int ph_ = (int)(a_ >> 4) & 7;                                                                      \
-        ptr##P = data128 + (((a_ & ~(uintptr_t)127) - base128) + 16u * (unsigned)svec) + (int64_t)chunk0 * 128;   \
+        ptr##P = data128 + (((a_ & ~(uintptr_t)127) - base128) + 16u * (unsigned)svec);                           \
         old##P = svec >= ph_;                                                                                    \
         /* (passes beyond the tile's last row hold a copy of it and store that copy where the row itself goes) */  \
         lds##P = (uint32_t)(min(P * RPP + srow, n_r - 1) * 8 + ((svec - ph_) & 7)) * 16u;                         \
@@ -663,6 +663,17 @@ interp_planned_shift_kernel(const int32_t *__restrict__ perm, const int32_t *__r
 #define S3H_STORE_BA(P) S3H_STORE2(P, preB##P, preA##P)
 #define S3H_STORES_DONE()
 
+    // Output rows of 8 * row_len bytes start 64 bytes into a 128-byte line whenever row_len is an odd multiple of 8 (1000 snapshots:
+    // 8000-byte rows, every other cell): the 256 bytes a cell writes per step then end in HALF a line whose other half follows a
+    // step (7 us) later -- the L2 has turned over by then and the line goes out as two partial writes (WRITE_SIZE 7 % over the
+    // output's size).  Such a cell holds its last 64 bytes (blocks 6 and 7 of the chunk: the second vector of its lanes
+    // 2 and 3) back for one step, so that every step writes the whole aligned lines [c * 256 - 64, c * 256 + 192) of the row.
+    bool defer = false;
+    if constexpr (std::is_same<T, float>::value)
+        defer = has_cell && even_rows && v0 >= 2 && (reinterpret_cast<uintptr_t>(out + cell * row_len) & 127) == 64 && hold != 0;
+    int run_first = 0;                                              // first chunk of the run being swept
+    double held0 = 0.0, held1 = 0.0, held2 = 0.0, held3 = 0.0;      // (named: a loop-carried local array ends up in scratch memory)
+
     auto accumulate = [&](int chunk) {
         if (!has_cell) return;
         const int64_t col0 = (int64_t)chunk * EPC;
@@ -685,28 +696,91 @@ interp_planned_shift_kernel(const int32_t *__restrict__ perm, const int32_t *__r
         }
         double *o = out + cell * row_len + col0;
         store_piece<EPV>(o + v0 * EPV, acc0, row_len - col0 - (int64_t)v0 * EPV, even_rows);
-        store_piece<EPV>(o + (v0 + 4) * EPV, acc1, row_len - col0 - (int64_t)(v0 + 4) * EPV, even_rows);
+        if (defer) {
+            // (the chunk before this one is never the row's last: its piece is whole)
+            if constexpr (EPV == 4) {
+                if (chunk > run_first) {
+                    double *h = o - EPC + (v0 + 4) * EPV;
+                    *reinterpret_cast<double2 *>(h) = make_double2(held0, held1);
+                    *reinterpret_cast<double2 *>(h + 2) = make_double2(held2, held3);
+                }
+                held0 = acc1[0], held1 = acc1[1], held2 = acc1[2], held3 = acc1[3];
+            }
+        } else {
+            store_piece<EPV>(o + (v0 + 4) * EPV, acc1, row_len - col0 - (int64_t)(v0 + 4) * EPV, even_rows);
+        }
     };
 
-    if (chunk0 < chunk1) {
-        S3H_ISSUE(A, chunk0, 0);
-        S3H_ISSUE(B, chunk0 + 1, 1);
+    // (S3_PACE_TICKS, experiment) chunk phase tied to a chip-wide clock: time is cut into slots of `pace` ticks of the 100-MHz
+    // counter; slot n belongs to chunk n mod n_chunks on EVERY workgroup, and a workgroup issues the loads of a step no earlier than
+    // that step's slot begins -- tiles that share rows then ask for the same lines within the time the L2 keeps them.  A tile that
+    // starts in slot n sweeps the chunks n mod n_chunks ... n_chunks - 1 and then 0 ... (n mod n_chunks) - 1 (two runs).
+    unsigned long long slot = 0;
+    int c_start = chunk0;
+    if (pace > 0 && n_split == 1) {
+        __shared__ unsigned long long s_slot;
+        if (threadIdx.x == 0) s_slot = __builtin_amdgcn_s_memrealtime() / (unsigned)pace + 1;
+        __syncthreads();
+        const unsigned long long v_ = s_slot;            // (wave-uniform: into scalar registers)
+        slot = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(v_ >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned)v_);
+        c_start = (int)(slot % (unsigned)n_chunks);
     }
-    for (int chunk = chunk0; chunk < chunk1; chunk += 2) {
-        S3_REP16(S3H_STORE_AB)
-        S3H_STORES_DONE();
-        __syncthreads();
-        if (chunk + 1 < chunk1) S3H_ISSUE(A, chunk + 2, 2);
-        accumulate(chunk);
-        __syncthreads();
-        if (chunk + 1 >= chunk1) break;
-        S3_REP16(S3H_STORE_BA)
-        S3H_STORES_DONE();
-        __syncthreads();
-        if (chunk + 2 < chunk1) S3H_ISSUE(B, chunk + 3, 3);
-        accumulate(chunk + 1);
-        __syncthreads();
-        S3_REP16(S3H_ADVANCE)
+    auto wait_slot = [&]() {
+        if (pace > 0 && n_split == 1) {
+            const unsigned long long target = slot * (unsigned)pace;
+            while (__builtin_amdgcn_s_memrealtime() < target) __builtin_amdgcn_s_sleep(4);
+            ++slot;
+        }
+    };
+    // (one body for both runs -- a loop, not two calls of a lambda: inlined twice the kernel spills)
+    const bool paced = pace > 0 && n_split == 1;
+#pragma unroll 1
+    for (int rr = 0; rr < (paced ? 2 : 1); ++rr) {
+        const int c0 = paced ? (rr == 0 ? c_start : chunk0) : chunk0, c1 = paced ? (rr == 0 ? chunk1 : c_start) : chunk1;
+        if (c0 >= c1) continue;
+        run_first = c0;
+#define S3H_SEEK(P) ptr##P += (int64_t)c0 * 128;
+        S3_REP16(S3H_SEEK)
+#undef S3H_SEEK
+        wait_slot();
+        S3H_ISSUE(A, c0, 0);
+        S3H_ISSUE(B, c0 + 1, 1);
+        int done = 0;
+        for (int chunk = c0; chunk < c1; chunk += 2) {
+            S3_REP16(S3H_STORE_AB)
+            S3H_STORES_DONE();
+            __syncthreads();
+            if (chunk + 1 < c1) {
+                wait_slot();
+                S3H_ISSUE(A, chunk + 2, 2);
+            }
+            accumulate(chunk);
+            __syncthreads();
+            if (chunk + 1 >= c1) break;
+            S3_REP16(S3H_STORE_BA)
+            S3H_STORES_DONE();
+            __syncthreads();
+            if (chunk + 2 < c1) {
+                wait_slot();
+                S3H_ISSUE(B, chunk + 3, 3);
+            }
+            accumulate(chunk + 1);
+            __syncthreads();
+            S3_REP16(S3H_ADVANCE)
+            ++done;
+        }
+        if (defer) {                             // the held piece of the run's last chunk (ragged tails: nothing beyond the row)
+            const int64_t col0 = (int64_t)(c1 - 1) * EPC;
+            if constexpr (EPV == 4) {
+                const double held[EPV] = {held0, held1, held2, held3};
+                store_piece<EPV>(out + cell * row_len + col0 + (v0 + 4) * EPV, held, row_len - col0 - (int64_t)(v0 + 4) * EPV, even_rows);
+            }
+        }
+        // back to line 0 of the rows (a second run starts from there)
+        const int64_t back = (int64_t)c0 * 128 + (int64_t)done * 256;
+#define S3H_REWIND(P) ptr##P -= back;
+        S3_REP16(S3H_REWIND)
+#undef S3H_REWIND
     }
 #undef S3H_ADVANCE
 #undef S3H_DECL
@@ -1226,8 +1300,6 @@ static int plan_schedule(s3_interp_plan *p, hipStream_t st) {
         tiles.insert(tiles.end(), lists[b].begin(), lists[b].end());
         begin[b + 1] = (int32_t)tiles.size();
     }
-    S3_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&p->sched_tiles), sizeof(int32_t) * std::max<size_t>(nt, 1)));
-    S3_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&p->sched_begin), sizeof(int32_t) * ((size_t)wgs + 1)));
     // what the persistent kernel needs to know of a tile, in list order: the descriptors of the tiles ahead sit at known
     // addresses and are fetched a whole step early (looked up through the tile id they were a chain of two dependent round trips
     // per tile, in front of the accumulate phase)
@@ -1236,14 +1308,36 @@ static int plan_schedule(s3_interp_plan *p, hipStream_t st) {
         const int32_t t = tiles[i];
         desc[i] = make_int4(rb[t], rb[t + 1] - rb[t], cb[t], cb[t + 1] - cb[t]);
     }
-    S3_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&p->pl), sizeof(uint16_t) * (size_t)p->nc * 32));
-    lane_positions_kernel<<<(unsigned)p->n_tiles, 256, 0, st>>>(p->tile_cell_begin, p->loc, p->k, p->pl);
-    S3_LAUNCH_CHECK();
-    S3_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&p->sched_desc), sizeof(int4) * desc.size()));
-    S3_HIP_CHECK(hipMemcpyAsync(p->sched_desc, desc.data(), sizeof(int4) * desc.size(), hipMemcpyHostToDevice, st));
-    S3_HIP_CHECK(hipMemcpyAsync(p->sched_tiles, tiles.data(), sizeof(int32_t) * nt, hipMemcpyHostToDevice, st));
-    S3_HIP_CHECK(hipMemcpyAsync(p->sched_begin, begin.data(), sizeof(int32_t) * ((size_t)wgs + 1), hipMemcpyHostToDevice, st));
-    S3_HIP_CHECK(hipStreamSynchronize(st));
+    // built into locals and handed to the plan only when every step has succeeded: a failure half way (a transient out-of-memory)
+    // must not leave a plan whose next launch skips this function and runs with a grid of 0 workgroups and null tables
+    int32_t *d_tiles = nullptr, *d_begin = nullptr;
+    int4 *d_desc = nullptr;
+    uint16_t *d_pl = nullptr;
+    auto build = [&]() -> int {
+        S3_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&d_tiles), sizeof(int32_t) * std::max<size_t>(nt, 1)));
+        S3_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&d_begin), sizeof(int32_t) * ((size_t)wgs + 1)));
+        S3_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&d_pl), sizeof(uint16_t) * (size_t)p->nc * 32));
+        lane_positions_kernel<<<(unsigned)p->n_tiles, 256, 0, st>>>(p->tile_cell_begin, p->loc, p->k, d_pl);
+        S3_LAUNCH_CHECK();
+        S3_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&d_desc), sizeof(int4) * desc.size()));
+        S3_HIP_CHECK(hipMemcpyAsync(d_desc, desc.data(), sizeof(int4) * desc.size(), hipMemcpyHostToDevice, st));
+        S3_HIP_CHECK(hipMemcpyAsync(d_tiles, tiles.data(), sizeof(int32_t) * nt, hipMemcpyHostToDevice, st));
+        S3_HIP_CHECK(hipMemcpyAsync(d_begin, begin.data(), sizeof(int32_t) * ((size_t)wgs + 1), hipMemcpyHostToDevice, st));
+        S3_HIP_CHECK(hipStreamSynchronize(st));
+        return S3_OK;
+    };
+    const int rc = build();
+    if (rc != S3_OK) {
+        if (d_tiles) (void)hipFree(d_tiles);
+        if (d_begin) (void)hipFree(d_begin);
+        if (d_pl) (void)hipFree(d_pl);
+        if (d_desc) (void)hipFree(d_desc);
+        return rc;
+    }
+    p->sched_tiles = d_tiles;
+    p->sched_begin = d_begin;
+    p->pl = d_pl;
+    p->sched_desc = d_desc;
     p->sched_wgs = wgs;
     return S3_OK;
 }
@@ -1396,9 +1490,11 @@ static int launch_planned(s3_interp_plan *p, const int32_t *rows, int64_t n_rows
     if (shift_ok) {
         auto kern = interp_planned_shift_kernel<T>;
         S3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        // (S3_OUT_HOLD=0: every step writes its own 256 bytes, for A/B runs)
+        const char *he = getenv("S3_OUT_HOLD"), *pe = getenv("S3_PACE_TICKS");
         kern<<<grid, 256, lds, st>>>(p->perm, p->tile_cell_begin, p->tile_row_begin, rows, p->loc, p->wp, p->k, p->ucap,
                                      static_cast<const T *>(data), row_len, in_stride, out, p->n_tiles, tiles_per_xcd,
-                                     chunks_per_block, n_chunks, brick, gy);
+                                     chunks_per_block, n_chunks, brick, gy, he ? atoi(he) : 1, pe ? atoi(pe) : 0);
         S3_LAUNCH_CHECK();
         return S3_OK;
     }

@@ -13,7 +13,7 @@
 #include <thread>
 #include <vector>
 
-#include <emmintrin.h>
+#include "host_lanes.h"
 #include <pthread.h>
 #include <unistd.h>
 #include <sched.h>
@@ -66,54 +66,6 @@ int upload_threads() {
     }();
     return v;
 }
-
-// Rows appended back to back into a 64-byte aligned pinned buffer with NON-TEMPORAL stores: a plain memcpy into the staging
-// buffer first reads every destination line into the cache (write-allocate) and writes it back later, next to the DMA engine
-// that reads the same lines for the transfer -- four trips through the host's memory system per byte uploaded.  Streaming
-// stores skip the read and leave the caches to the source rows.
-struct StreamPacker {
-    static constexpr int BLOCK = 4096;               // flushed at a time; pieces of up to BLOCK bytes go through the bounce buffer
-    char *dst;
-    alignas(64) char bounce[2 * BLOCK];
-    int fill = 0;
-    explicit StreamPacker(char *d) : dst(d) {}
-    static void stream(char *d, const char *s, size_t n) {      // n = multiple of 64, d 64-byte aligned
-        for (size_t o = 0; o < n; o += 64) {
-            const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i *>(s + o)), b = _mm_loadu_si128(reinterpret_cast<const __m128i *>(s + o + 16)),
-                          c = _mm_loadu_si128(reinterpret_cast<const __m128i *>(s + o + 32)), e = _mm_loadu_si128(reinterpret_cast<const __m128i *>(s + o + 48));
-            _mm_stream_si128(reinterpret_cast<__m128i *>(d + o), a);
-            _mm_stream_si128(reinterpret_cast<__m128i *>(d + o + 16), b);
-            _mm_stream_si128(reinterpret_cast<__m128i *>(d + o + 32), c);
-            _mm_stream_si128(reinterpret_cast<__m128i *>(d + o + 48), e);
-        }
-    }
-    void append(const char *src, size_t n) {
-        while (n) {
-            if (fill == 0 && n >= BLOCK) {                       // long pieces: whole lines straight from the source
-                const size_t whole = n & ~(size_t)63;
-                stream(dst, src, whole);
-                dst += whole; src += whole; n -= whole;
-                continue;
-            }
-            const size_t m = std::min(n, (size_t)(2 * BLOCK - fill));
-            std::memcpy(bounce + fill, src, m);                  // short pieces gather in the (cache-resident) bounce buffer ...
-            fill += (int)m; src += m; n -= m;
-            if (fill >= BLOCK) {                                 // ... and leave it a block at a time
-                const int whole = fill & ~63;
-                stream(dst, bounce, (size_t)whole);
-                dst += whole;
-                std::memmove(bounce, bounce + whole, (size_t)(fill - whole));
-                fill -= whole;
-            }
-        }
-    }
-    void finish() {
-        const int whole = fill & ~63;
-        stream(dst, bounce, (size_t)whole);
-        if (fill > whole) std::memcpy(dst + whole, bounce + whole, (size_t)(fill - whole));
-        _mm_sfence();
-    }
-};
 
 // ... for LARGE uploads only: a small batch's staging lines are still in the last-level cache when the DMA engine comes for them
 // (16 buffers of 8 MB), and streaming them to DRAM first makes it slower.  MI355X host, batches back to back, download of the
@@ -187,15 +139,29 @@ const NodeCpus &gpu_node_cpus(int dev) {
     }
     return table[dev];
 }
-// this thread onto the GPU's node (within its present mask); restores the mask when it goes out of scope if `restore`
+// the affinity mask the process was given, saved the first time anybody asks (before this library has moved any thread): the pool's
+// threads are pinned PERMANENTLY, and a thread pinned to the node of the first GPU it served must be able to move to another
+// GPU's node later -- the intersection is taken with this mask, not with the thread's present one
+const cpu_set_t &process_mask() {
+    static const cpu_set_t saved = [] {
+        cpu_set_t m;
+        CPU_ZERO(&m);
+        if (sched_getaffinity(getpid(), sizeof(m), &m) != 0)
+            for (int i = 0; i < CPU_SETSIZE; ++i) CPU_SET(i, &m);
+        return m;
+    }();
+    return saved;
+}
+// this thread onto the GPU's node (within the process's mask); restores its previous mask when it goes out of scope if `restore`
 struct OnGpuNode {
     cpu_set_t before;
     bool changed = false, restore;
     OnGpuNode(int dev, bool restore_) : restore(restore_) {
+        const cpu_set_t &allowed = process_mask();
         const NodeCpus &nc = gpu_node_cpus(dev);
         if (!nc.known || pthread_getaffinity_np(pthread_self(), sizeof(before), &before) != 0) return;
         cpu_set_t want;
-        CPU_AND(&want, &before, &nc.set);
+        CPU_AND(&want, &allowed, &nc.set);
         if (CPU_COUNT(&want) == 0 || CPU_EQUAL(&want, &before)) return;
         changed = pthread_setaffinity_np(pthread_self(), sizeof(want), &want) == 0;
     }
@@ -204,71 +170,7 @@ struct OnGpuNode {
     }
 };
 
-// The lanes' host threads, kept between calls (creating seven threads cost an upload or download ~0.2 ms: 4 % of a 25-snapshot
-// batch).  run(n, fn): fn(0) on the caller, fn(1 .. n-1) on the pool's threads; returns when all are done.  One job at a time (the
-// callers hold g_upload_mutex).  S3_LANE_POOL=0: a fresh thread per lane and call, as before (A/B runs).
-class LanePool {
-    int n_threads = 0;                   // (detached: nothing of the pool is torn down at process exit -- a blocked thread there is
-    pid_t owner = 0;                     //  the kernel's to end; a forked child starts its own)
-    std::mutex m;
-    std::condition_variable cv_go, cv_done;
-    const std::function<void(int)> *job = nullptr;
-    int n_active = 0, remaining = 0;
-    uint64_t generation = 0;
-    bool stop = false;
-
-    void loop(int t, uint64_t seen) {
-        while (true) {
-            const std::function<void(int)> *fn = nullptr;
-            {
-                std::unique_lock<std::mutex> lk(m);
-                cv_go.wait(lk, [&] { return stop || generation != seen; });
-                if (stop) return;
-                seen = generation;
-                if (t < n_active) fn = job;
-            }
-            if (!fn) continue;
-            (*fn)(t);
-            std::lock_guard<std::mutex> lk(m);
-            if (--remaining == 0) cv_done.notify_all();
-        }
-    }
-
-public:
-    void run(int n, const std::function<void(int)> &fn) {
-        static const bool pooled = [] { const char *e = getenv("S3_LANE_POOL"); return !(e && e[0] == '0'); }();
-        if (!pooled) {
-            std::vector<std::thread> fresh;
-            for (int t = 1; t < n; ++t) fresh.emplace_back(fn, t);
-            fn(0);
-            for (auto &w : fresh) w.join();
-            return;
-        }
-        {
-            std::lock_guard<std::mutex> lk(m);
-            if (owner != getpid()) {                         // first use, or the threads belong to the process this one was forked from
-                owner = getpid();
-                n_threads = 0;
-                generation = 0;
-            }
-            while (n_threads < n - 1) {
-                const int t = ++n_threads;
-                const uint64_t start = generation;           // (a thread born now must not take a job that was finished before it)
-                std::thread([this, t, start] { loop(t, start); }).detach();
-            }
-            job = &fn;
-            n_active = n;
-            remaining = n - 1;
-            ++generation;
-        }
-        cv_go.notify_all();
-        fn(0);
-        std::unique_lock<std::mutex> lk(m);
-        cv_done.wait(lk, [&] { return remaining == 0; });
-        job = nullptr;
-    }
-};
-LanePool &g_pool = *new LanePool();      // (never destroyed: see above)
+LanePool &g_pool = *new LanePool();      // (the object itself is never destroyed; its threads end in s3_shutdown)
 
 hipError_t upload_lane_init(UploadLane &l) {
     for (int b = 0; b < UP_BUFS; ++b) {
@@ -507,6 +409,13 @@ int s3_download(void *h_dst, const void *d_src, size_t bytes, s3_stream stream) 
 const char *s3_last_error(void) { return s3::g_err; }
 
 int s3_abi_version(void) { return S3_ABI_VERSION; }
+
+// stops and joins the host threads the library keeps between calls (the transfer lanes); returns how many were joined.  Meant
+// for the very end of a process: the bindings call it from an atexit hook that runs BEFORE the interpreter and the HIP runtime
+// tear down (round 4 ended a suite run with a core dump in a joining destructor at static-destruction time and then detached
+// the threads for good; joining them while everything they could touch is still alive is the orderly form).  Harmless at any
+// other time: the next upload / download starts fresh lanes.
+int s3_shutdown(void) { return s3::g_pool.shutdown(); }
 
 int s3_device_count(int *h_count) {
     S3_REQUIRE(h_count != nullptr, "s3_device_count: null output");

@@ -16,7 +16,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-H5_SO = os.path.join(_HERE, "libs3h5.so")
+H5_SO = os.environ.get("S3_H5_SO") or os.path.join(_HERE, "libs3h5.so")             # (S3_H5_SO: the sanitizer build of the CPU test job)
 
 _CODES = {np.dtype(np.float32): 0, np.dtype(np.float64): 1, np.dtype(np.int32): 2, np.dtype(np.int64): 3, np.dtype(np.uint8): 4}
 _TYPES = {v: k for k, v in _CODES.items()}
@@ -83,7 +83,8 @@ class NativeH5File:
         self.path, self.mode = path, mode
         self._h = C.c_void_p(0)
         self._check(self._lib.s3h5_open(os.fsencode(path), mode.encode(), C.byref(self._h)), f"open {path!r}")
-        self._keep = []                                 # host buffers of queued writes
+        self._keep = {}                                 # host buffers of queued writes, by address: the same two stages and one flag
+                                                        # come back batch after batch -- the dict does not grow with the export
 
     def _check(self, rc, what):
         if rc < 0:
@@ -104,7 +105,7 @@ class NativeH5File:
         if h is not None and h.value:
             self._h = C.c_void_p(0)
             self._check(self._lib.s3h5_close(h), "close")
-            self._keep = []
+            self._keep = {}
 
     def __del__(self):
         try:
@@ -140,15 +141,15 @@ class NativeH5File:
                                                               _CODES[a.dtype], a.ndim - 1, dims, a.ctypes.data_as(C.c_void_p),
                                                               stride, flag, value),
                     f"queue {group}/*/{name}")
-        self._keep.append(host)
+        self._keep[a.ctypes.data] = host
         if ready is not None:
-            self._keep.append(ready[0])
+            self._keep[ready[0].data_ptr()] = ready[0]
 
     def flush(self):
         """wait for the queued writes; returns how many datasets were skipped because they existed"""
         skipped = C.c_int64(0)
         self._check(self._lib.s3h5_flush(self._h, C.byref(skipped)), "flush")
-        self._keep = []
+        self._keep = {}
         return skipped.value
 
     def wait_buffer(self, host):

@@ -68,6 +68,38 @@ def temporal_mean(field: pt.Tensor) -> pt.Tensor:
     return temporal_moments(field)[0]
 
 
+class RunningMoments:
+    """mean / standard deviation over time of a field that arrives in snapshot BATCHES (the reference's cylinder3D script never
+    holds all snapshots at once, examples/s3_for_cylinder3D_Re3900.py:28-69): every batch is reduced by one streaming pass on the
+    GPU (``temporal_moments``) and merged into the running (count, mean, M2) per cell with the pairwise update of Chan et al. --
+    float64 throughout, equal to ``torch.std`` / ``torch.mean`` over the concatenated snapshots to rounding"""
+
+    def __init__(self):
+        self.count, self._mean, self._m2 = 0, None, None
+
+    def update(self, batch: pt.Tensor) -> "RunningMoments":
+        n_b = int(batch.shape[-1])
+        if n_b == 0:
+            return self
+        mean_b, std_b = temporal_moments(batch, unbiased=False)
+        m2_b = std_b * std_b * n_b
+        if self.count == 0:
+            self.count, self._mean, self._m2 = n_b, mean_b, m2_b
+            return self
+        n = self.count + n_b
+        delta = mean_b - self._mean
+        self._mean = self._mean + delta * (n_b / n)
+        self._m2 = self._m2 + m2_b + delta * delta * (self.count * n_b / n)
+        self.count = n
+        return self
+
+    def mean(self) -> pt.Tensor:
+        return self._mean
+
+    def std(self, unbiased: bool = True) -> pt.Tensor:
+        return (self._m2 / (self.count - 1 if unbiased else self.count)).sqrt()
+
+
 def tke_from_uprime2mean(prime2mean: pt.Tensor) -> pt.Tensor:
     """turbulent kinetic energy ``0.5 * (u'u' + v'v' + w'w')`` from one snapshot of OpenFOAM's ``UPrime2Mean`` field -- the
     metric of the reference's cylinder3D script, examples/s3_for_cylinder3D_Re3900.py:104

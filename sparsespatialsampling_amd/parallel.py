@@ -295,6 +295,13 @@ class SharedMemoryUnavailable(OSError):
     """raised on EVERY rank when the node's shared-memory file system cannot hold a batch buffer (a container with a 64-MB /dev/shm)"""
 
 
+def _boot_id():
+    try:
+        return open("/proc/sys/kernel/random/boot_id").read().strip()
+    except OSError:
+        return ""
+
+
 class SharedHostArray:
     """``n_bytes`` of host memory that every rank of the node maps (POSIX shared memory) and that every rank's GPU can write
     through its own PCIe link (``s3_host_register``): the snapshot-major batch buffer of the sharded export.  Collective:
@@ -306,33 +313,55 @@ class SharedHostArray:
 
     def __init__(self, comm, n_bytes, register=True):
         import mmap
+        import socket
         self.n_bytes = int(n_bytes)
         SharedHostArray._serial += 1
-        proposal = None
+        proposal, fd = None, None
         if comm.rank == 0:
-            try:                                             # room for the buffer (tmpfs pages are committed when touched: a buffer
-                st = os.statvfs("/dev/shm")                  # that does not fit ends in SIGBUS, not in an error)
-                fits = st.f_bavail * st.f_frsize >= self.n_bytes + (64 << 20)
+            # the root creates the segment BEFORE it tells anybody its name: a failure here (no room -- tmpfs pages are committed
+            # when touched, a buffer that does not fit ends in SIGBUS, not in an error --, no permission, a name that exists) is
+            # broadcast as an empty name, so that all ranks leave together instead of waiting at a barrier the root never reaches
+            try:
+                st = os.statvfs("/dev/shm")
+                if st.f_bavail * st.f_frsize < self.n_bytes + (64 << 20):
+                    raise OSError("not enough room in /dev/shm")
+                name = f"s3_{os.getpid()}_{SharedHostArray._serial}"
+                fd = os.open(os.path.join("/dev/shm", name), os.O_CREAT | os.O_EXCL | os.O_RDWR, 0o600)
+                os.ftruncate(fd, max(self.n_bytes, 1))
+                # (the host's identity travels with the name: a rank on another node must not look for the segment in ITS /dev/shm)
+                proposal = (name + "\n" + socket.gethostname() + "\n" + _boot_id()).encode()
             except OSError:
-                fits = False
-            proposal = f"s3_{os.getpid()}_{SharedHostArray._serial}".encode() if fits else b""
-        name = comm.broadcast_bytes(proposal).decode()
-        if not name:                                         # (decided by the root, learnt by everybody: all ranks take the same way)
+                if fd is not None:
+                    os.close(fd)
+                    fd = None
+                proposal = b""
+        msg = comm.broadcast_bytes(proposal).decode()
+        if not msg:                                          # (decided by the root, learnt by everybody: all ranks take the same way)
             raise SharedMemoryUnavailable(f"/dev/shm cannot hold a batch buffer of {self.n_bytes} bytes")
+        name, root_host, root_boot = msg.split("\n")
         path = os.path.join("/dev/shm", name)
-        if comm.rank == 0:
-            fd = os.open(path, os.O_CREAT | os.O_EXCL | os.O_RDWR, 0o600)
-            os.ftruncate(fd, max(self.n_bytes, 1))
-        comm.barrier()                                       # the segment exists and has its size
+        ok, self._map = True, None
         try:
+            if (socket.gethostname(), _boot_id()) != (root_host, root_boot):
+                raise OSError("this rank runs on another host than rank 0")
             if comm.rank != 0:
                 fd = os.open(path, os.O_RDWR)
             self._map = mmap.mmap(fd, max(self.n_bytes, 1))
-            os.close(fd)
+        except OSError:
+            ok = False
         finally:
-            comm.barrier()                                   # everybody holds a mapping (or has failed loudly)
-            if comm.rank == 0:
-                os.unlink(path)
+            if fd is not None:
+                os.close(fd)
+        # everybody reports; nobody goes on with a buffer that somebody else does not have
+        everybody = comm.allreduce_max(0.0 if ok else 1.0) == 0.0
+        if comm.rank == 0:
+            os.unlink(path)                                  # the mappings keep the pages; nothing is left behind whatever happens later
+        if not everybody:
+            if self._map is not None:
+                self._map.close()
+                self._map = None
+            raise SharedMemoryUnavailable("not every rank could map the shared batch buffer (ranks on several hosts, or no "
+                                          "access to /dev/shm)")
         self.array = np.frombuffer(self._map, dtype=np.uint8)
         self.device_ptr = None
         if register and self.n_bytes:

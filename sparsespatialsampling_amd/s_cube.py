@@ -651,6 +651,12 @@ class SamplingTree(object):
         order = _ordered(to_refine)
         if len(order):
             self._current_max_level = max(self._current_max_level, int(self._topo_engine.level_now[order].max()) + 1)
+        if len(order) == 1 and not getattr(self, "_warned_single_cell", False):
+            # deviation on an input the reference rejects: with exactly one cell to refine its `_compute_cell_centers` squeezes the
+            # cell axis away (s_cube.py:445) and `_refine_cells` then indexes a 2-D tensor with three indices (s_cube.py:883)
+            logger.warning("Exactly one cell is refined in this step: the reference implementation raises an IndexError here "
+                           "(s_cube.py:445, 883); this implementation refines the cell and continues.")
+            self._warned_single_cell = True
         first, n_new = self._refine_batch(order, uniform=False)
         all_parents, all_children = self._batch_sets(order, first, n_new)
         self._update_leaf_cells(all_parents, all_children)

@@ -305,7 +305,14 @@ def test_snapshot_pieces_follow_chunk_size(export_mod, tmp_path, monkeypatch):
             assert pieces == [(0, t)]
         else:
             lengths = [b - a for a, b in pieces]
-            assert all(n % 8 == 0 for n in lengths[:-1]) and max(lengths) <= want + 8 and len(pieces) == -(-t // want)
+            assert all(n % 8 == 0 for n in lengths[:-1]) and len(pieces) in (-(-t // want), -(-t // want) - 1)
+            assert max(lengths) <= want + 8 + 15 and min(lengths) >= 16           # (a tail of < 16 snapshots joins the piece before it)
+    # the tails the rounding to multiples of 8 used to leave: 97 = 32 + 32 + 32 + 1, 129 = 4 x 32 + 1
+    ex._chunk_size = 50
+    for t in (97, 98, 99, 129, 130, 161, 1001):
+        pieces = ex._snapshot_pieces(pt.zeros((10, 1, t), dtype=pt.float32), 1, t)
+        assert pieces[0][0] == 0 and pieces[-1][1] == t and all(a[1] == b[0] for a, b in zip(pieces, pieces[1:]))
+        assert min(b - a for a, b in pieces) >= 16, (t, pieces)
     monkeypatch.setenv("S3_EXPORT_PIPELINE", "0")
     assert ex._snapshot_pieces(pt.zeros((10, 1, 1000), dtype=pt.float32), 1, 1000) == [(0, 1000)]
 

@@ -45,6 +45,9 @@ def test_bench_contract_small_workload():
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(res["cpu_baseline"]) and res["cpu_baseline"]["kind"] == "port"
     assert res["config"]["parallelism"] == "leaf-cell shards x1"
     assert res["refine_cpu_baseline"]["same_grid_size"] and res["refine_cpu_baseline"]["speedup"] > 1
+    # full-size parity in the bench run itself: centres, levels, faces, nodes of the CPU port's grid == the HIP backend's, by SHA-256
+    assert res["refine_cpu_baseline"]["same_grid_sha"] and res["refine_cpu_baseline"]["grid_sha256_gpu"] == res["grid_sha256"]
+    assert set(("host_cpus", "cgroup_cpus", "threads_used", "all_cells")) <= set(res["cpu_baseline"]) and res["cpu_baseline"]["all_cells"]
     assert res["end_to_end"]["T25"]["Gcells_snapshots_per_s"] > 0
 
 
@@ -66,6 +69,49 @@ def test_bench_two_ranks_share_one_gpu():
     assert r2["n_gpus"] == 2 and r2["config"]["parallelism"] == "leaf-cell shards x2" and r2["config"]["collectives"] == "gloo"
     assert r1["config"]["n_cells"] == r2["config"]["n_cells"] and r1["refine_cells_created"] == r2["refine_cells_created"]
     assert r1["captured_metric"] == r2["captured_metric"] and r1["refine_iterations"] == r2["refine_iterations"]
+
+
+def _self_launched_bench(extra_env, timeout=900):
+    import json
+    env = dict(os.environ, S3_BENCH_SHARE_GPU="1", **extra_env)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "S3_DIST_BACKEND"):
+        env.pop(k, None)
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "cylinder3D_small", "--steps", "2",
+                          "--warmup", "1", "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    return run, [json.loads(ln) for ln in run.stdout.splitlines() if ln.startswith("{")]
+
+
+@pytest.mark.gpu
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` the way the driver runs `--gpus 1` -- no torch.distributed.run around it: the parent (which never
+    touches the GPU) starts two fresh ranks, watches them and relays rank 0's ONE JSON line.  Two ranks share the one GPU here; RCCL
+    refuses that inside the ranks, which agree on gloo among themselves (parallel.init) -- the first attempt succeeds."""
+    run, lines = _self_launched_bench({})
+    assert run.returncode == 0, run.stderr[-3000:]
+    assert len(lines) == 1
+    line = lines[0]
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["config"]["parallelism"] == "leaf-cell shards x2"
+    assert line["launcher"]["self_launched"] and [a["ok"] for a in line["launcher"]["attempts"]] == [True]
+    assert "kernel_ms" in line["roofline"] and "ms_per_batch" in line["export_sharded"]
+    assert line["export_sharded"]["data_path_collectives_per_batch"] == 0
+
+
+@pytest.mark.gpu
+def test_bench_watchdog_retries_a_wedged_bootstrap_on_gloo_and_reports_a_dead_run():
+    """(1) rank 1 stops right before the communicator bootstrap on the RCCL attempt: rank 0 waits for it in the rendezvous, nothing
+    inside the ranks can end that.  The parent sees the bootstrap overdue, kills both ranks, starts two FRESH ranks on gloo and
+    relays their line.  (2) the same on every backend: exactly one JSON line with an `error` field, exit status 1."""
+    run, lines = _self_launched_bench(dict(S3_BENCH_HANG="1:alive:rccl", S3_BENCH_BOOT_TIMEOUT_S="15"))
+    assert run.returncode == 0, run.stderr[-3000:]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["value"] > 0
+    att = lines[0]["launcher"]["attempts"]
+    assert [a["backend"] for a in att] == ["rccl", "gloo"] and [a["ok"] for a in att] == [False, True]
+    assert "bootstrap not finished" in att[0]["failure"]            # (rank 0 waits for rank 1 in the rendezvous: neither has a communicator)
+    assert lines[0]["config"]["collectives"] == "gloo"
+    run, lines = _self_launched_bench(dict(S3_BENCH_HANG="1:alive:any", S3_BENCH_BOOT_TIMEOUT_S="10"))
+    assert run.returncode == 1
+    assert len(lines) == 1 and lines[0]["value"] is None and "bootstrap not finished" in lines[0]["error"]
+    assert [a["ok"] for a in lines[0]["launcher"]["attempts"]] == [False, False]
 
 
 @pytest.mark.gpu

@@ -726,6 +726,21 @@ def test_temporal_moments(shape, dtype):
     assert pt.equal(metrics.temporal_mean(field), mean)
 
 
+def test_running_moments_over_snapshot_batches():
+    """the metric of a field that arrives in snapshot batches (reference examples/s3_for_cylinder3D_Re3900.py:28-69 never holds all
+    snapshots): per-batch streaming pass + pairwise merge == torch's mean / std over the concatenated snapshots, 1e-12 relative"""
+    from sparsespatialsampling_amd import metrics
+    gen = pt.Generator().manual_seed(5)
+    field = (pt.randn((3000, 2, 407), generator=gen, dtype=pt.float64) * 2.0 + 50.0 * pt.rand((3000, 2, 1), generator=gen, dtype=pt.float64)).float()
+    run = metrics.RunningMoments()
+    for a, b in ((0, 100), (100, 101), (101, 101), (101, 300), (300, 407)):             # ragged batches, a single snapshot, an empty one
+        run.update(field[:, :, a:b].cuda())
+    assert run.count == 407
+    assert pt.allclose(run.mean().cpu(), field.double().mean(-1), rtol=1e-12, atol=0)
+    assert pt.allclose(run.std().cpu(), field.double().std(-1), rtol=1e-11, atol=0)
+    assert pt.allclose(run.std(unbiased=False).cpu(), field.double().std(-1, unbiased=False), rtol=1e-11, atol=0)
+
+
 def test_temporal_std_is_a_valid_metric():
     """the example workflow: metric = std over time -> SamplingTree (same grid as with torch's std of the f64 data when
     the two metrics agree to rounding)"""

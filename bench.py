@@ -303,6 +303,48 @@ def recorded_traffic(workload_key):
     return None, None, None
 
 
+def measure_traffic(argv, kernel_prefix):
+    """HBM bytes per launch of the headline kernel, measured IN THIS RUN: before this process touches the GPU it starts two child
+    processes of itself under `rocprofv3 --pmc <counter> --kernel-trace` (one pass per counter: FETCH_SIZE and WRITE_SIZE do not fit
+    one pass, MI355X_MICROARCH.md "rocprofv3 PMC slots"), each a short run of the same workload (3 launches), and averages the
+    counter over the launches of the headline kernel.  traffic = 2 x FETCH_SIZE + WRITE_SIZE (gfx950: FETCH_SIZE tallies 128-byte
+    requests at 64 bytes; both in KiB).  -> dict or None (no rocprofv3, a failing pass, a profiler already attached)."""
+    import csv
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None or "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return None
+    out, t0 = {}, time.perf_counter()
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="s3_bench_pmc_")
+        try:
+            cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
+                   os.path.abspath(__file__)] + argv + ["--traffic-child"]
+            run = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdin=subprocess.DEVNULL, stdout=subprocess.DEVNULL,
+                                 stderr=subprocess.PIPE, text=True, timeout=float(os.environ.get("S3_BENCH_PMC_TIMEOUT_S", "300")))
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if run.returncode != 0 or not files:
+                print(f"[bench] PMC pass {counter} failed (rc {run.returncode}): {run.stderr[-300:]}", file=sys.stderr)
+                return None
+            vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(files[0]))
+                    if r["Counter_Name"] == counter and kernel_prefix in r["Kernel_Name"] and "permute" not in r["Kernel_Name"]]
+            if not vals:
+                print(f"[bench] PMC pass {counter}: no launch of {kernel_prefix}", file=sys.stderr)
+                return None
+            out[counter] = (sum(vals) / len(vals), len(vals))
+        except (OSError, subprocess.SubprocessError, ValueError, KeyError) as err:
+            print(f"[bench] PMC pass {counter} failed: {type(err).__name__}: {err}", file=sys.stderr)
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    fetch, write = out["FETCH_SIZE"][0], out["WRITE_SIZE"][0]
+    return dict(traffic=(2.0 * fetch + write) * 1024.0, FETCH_SIZE_KiB_per_launch=fetch, WRITE_SIZE_KiB_per_launch=write,
+                launches_averaged=[out["FETCH_SIZE"][1], out["WRITE_SIZE"][1]], seconds=time.perf_counter() - t0,
+                how="measured in this run: two child processes of this command under rocprofv3 --pmc (one pass per counter, kernel-trace "
+                    "only), 2 x FETCH_SIZE + WRITE_SIZE")
+
+
 def copy_bandwidth_gbs(n_bytes=2 << 30, reps=5):
     """device-to-device copy rate of this box (read + write bytes per second), the practical HBM ceiling next to the
     8 TB/s datasheet peak (report both fractions)"""
@@ -578,6 +620,11 @@ def bench_svd(args, json_fd):
     svd._eigh(gram)
     pt.cuda.synchronize()
     parts["eigen_solve_ms"] = (time.perf_counter() - t1) * 1e3
+    # the ONE library call of the path, said so in the line itself: the symmetric eigen-solve of the T x T Gram matrix
+    # is rocSOLVER through torch.linalg.eigh; everything else of compute_svd is this repository's kernels
+    parts["eigh"] = "library"
+    parts["eigh_library"] = "rocSOLVER (torch.linalg.eigh)"
+    parts["eigh_share_of_compute_svd"] = parts["eigen_solve_ms"] * 1e-3 / float(np.median(steady))
     achieved = flops / (st["kernel_ms"] * 1e-3) / 1e12
     # the tall GEMMs of the same SVD on the same matrix cores (s3_centered_gemm): the mode GEMM U = (X - mean) V S^-1 at the rank
     # compute_svd was asked for (50 columns occupy half of a 128-column tile) and at full width (the shape of a deflation level)
@@ -601,7 +648,7 @@ def bench_svd(args, json_fd):
                         "kernel": "gram_block_kernel", "algorithmic_flops": flops, "traffic": None, **st},
            "mode_gemm": dict(kernel="centered_gemm_kernel", shapes=gemm,
                              note="C[N, r] = (X - mean 1^T) B, X [N, T] f64 as the interpolation left it, B [T, r]; flops 2 N T r"),
-           "compute_svd_s": svd_s, "compute_svd_steady_s": float(np.median(steady)), "compute_svd_parts": parts, "compute_svd_rank": int(len(s_)),
+           "eigh": "library", "compute_svd_s": svd_s, "compute_svd_steady_s": float(np.median(steady)), "compute_svd_parts": parts, "compute_svd_rank": int(len(s_)),
            "compute_svd_note": "mean + Gram kernel + eigen-solve (rocSOLVER, the one library call) + mode GEMM (s3_centered_gemm), rank 50; "
                                "compute_svd_s: first call of the process (the solver library initialises), compute_svd_steady_s: median of the next three"}
     os.write(json_fd, (json.dumps(res) + "\n").encode())
@@ -753,6 +800,9 @@ def main():
     ap.add_argument("--no-batches", action="store_true", help="skip the roofline_batches sub-records")
     ap.add_argument("--no-pitched-copy", action="store_true", help="skip the pitched_copy sub-record (profiling runs: its launches may "
                     "carry the headline kernel's name -- 16-byte aligned rows of up to four chunks -- and would be averaged into its statistics)")
+    ap.add_argument("--no-traffic", action="store_true", help="do not measure roofline.traffic in this run (two rocprofv3 --pmc child passes "
+                    "before the GPU is touched); the recorded value of profiles/ is reported instead, labelled")
+    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)      # (the short run a PMC pass profiles)
     ap.add_argument("--n-comp", type=int, default=1, help="components per snapshot: the row holds n_comp * t_batch values")
     ap.add_argument("--shard", choices=["cells", "snapshots"], default="cells",
                     help="N>1: every rank interpolates its contiguous range of the generated cells for the same snapshots "
@@ -763,6 +813,9 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
         sys.exit(launch_ranks(args, sys.argv[1:]))            # no launcher around us: start (and watch) the N ranks ourselves
+    if args.traffic_child:                 # what a PMC pass profiles: the headline launch only, three times
+        args.steps, args.warmup = 3, 1
+        args.no_cpu_baseline = args.no_batches = args.no_pitched_copy = args.no_traffic = True
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -780,6 +833,13 @@ def main():
     _mark("start")                         # (watchdog protocol of a self-launched run: nothing has touched the GPU yet)
     if rank == 0:
         query_rocm_smi()                   # (before anything initialises the GPU)
+    measured = None
+    if rank == 0 and world == 1 and not args.no_traffic and args.workload != "svd" and not args.direct:
+        # (also before anything initialises the GPU: the passes are child processes of this one)
+        child_argv = [a for a in sys.argv[1:] if a not in ("--no-cpu-baseline", "--no-batches", "--no-pitched-copy")]
+        measured = optional_leg("measure_traffic", lambda: measure_traffic(child_argv, "interp_planned"))
+        if isinstance(measured, dict) and "error" in measured:
+            measured = None
     # S3_BENCH_SHARE_GPU=1 + S3_DIST_BACKEND=gloo: rehearsal of the N>1 code path on a box with a single GPU
     share = os.environ.get("S3_BENCH_SHARE_GPU") == "1"
     pt.cuda.set_device(0 if share else local_rank)
@@ -821,7 +881,7 @@ def main():
     # the grid generation is timed four times: the first full-size run of the process also pays for the device allocations
     # (cell arrays, topology tables, allocator pools) -- it is reported apart, `refine_wall_s` is the median of the other three
     timings = []
-    for attempt in range(4):
+    for attempt in range(1 if args.traffic_child else 4):
         pt.cuda.synchronize()
         comm.barrier()
         t0 = time.perf_counter()
@@ -833,6 +893,8 @@ def main():
         centers = tree.all_centers.numpy()
         tree_out = (tree.all_centers, tree.all_nodes, tree.face_ids, tree.all_levels, float(tree.width))
         sha_gpu = grid_sha(tree.all_centers, tree.all_levels, tree.face_ids, tree.all_nodes) if attempt == 3 else None
+        if args.traffic_child:
+            timings = timings * 4
         info = dict(tree.data_final_mesh)
         n_cells_total = tree._topo_engine.n_created
         tree.close()
@@ -941,6 +1003,10 @@ def main():
         shape_key = f"T{t_b}" + (f"x{args.n_comp}" if args.n_comp > 1 else "")
         traffic, traffic_src, traffic_stale = (recorded_traffic(f"{args.workload}/{shape_key}/inplace") if plan is not None and world == 1
                                                else (None, None, None))
+        recorded = traffic
+        traffic_how = None if traffic is None else f"recorded, not measured in this run: {traffic_src}"
+        if measured is not None:           # measured in THIS run (two PMC child passes before the GPU was touched): preferred
+            traffic, traffic_how, traffic_stale = measured["traffic"], measured["how"], False
         res = {
             "metric": "Mcells*snapshots/s interpolated", "value": value, "unit": "Mcells*snapshots/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -958,8 +1024,9 @@ def main():
             "captured_metric": info["metric_per_iter"][-1], "grid_sha256": sha_gpu,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "copy_kernel_GBs": copy_bw, "frac_of_copy_kernel": achieved / copy_bw,
-                         "traffic": traffic, "traffic_source": None if traffic is None else f"recorded, not measured in this run: {traffic_src}",
-                         "traffic_stale": traffic_stale,
+                         "traffic": traffic, "traffic_source": traffic_how, "traffic_stale": traffic_stale,
+                         "traffic_over_algorithmic": None if traffic is None else traffic / b_alg,
+                         "traffic_measured": measured, "traffic_recorded_in_profiles": recorded,
                          "kernel": "interp_kernel<float,4>" if plan is None else planned_kernel_name(row_len, k, plan.n_tiles, row_len, table_bytes=len(x) * row_len * 4),
                          "staged_rows_per_launch": None if plan is None else plan.total_rows, **ms_stats(launch_ms),
                          "frac_best_launch": b_alg / (min(launch_ms) * 1e-3) / 8e12,

@@ -32,6 +32,7 @@ __device__ long long s3_probe_stamps[1024 * 4 * 8];
 
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <exception>
 #include <type_traits>
 #include <vector>
@@ -431,13 +432,34 @@ __device__ __forceinline__ void brick_map(int64_t b, int64_t tiles_per_xcd, int 
     tile = (b & 7) * tiles_per_xcd + bk * brick + (rem - (int64_t)run * bl);
 }
 
+// The same with a finer grain at the END of every XCD's share: the last `tail` tiles are cut into `tail_split` runs of column
+// chunks each (run-major among them), all tiles before them are swept whole.  While the launch drains -- the last tile of a slot
+// starts up to one tile lifetime (~240 us of a 3.6-ms launch) before the end, and the slots empty one by one -- the pieces still
+// waiting are short, so the chip stays full for longer.  -> tile, [chunk0, chunk1)
+__device__ __forceinline__ void tail_map(int64_t b, int64_t tiles_per_xcd, int tail, int tail_split, int n_chunks, int64_t &tile,
+                                         int &chunk0, int &chunk1) {
+    const int64_t i = b >> 3, head = tiles_per_xcd - tail;
+    if (i < head) {
+        tile = (b & 7) * tiles_per_xcd + i;
+        chunk0 = 0;
+        chunk1 = n_chunks;
+        return;
+    }
+    const int64_t j = i - head;
+    const int run = (int)(j / tail);
+    const int per = (n_chunks + tail_split - 1) / tail_split;
+    tile = (b & 7) * tiles_per_xcd + head + (j - (int64_t)run * tail);
+    chunk0 = run * per;
+    chunk1 = chunk0 + per < n_chunks ? chunk0 + per : n_chunks;
+}
+
 template <typename T, int TC>
 __global__ void __launch_bounds__(TC * 4, 2)  // 226 VGPRs: two waves per SIMD
 interp_planned_kernel(const int32_t *__restrict__ perm, const int32_t *__restrict__ tile_cell_begin,
                       const int32_t *__restrict__ tile_row_begin, const int32_t *__restrict__ rows,
                       const uint16_t *__restrict__ loc, const double *__restrict__ w /*plan order*/, int k, int ucap,
                       const T *__restrict__ data, int64_t row_len, int64_t in_stride, double *__restrict__ out,
-                      int64_t n_tiles, int64_t tiles_per_xcd, int chunks_per_block, int n_chunks, int brick, int n_split) {
+                      int64_t n_tiles, int64_t tiles_per_xcd, int chunks_per_block, int n_chunks, int brick, int n_split, int tail, int tail_split) {
     using V = typename Vec16<T>::type;
     constexpr int EPV = Vec16<T>::N;                 // elements per 16-byte vector
     constexpr int EPC = PL_SEG / (int)sizeof(T);     // elements per chunk
@@ -449,9 +471,18 @@ interp_planned_kernel(const int32_t *__restrict__ perm, const int32_t *__restric
     uint16_t *s_loc = reinterpret_cast<uint16_t *>(s_w + (size_t)k * TC);        // [k][TC]
 
     int64_t tile;
-    int run;
-    brick_map(blockIdx.x, tiles_per_xcd, brick, n_split, tile, run);     // XCD-aware (speed only)
+    int run = 0, chunk0, chunk1;
+    if (tail > 0) {
+        tail_map(blockIdx.x, tiles_per_xcd, tail, tail_split, n_chunks, tile, chunk0, chunk1);
+    } else {
+        brick_map(blockIdx.x, tiles_per_xcd, brick, n_split, tile, run);     // XCD-aware (speed only)
+        chunk0 = run * chunks_per_block;
+        chunk1 = min(n_chunks, chunk0 + chunks_per_block);
+    }
     if (tile >= n_tiles) return;
+    // (functions of blockIdx: kept in scalar registers -- left to itself the compiler carried them in vector registers and spilled)
+    chunk0 = __builtin_amdgcn_readfirstlane(chunk0);
+    chunk1 = __builtin_amdgcn_readfirstlane(chunk1);
     const int c_begin = tile_cell_begin[tile], n_c = tile_cell_begin[tile + 1] - c_begin;
     const int r_begin = tile_row_begin[tile], n_r = tile_row_begin[tile + 1] - r_begin;
     const bool even_rows = (row_len & 1) == 0;                   // output rows 16-byte aligned -> double2 stores
@@ -465,8 +496,6 @@ interp_planned_kernel(const int32_t *__restrict__ perm, const int32_t *__restric
     const bool has_cell = cl < n_c;
     const int64_t cell = has_cell ? perm[c_begin + cl] : 0;
 
-    const int chunk0 = run * chunks_per_block;
-    const int chunk1 = min(n_chunks, chunk0 + chunks_per_block);
 
     // staging role: 8 lanes per 128-B row segment, 32 rows per pass, <= PL_NP passes.  The row ids of this lane's passes
     // are loaded once per tile; the segment loads of chunk c+1 are issued (into registers) before chunk c is accumulated
@@ -569,7 +598,7 @@ interp_planned_shift_kernel(const int32_t *__restrict__ perm, const int32_t *__r
                             const int32_t *__restrict__ tile_row_begin, const int32_t *__restrict__ rows,
                             const uint16_t *__restrict__ loc, const double *__restrict__ w /*plan order*/, int k, int ucap,
                             const T *__restrict__ data, int64_t row_len, int64_t in_stride, double *__restrict__ out,
-                            int64_t n_tiles, int64_t tiles_per_xcd, int chunks_per_block, int n_chunks, int brick, int n_split, int hold, int pace) {
+                            int64_t n_tiles, int64_t tiles_per_xcd, int chunks_per_block, int n_chunks, int brick, int n_split, int tail, int tail_split, int hold) {
     using V = typename Vec16<T>::type;
     constexpr int TC = 64;
     constexpr int EPV = Vec16<T>::N;
@@ -582,9 +611,18 @@ interp_planned_shift_kernel(const int32_t *__restrict__ perm, const int32_t *__r
     uint16_t *s_loc = reinterpret_cast<uint16_t *>(s_w + (size_t)k * TC);        // [k][TC]
 
     int64_t tile;
-    int run;
-    brick_map(blockIdx.x, tiles_per_xcd, brick, n_split, tile, run);     // XCD-aware (speed only)
+    int run = 0, chunk0, chunk1;
+    if (tail > 0) {
+        tail_map(blockIdx.x, tiles_per_xcd, tail, tail_split, n_chunks, tile, chunk0, chunk1);
+    } else {
+        brick_map(blockIdx.x, tiles_per_xcd, brick, n_split, tile, run);     // XCD-aware (speed only)
+        chunk0 = run * chunks_per_block;
+        chunk1 = min(n_chunks, chunk0 + chunks_per_block);
+    }
     if (tile >= n_tiles) return;
+    // (functions of blockIdx: kept in scalar registers -- left to itself the compiler carried them in vector registers and spilled)
+    chunk0 = __builtin_amdgcn_readfirstlane(chunk0);
+    chunk1 = __builtin_amdgcn_readfirstlane(chunk1);
     const int c_begin = tile_cell_begin[tile], n_c = tile_cell_begin[tile + 1] - c_begin;
     const int r_begin = tile_row_begin[tile], n_r = tile_row_begin[tile + 1] - r_begin;
     const bool even_rows = (row_len & 1) == 0;
@@ -597,8 +635,6 @@ interp_planned_shift_kernel(const int32_t *__restrict__ perm, const int32_t *__r
     const bool has_cell = cl < n_c;
     const int64_t cell = has_cell ? perm[c_begin + cl] : 0;
 
-    const int chunk0 = run * chunks_per_block;
-    const int chunk1 = min(n_chunks, chunk0 + chunks_per_block);
 
     const int srow = threadIdx.x >> 3, svec = threadIdx.x & 7;
     const uintptr_t base = reinterpret_cast<uintptr_t>(data);
@@ -621,7 +657,7 @@ interp_planned_shift_kernel(const int32_t *__restrict__ perm, const int32_t *__r
     {                                                                                                            \
         const uintptr_t a_ = base + (uint64_t)(uint32_t)rows[r_begin + min(P * RPP + srow, n_r - 1)] * stride_bytes; \
         const int ph_ = (int)(a_ >> 4) & 7;                                                                      \
-        ptr##P = data128 + (((a_ & ~(uintptr_t)127) - base128) + 16u * (unsigned)svec);                           \
+        ptr##P = data128 + (((a_ & ~(uintptr_t)127) - base128) + 16u * (unsigned)svec) + (int64_t)chunk0 * 128;   \
         old##P = svec >= ph_;                                                                                    \
         /* (passes beyond the tile's last row hold a copy of it and store that copy where the row itself goes) */  \
         lds##P = (uint32_t)(min(P * RPP + srow, n_r - 1) * 8 + ((svec - ph_) & 7)) * 16u;                         \
@@ -671,7 +707,6 @@ interp_planned_shift_kernel(const int32_t *__restrict__ perm, const int32_t *__r
     bool defer = false;
     if constexpr (std::is_same<T, float>::value)
         defer = has_cell && even_rows && v0 >= 2 && (reinterpret_cast<uintptr_t>(out + cell * row_len) & 127) == 64 && hold != 0;
-    int run_first = 0;                                              // first chunk of the run being swept
     double held0 = 0.0, held1 = 0.0, held2 = 0.0, held3 = 0.0;      // (named: a loop-carried local array ends up in scratch memory)
 
     auto accumulate = [&](int chunk) {
@@ -699,7 +734,7 @@ interp_planned_shift_kernel(const int32_t *__restrict__ perm, const int32_t *__r
         if (defer) {
             // (the chunk before this one is never the row's last: its piece is whole)
             if constexpr (EPV == 4) {
-                if (chunk > run_first) {
+                if (chunk > chunk0) {
                     double *h = o - EPC + (v0 + 4) * EPV;
                     *reinterpret_cast<double2 *>(h) = make_double2(held0, held1);
                     *reinterpret_cast<double2 *>(h + 2) = make_double2(held2, held3);
@@ -711,76 +746,38 @@ interp_planned_shift_kernel(const int32_t *__restrict__ perm, const int32_t *__r
         }
     };
 
-    // (S3_PACE_TICKS, experiment) chunk phase tied to a chip-wide clock: time is cut into slots of `pace` ticks of the 100-MHz
-    // counter; slot n belongs to chunk n mod n_chunks on EVERY workgroup, and a workgroup issues the loads of a step no earlier than
-    // that step's slot begins -- tiles that share rows then ask for the same lines within the time the L2 keeps them.  A tile that
-    // starts in slot n sweeps the chunks n mod n_chunks ... n_chunks - 1 and then 0 ... (n mod n_chunks) - 1 (two runs).
-    unsigned long long slot = 0;
-    int c_start = chunk0;
-    if (pace > 0 && n_split == 1) {
-        __shared__ unsigned long long s_slot;
-        if (threadIdx.x == 0) s_slot = __builtin_amdgcn_s_memrealtime() / (unsigned)pace + 1;
-        __syncthreads();
-        const unsigned long long v_ = s_slot;            // (wave-uniform: into scalar registers)
-        slot = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(v_ >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned)v_);
-        c_start = (int)(slot % (unsigned)n_chunks);
+    // Built, measured and NOT kept (r5): chunk phases tied to a chip-wide clock (time cut into slots of the 100-MHz counter, slot n
+    // belongs to chunk n mod n_chunks on every workgroup, the loads of a step issued no earlier than its slot begins, a tile sweeping
+    // [c_start, n) and then [0, c_start)).  Tiles that share rows then ask for the same lines within the few microseconds the L2 keeps
+    // them: FETCH_SIZE -11.6 % with 10-us slots, -6.3 % at 6.0 us, -3.7 % at 5.4 us (a step takes 5.8 us on its own) -- but the launch
+    // took 4.07 / 3.86 ms against 3.65: in lock-step all workgroups load at once and compute at once, and the overlap between
+    // workgroups that the memory system lives on is gone.  (tools/ab_order.py, tools/pmc_order.sh)
+    if (chunk0 < chunk1) {
+        S3H_ISSUE(A, chunk0, 0);
+        S3H_ISSUE(B, chunk0 + 1, 1);
     }
-    auto wait_slot = [&]() {
-        if (pace > 0 && n_split == 1) {
-            const unsigned long long target = slot * (unsigned)pace;
-            while (__builtin_amdgcn_s_memrealtime() < target) __builtin_amdgcn_s_sleep(4);
-            ++slot;
+    for (int chunk = chunk0; chunk < chunk1; chunk += 2) {
+        S3_REP16(S3H_STORE_AB)
+        S3H_STORES_DONE();
+        __syncthreads();
+        if (chunk + 1 < chunk1) S3H_ISSUE(A, chunk + 2, 2);
+        accumulate(chunk);
+        __syncthreads();
+        if (chunk + 1 >= chunk1) break;
+        S3_REP16(S3H_STORE_BA)
+        S3H_STORES_DONE();
+        __syncthreads();
+        if (chunk + 2 < chunk1) S3H_ISSUE(B, chunk + 3, 3);
+        accumulate(chunk + 1);
+        __syncthreads();
+        S3_REP16(S3H_ADVANCE)
+    }
+    if (defer && chunk1 > chunk0) {              // the held piece of the run's last chunk (ragged tails: nothing beyond the row)
+        const int64_t col0 = (int64_t)(chunk1 - 1) * EPC;
+        if constexpr (EPV == 4) {
+            const double held[EPV] = {held0, held1, held2, held3};
+            store_piece<EPV>(out + cell * row_len + col0 + (v0 + 4) * EPV, held, row_len - col0 - (int64_t)(v0 + 4) * EPV, even_rows);
         }
-    };
-    // (one body for both runs -- a loop, not two calls of a lambda: inlined twice the kernel spills)
-    const bool paced = pace > 0 && n_split == 1;
-#pragma unroll 1
-    for (int rr = 0; rr < (paced ? 2 : 1); ++rr) {
-        const int c0 = paced ? (rr == 0 ? c_start : chunk0) : chunk0, c1 = paced ? (rr == 0 ? chunk1 : c_start) : chunk1;
-        if (c0 >= c1) continue;
-        run_first = c0;
-#define S3H_SEEK(P) ptr##P += (int64_t)c0 * 128;
-        S3_REP16(S3H_SEEK)
-#undef S3H_SEEK
-        wait_slot();
-        S3H_ISSUE(A, c0, 0);
-        S3H_ISSUE(B, c0 + 1, 1);
-        int done = 0;
-        for (int chunk = c0; chunk < c1; chunk += 2) {
-            S3_REP16(S3H_STORE_AB)
-            S3H_STORES_DONE();
-            __syncthreads();
-            if (chunk + 1 < c1) {
-                wait_slot();
-                S3H_ISSUE(A, chunk + 2, 2);
-            }
-            accumulate(chunk);
-            __syncthreads();
-            if (chunk + 1 >= c1) break;
-            S3_REP16(S3H_STORE_BA)
-            S3H_STORES_DONE();
-            __syncthreads();
-            if (chunk + 2 < c1) {
-                wait_slot();
-                S3H_ISSUE(B, chunk + 3, 3);
-            }
-            accumulate(chunk + 1);
-            __syncthreads();
-            S3_REP16(S3H_ADVANCE)
-            ++done;
-        }
-        if (defer) {                             // the held piece of the run's last chunk (ragged tails: nothing beyond the row)
-            const int64_t col0 = (int64_t)(c1 - 1) * EPC;
-            if constexpr (EPV == 4) {
-                const double held[EPV] = {held0, held1, held2, held3};
-                store_piece<EPV>(out + cell * row_len + col0 + (v0 + 4) * EPV, held, row_len - col0 - (int64_t)(v0 + 4) * EPV, even_rows);
-            }
-        }
-        // back to line 0 of the rows (a second run starts from there)
-        const int64_t back = (int64_t)c0 * 128 + (int64_t)done * 256;
-#define S3H_REWIND(P) ptr##P -= back;
-        S3_REP16(S3H_REWIND)
-#undef S3H_REWIND
     }
 #undef S3H_ADVANCE
 #undef S3H_DECL
@@ -1482,19 +1479,34 @@ static int launch_planned(s3_interp_plan *p, const int32_t *rows, int64_t n_rows
     gy = (n_chunks + chunks_per_block - 1) / chunks_per_block;
     int brick = (int)std::min<int64_t>(tiles_per_xcd, 1 << 30);
     if (const char *e = getenv("S3_PLAN_BRICK")) brick = std::max(1, std::min(brick, atoi(e)));
-    S3_REQUIRE(gx * gy < ((int64_t)1 << 31), "s3_interp_planned: too many workgroups");
+    // a finer grain for the last tiles of every XCD's share (tail_map): only where a tile is swept by ONE workgroup and a launch
+    // has several rounds of tiles per slot to drain (S3_PLAN_TAIL="<tiles per XCD>x<runs>", 0 = off)
+    int tail = 0, tail_split = 1;
+    if (gy == 1 && n_chunks >= 8 && tiles_per_xcd >= 4 * 64) {
+        tail = 32, tail_split = 4;          // (MI355X, cylinder3D, interleaved in one process: off 3.768 ms, 64x4 3.749, 32x4 3.736, 128x4 3.789, 64x8 3.781)
+        if (const char *e = getenv("S3_PLAN_TAIL")) {
+            tail = atoi(e);
+            const char *x = strchr(e, 'x');
+            tail_split = x ? atoi(x + 1) : 4;
+        }
+        if (tail < 1 || tail_split < 2) tail = 0, tail_split = 1;
+        if (tail > tiles_per_xcd) tail = (int)tiles_per_xcd;
+        if (tail_split > n_chunks) tail_split = n_chunks;
+    }
+    const int64_t n_wg = tail > 0 ? 8 * (tiles_per_xcd + (int64_t)tail * (tail_split - 1)) : gx * gy;
+    S3_REQUIRE(n_wg < ((int64_t)1 << 31), "s3_interp_planned: too many workgroups");
     const size_t lds = (size_t)p->ucap * PL_SEG + (size_t)p->k * p->tc * (sizeof(double) + sizeof(uint16_t));
-    dim3 grid((unsigned)(gx * gy));
+    dim3 grid((unsigned)n_wg);
     // rows that do not start on 128-byte boundaries (a dense batch read where it lies): whole aligned lines per load, the
     // per-row phase undone on the way into LDS (S3_INPLACE_SHIFT=0: the kernel below with straddling segments, for A/B runs)
     if (shift_ok) {
         auto kern = interp_planned_shift_kernel<T>;
         S3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         // (S3_OUT_HOLD=0: every step writes its own 256 bytes, for A/B runs)
-        const char *he = getenv("S3_OUT_HOLD"), *pe = getenv("S3_PACE_TICKS");
+        const char *he = getenv("S3_OUT_HOLD");
         kern<<<grid, 256, lds, st>>>(p->perm, p->tile_cell_begin, p->tile_row_begin, rows, p->loc, p->wp, p->k, p->ucap,
                                      static_cast<const T *>(data), row_len, in_stride, out, p->n_tiles, tiles_per_xcd,
-                                     chunks_per_block, n_chunks, brick, gy, he ? atoi(he) : 1, pe ? atoi(pe) : 0);
+                                     chunks_per_block, n_chunks, brick, gy, tail, tail_split, he ? atoi(he) : 1);
         S3_LAUNCH_CHECK();
         return S3_OK;
     }
@@ -1503,13 +1515,13 @@ static int launch_planned(s3_interp_plan *p, const int32_t *rows, int64_t n_rows
         S3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         kern<<<grid, 512, lds, st>>>(p->perm, p->tile_cell_begin, p->tile_row_begin, rows, p->loc, p->wp, p->k, p->ucap,
                                      static_cast<const T *>(data), row_len, in_stride, out, p->n_tiles, tiles_per_xcd,
-                                     chunks_per_block, n_chunks, brick, gy);
+                                     chunks_per_block, n_chunks, brick, gy, tail, tail_split);
     } else {
         auto kern = interp_planned_kernel<T, 64>;
         S3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         kern<<<grid, 256, lds, st>>>(p->perm, p->tile_cell_begin, p->tile_row_begin, rows, p->loc, p->wp, p->k, p->ucap,
                                      static_cast<const T *>(data), row_len, in_stride, out, p->n_tiles, tiles_per_xcd,
-                                     chunks_per_block, n_chunks, brick, gy);
+                                     chunks_per_block, n_chunks, brick, gy, tail, tail_split);
     }
     S3_LAUNCH_CHECK();
     return S3_OK;

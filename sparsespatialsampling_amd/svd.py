@@ -10,7 +10,11 @@ How it runs on the MI355X (method of snapshots; the snapshot count T is small ag
 2. ``G = sum_n a_n (x_n - mean_n)(x_n - mean_n)^T`` [T, T] -- ``s3_weighted_gram`` on the f64 matrix cores
    (``v_mfma_f64_16x16x4_f64``, csrc/svd.hip); centring and weighting are fused into the operand staging, the data matrix
    is read as the interpolation kernel left it (f64, HBM resident);
-3. ``G = V diag(s^2) V^T`` -- symmetric eigenproblem of a T x T matrix: the vendor's dense solver (library call);
+3. ``G = V diag(s^2) V^T`` -- symmetric eigenproblem of a T x T matrix: the vendor's dense solver, the ONE library call of the path
+   (rocSOLVER through ``torch.linalg.eigh``; ``bench.py --workload svd`` reports it as ``"eigh": "library"`` with its share of a
+   ``compute_svd`` call.  A hand-written solver was priced and not built: one-sided Jacobi needs ~10 sweeps x (T - 1) rounds with a
+   chip-wide synchronisation each -- 10^4 x ~5 us at T = 1000, more than the 23 ms of the library's tridiagonal solver -- and the
+   blocked form leaves 16 workgroups busy);
 4. modes ``U = (X - mean) V diag(1/s)`` -- ``s3_centered_gemm`` on the same matrix cores, the centring fused into the operand
    staging; the weights cancel: ``(sqrt(a) (X - mean) V / s) / sqrt(a)``.
 
@@ -119,13 +123,20 @@ def _spectrum(x2: pt.Tensor, mean: pt.Tensor, w: pt.Tensor, wanted: int):
     gram = weighted_gram(x2, mean, w)
     s_parts, v_parts, found = [], [], 0
     for level in range(MAX_LEVELS):
+        if found:
+            # The residual's Gram matrix has the directions already found as a null space, and the solver is free to mix them with
+            # the small directions still wanted.  Instead of projecting the vectors afterwards (round 4: two T x T products and a QR
+            # on the host) the found directions are SHIFTED out of the way first: G + sigma B B^T gives them the eigenvalue sigma, twice
+            # the largest one of the residual -- an eigenvalue of its own, so the solver returns every other vector orthogonal to B
+            # to rounding, and orthonormal among themselves as always.  B B^T on the f64 matrix cores (s3_centered_gemm).
+            basis = pt.cat(v_parts, dim=1).to(x2.device)                          # [T, found]
+            # (Frobenius norm >= largest eigenvalue, and a tighter bound than the trace when the residual's spectrum is flat: the
+            # solver's absolute tolerance scales with sigma)
+            sigma = 2.0 * float((gram * gram).sum().sqrt())
+            gram = gram + sigma * centered_gemm(basis, None, basis.T.contiguous()) if sigma > 0 else gram
         lam, vec = _eigh(gram)                                    # ascending; T x T
         lam, vec = lam.flip(0).clamp_min(0.0), vec.flip(1)
-        lam, vec = lam[:t - found], vec[:, :t - found]            # (the directions already found come out as ~0: dropped)
-        if found:                                                 # keep the new vectors in the complement of the old ones
-            basis = pt.cat(v_parts, dim=1)
-            vec = vec - pt.matmul(basis, pt.matmul(basis.T, vec))     # (T x T host matrices)
-            vec, _ = pt.linalg.qr(vec)
+        lam, vec = lam[found:], vec[:, found:]                    # (the `found` directions come out first, at sigma: dropped)
         s_level = lam.sqrt()
         good = int((lam >= lam[0] * LEVEL_RANGE ** 2).sum()) if float(lam[0]) > 0 else 0
         meaningful = len(lam) - 1                                 # the centring's null direction never passes the test above

@@ -41,6 +41,13 @@ def test_bench_contract_small_workload():
     assert res["n_gpus"] == 1 and res["steps"] == 3 and res["warmup"] == 1 and res["higher_is_better"] is True
     assert res["scaling"] == "strong" and res["vs_baseline"] is None and res["data"] == "synthetic" and "workload" in res["config"]
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(res["roofline"])
+    # the traffic of the dominant kernel is MEASURED in the run (two rocprofv3 --pmc child passes before the GPU is touched), where a
+    # profiler is installed: its own source line says so, and it cannot be below what the launch must move at least once
+    import shutil
+    if shutil.which("rocprofv3"):
+        m = res["roofline"]["traffic_measured"]
+        assert m is not None and m["launches_averaged"] == [4, 4] and "measured in this run" in res["roofline"]["traffic_source"]
+        assert 0.9 < res["roofline"]["traffic_over_algorithmic"] < 3 and res["roofline"]["traffic_stale"] is False
     assert res["roofline"]["bound"] == "hbm" and 0 < res["roofline"]["frac"] < 1 and res["value"] > 0
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(res["cpu_baseline"]) and res["cpu_baseline"]["kind"] == "port"
     assert res["config"]["parallelism"] == "leaf-cell shards x1"

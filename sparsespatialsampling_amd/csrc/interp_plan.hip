@@ -592,13 +592,13 @@ __device__ __forceinline__ float4 select16(bool c, const float4 &a, const float4
 __device__ __forceinline__ double2 select16(bool c, const double2 &a, const double2 &b) {
     return make_double2(c ? a.x : b.x, c ? a.y : b.y);
 }
-template <typename T>
+template <typename T, int HOLD>      // HOLD: 0 every step writes its own 256 bytes (default); 1 whole-line output stores (below)
 __global__ void __launch_bounds__(256, 2)
 interp_planned_shift_kernel(const int32_t *__restrict__ perm, const int32_t *__restrict__ tile_cell_begin,
                             const int32_t *__restrict__ tile_row_begin, const int32_t *__restrict__ rows,
                             const uint16_t *__restrict__ loc, const double *__restrict__ w /*plan order*/, int k, int ucap,
                             const T *__restrict__ data, int64_t row_len, int64_t in_stride, double *__restrict__ out,
-                            int64_t n_tiles, int64_t tiles_per_xcd, int chunks_per_block, int n_chunks, int brick, int n_split, int tail, int tail_split, int hold) {
+                            int64_t n_tiles, int64_t tiles_per_xcd, int chunks_per_block, int n_chunks, int brick, int n_split, int tail, int tail_split) {
     using V = typename Vec16<T>::type;
     constexpr int TC = 64;
     constexpr int EPV = Vec16<T>::N;
@@ -705,8 +705,8 @@ interp_planned_shift_kernel(const int32_t *__restrict__ perm, const int32_t *__r
     // output's size).  Such a cell holds its last 64 bytes (blocks 6 and 7 of the chunk: the second vector of its lanes
     // 2 and 3) back for one step, so that every step writes the whole aligned lines [c * 256 - 64, c * 256 + 192) of the row.
     bool defer = false;
-    if constexpr (std::is_same<T, float>::value)
-        defer = has_cell && even_rows && v0 >= 2 && (reinterpret_cast<uintptr_t>(out + cell * row_len) & 127) == 64 && hold != 0;
+    if constexpr (std::is_same<T, float>::value && HOLD != 0)
+        defer = has_cell && even_rows && v0 >= 2 && (reinterpret_cast<uintptr_t>(out + cell * row_len) & 127) == 64;
     double held0 = 0.0, held1 = 0.0, held2 = 0.0, held3 = 0.0;      // (named: a loop-carried local array ends up in scratch memory)
 
     auto accumulate = [&](int chunk) {
@@ -731,7 +731,7 @@ interp_planned_shift_kernel(const int32_t *__restrict__ perm, const int32_t *__r
         }
         double *o = out + cell * row_len + col0;
         store_piece<EPV>(o + v0 * EPV, acc0, row_len - col0 - (int64_t)v0 * EPV, even_rows);
-        if (defer) {
+        if (EPV == 4 && HOLD == 1 && defer) {
             // (the chunk before this one is never the row's last: its piece is whole)
             if constexpr (EPV == 4) {
                 if (chunk > chunk0) {
@@ -1482,16 +1482,17 @@ static int launch_planned(s3_interp_plan *p, const int32_t *rows, int64_t n_rows
     // a finer grain for the last tiles of every XCD's share (tail_map): only where a tile is swept by ONE workgroup and a launch
     // has several rounds of tiles per slot to drain (S3_PLAN_TAIL="<tiles per XCD>x<runs>", 0 = off)
     int tail = 0, tail_split = 1;
-    if (gy == 1 && n_chunks >= 8 && tiles_per_xcd >= 4 * 64) {
+    const char *te = getenv("S3_PLAN_TAIL");
+    if (gy == 1 && (te || (n_chunks >= 8 && tiles_per_xcd >= 4 * 64))) {
         tail = 32, tail_split = 4;          // (MI355X, cylinder3D, interleaved in one process: off 3.768 ms, 64x4 3.749, 32x4 3.736, 128x4 3.789, 64x8 3.781)
-        if (const char *e = getenv("S3_PLAN_TAIL")) {
-            tail = atoi(e);
-            const char *x = strchr(e, 'x');
+        if (te) {
+            tail = atoi(te);
+            const char *x = strchr(te, 'x');
             tail_split = x ? atoi(x + 1) : 4;
         }
-        if (tail < 1 || tail_split < 2) tail = 0, tail_split = 1;
         if (tail > tiles_per_xcd) tail = (int)tiles_per_xcd;
         if (tail_split > n_chunks) tail_split = n_chunks;
+        if (tail < 1 || tail_split < 2) tail = 0, tail_split = 1;
     }
     const int64_t n_wg = tail > 0 ? 8 * (tiles_per_xcd + (int64_t)tail * (tail_split - 1)) : gx * gy;
     S3_REQUIRE(n_wg < ((int64_t)1 << 31), "s3_interp_planned: too many workgroups");
@@ -1500,13 +1501,24 @@ static int launch_planned(s3_interp_plan *p, const int32_t *rows, int64_t n_rows
     // rows that do not start on 128-byte boundaries (a dense batch read where it lies): whole aligned lines per load, the
     // per-row phase undone on the way into LDS (S3_INPLACE_SHIFT=0: the kernel below with straddling segments, for A/B runs)
     if (shift_ok) {
-        auto kern = interp_planned_shift_kernel<T>;
-        S3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        // (S3_OUT_HOLD=0: every step writes its own 256 bytes, for A/B runs)
+        // S3_OUT_HOLD=1: whole-line output stores (HOLD = 1 above).  They bring WRITE_SIZE down to the output's size (3.955 -> 3.690 GB
+        // per launch at 1000 snapshots, traffic 1.31 -> 1.29 x algorithmic) but cost the launch 0.2-0.9 % (3.564 against 3.531 ms,
+        // 3.488 / 3.456, 3.575 / 3.569 on three boxes, interleaved in one process): the counter tallies two partial write-backs of a
+        // line as more than the line, the DRAM bursts are the same, and the divergent store path is not free.  Off by default.
+        // (A form with ONE store sequence for all lanes behind selects: 3.588 ms -- worse than the branch.)
         const char *he = getenv("S3_OUT_HOLD");
-        kern<<<grid, 256, lds, st>>>(p->perm, p->tile_cell_begin, p->tile_row_begin, rows, p->loc, p->wp, p->k, p->ucap,
-                                     static_cast<const T *>(data), row_len, in_stride, out, p->n_tiles, tiles_per_xcd,
-                                     chunks_per_block, n_chunks, brick, gy, tail, tail_split, he ? atoi(he) : 1);
+        const int hold = he ? atoi(he) : 0;
+#define S3_LAUNCH_SHIFT(H)                                                                                                       \
+    do {                                                                                                                         \
+        auto kern = interp_planned_shift_kernel<T, H>;                                                                           \
+        S3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        kern<<<grid, 256, lds, st>>>(p->perm, p->tile_cell_begin, p->tile_row_begin, rows, p->loc, p->wp, p->k, p->ucap,        \
+                                     static_cast<const T *>(data), row_len, in_stride, out, p->n_tiles, tiles_per_xcd,           \
+                                     chunks_per_block, n_chunks, brick, gy, tail, tail_split);                                   \
+    } while (0)
+        if (hold == 0 || !std::is_same<T, float>::value) S3_LAUNCH_SHIFT(0);
+        else S3_LAUNCH_SHIFT(1);
+#undef S3_LAUNCH_SHIFT
         S3_LAUNCH_CHECK();
         return S3_OK;
     }

@@ -308,6 +308,16 @@ def test_shift_kernel_reads_rows_off_the_line_grid(ops, orc, row_len, dtype, lay
         assert pt.equal(plan.interp_src(table), direct)
     finally:
         del os.environ["S3_INPLACE_SHIFT"]
+    # the optional forms of the same launch: whole-line output stores (cells whose output row starts mid-line hold their last 64
+    # bytes back one step), no finer grain at the end of the launch, the tail cut differently -- the same bits every time
+    for env in ({"S3_OUT_HOLD": "1"}, {"S3_PLAN_MIN_BLOCKS": "1", "S3_PLAN_TAIL": "0"}, {"S3_PLAN_MIN_BLOCKS": "1", "S3_PLAN_TAIL": "7x3", "S3_OUT_HOLD": "1"},
+                {"S3_PLAN_MIN_BLOCKS": "1", "S3_PLAN_TAIL": "100x5"}, {"S3_PLAN_SPLIT": "3", "S3_PLAN_BRICK": "5"}):
+        os.environ.update(env)
+        try:
+            assert pt.equal(plan.interp_src(table), direct), env
+        finally:
+            for kk in env:
+                del os.environ[kk]
     ref = orc.interp(w.cpu().numpy(), idx.cpu().numpy(), table.contiguous().cpu().numpy().reshape(n, 1, row_len)).reshape(nc, row_len)
     assert np.abs(got.cpu().numpy() - ref).max() <= 1e-13 * np.abs(ref).max()
     # the plan over ALL rows (no source ids): s3_interp_planned on the same table

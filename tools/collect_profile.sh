@@ -13,11 +13,11 @@ root=$(pwd)
 out=$root/gpurun_out/prof_$tag/$name${S3_LEASE:+/lease$S3_LEASE}
 mkdir -p "$out"
 export TMPDIR=/tmp
-python bench.py --steps 20 --warmup 3 ${S3_BENCH_FAST:+--no-cpu-baseline --no-batches} "$@" > "$out/bench.json" 2> "$out/bench.err" || exit 1
+python bench.py --steps 20 --warmup 3 ${S3_BENCH_FAST:+--no-cpu-baseline --no-batches --no-traffic} "$@" > "$out/bench.json" 2> "$out/bench.err" || exit 1
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python "$root/bench.py" --steps 20 --warmup 3 --no-cpu-baseline --no-batches --no-pitched-copy "$@" > "$out/stats.log" 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python "$root/bench.py" --steps 20 --warmup 3 --no-cpu-baseline --no-batches --no-pitched-copy --no-traffic "$@" > "$out/stats.log" 2>&1 || exit 1
 for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$out/pmc_$c" -- python "$root/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-batches --no-pitched-copy "$@" > "$out/pmc_$c.log" 2>&1 || exit 1
+    rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$out/pmc_$c" -- python "$root/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-batches --no-pitched-copy --no-traffic "$@" > "$out/pmc_$c.log" 2>&1 || exit 1
 done
 cd "$root"
 # keep what travels back small: per-kernel stats + the counter rows of the interpolation kernels

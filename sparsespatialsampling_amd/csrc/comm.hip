@@ -4,9 +4,9 @@
 // The path shards without a data-path collective for the interpolation (leaf cells are split into contiguous ranges,
 // every rank interpolates its own range).  The level-synchronous refine has one real exchange per batch: every rank
 // evaluates the KNN metric / gain of its 1/W slice of the new cells (the reference does this with a process pool and
-// pickled tuples, s_cube.py:207-241), one grouped all-gather returns the slices to everybody; and one small all-gather
-// per captured-metric evaluation (s_cube.py:317-336) carries the per-block partial sums, which every rank then adds in
-// block order -- the result does not depend on the number of ranks.
+// pickled tuples, s_cube.py:207-241), one grouped all-gather returns the slices to everybody.  That is the only exchange of a
+// refinement step (r5): the captured metric (s_cube.py:317-336) is reduced from the then replicated arrays on every rank, per
+// fixed 1024-cell block and in block order -- the result does not depend on the number of ranks.
 //
 // RCCL is looked up at run time (dlopen of the soname torch has already loaded, so that both use the same copy);
 // libs3hip.so itself has no link-time dependency on it.

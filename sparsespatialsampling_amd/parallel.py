@@ -430,10 +430,28 @@ def init(backend=None):
         everybody = all(store.get(f"can_rccl_{r}") == b"1" for r in range(world_size))
         _comm, reason = None, why or "another rank cannot use RCCL"
         if everybody:
+            # ncclCommInitRank has no timeout and nothing inside a rank can see that ANOTHER rank never arrived: a timer ends this
+            # process loudly if the bootstrap is still running after S3_COMM_INIT_TIMEOUT_S (300; 0 = wait forever), so that a
+            # launcher (torch.distributed.run, bench.py's own parent) sees a failed rank instead of a silent hang and can end the rest
+            import threading
+            limit = float(os.environ.get("S3_COMM_INIT_TIMEOUT_S", "300"))
+
+            def _overdue():
+                import sys
+                print(f"[s3] rank {rank}: the RCCL communicator bootstrap (ncclCommInitRank, {world_size} ranks) did not finish within "
+                      f"{limit:.0f} s -- another rank is missing or wedged; ending this process (S3_COMM_INIT_TIMEOUT_S)", file=sys.stderr, flush=True)
+                os._exit(86)
+            timer = threading.Timer(limit, _overdue) if limit > 0 else None
+            if timer is not None:
+                timer.daemon = True
+                timer.start()
             try:
                 _comm, reason = RcclComm(rank, world_size, store), ""
             except Exception as err:     # id creation failed on rank 0 (every rank sees the marker), communicator refused
                 _comm, reason = None, str(err)
+            finally:
+                if timer is not None:
+                    timer.cancel()
         # every rank must end up with the same kind of communicator: agree through the store
         store.set(f"rccl_ok_{rank}", b"1" if _comm is not None else b"0")
         if all(store.get(f"rccl_ok_{r}") == b"1" for r in range(world_size)):

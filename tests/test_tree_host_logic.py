@@ -213,3 +213,29 @@ def test_base_class_kernel_spec_defaults_to_none():
     g = Slab("slab", False)
     assert g.kernel_spec() is None
     assert g.check_cell(pt.tensor([[0.1, 0.0], [0.2, 0.0], [0.3, 1.0], [0.4, 1.0]])) is True
+
+
+def test_bench_grid_sha_and_cpu_counts():
+    """helpers of bench.py that need no GPU: the grid digest depends on values, dtypes and shapes of all four arrays (what two
+    backends must agree on cell for cell), and the host-core report has the three counts north_star asks to be stated"""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root) if root not in sys.path else None
+    import numpy as np
+    import torch as pt
+    import bench
+    c = pt.arange(12, dtype=pt.float64).reshape(4, 3)
+    lv = pt.ones((4, 1), dtype=pt.int64)
+    f = pt.arange(32, dtype=pt.int32).reshape(4, 8)
+    nd = pt.arange(30, dtype=pt.float64).reshape(10, 3)
+    ref = bench.grid_sha(c, lv, f, nd)
+    assert ref == bench.grid_sha(c.clone(), lv.numpy(), f.clone(), nd.numpy()) and len(ref) == 64
+    assert ref != bench.grid_sha(c, lv, f.long(), nd)                          # dtype is part of the contract (faces int32 / int64)
+    bumped = c.clone()
+    bumped[3, 2] = np.nextafter(float(bumped[3, 2]), 1e9)
+    assert ref != bench.grid_sha(bumped, lv, f, nd)                            # one ulp in one centre
+    assert ref != bench.grid_sha(c, lv, f, nd.reshape(3, 10))
+    counts = bench.host_cpu_counts()
+    assert set(counts) == {"host_cpus", "affinity_cpus", "cgroup_cpus"} and counts["host_cpus"] >= counts["affinity_cpus"] >= 1
+    assert counts["cgroup_cpus"] is None or counts["cgroup_cpus"] > 0

@@ -52,7 +52,10 @@ def test_topology_engine_and_hdf5_sink_under_asan_ubsan(tmp_path):
                         f"-Wl,-rpath,{os.path.join(prefix, 'lib')}", "-lpthread"], check=True)
         env["S3_H5_SO"] = h5
         files.append("tests/test_export_host_logic.py")
-    run = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "not gpu", "-p", "no:cacheprovider"] + files, cwd=ROOT, env=env,
+    # (the three long random traces stay out: 13-15 s each natively, several times that under the sanitizer; the shorter traces and
+    # the refine-like ones walk the same code)
+    skip = [a for seed in (0, 9, 11) for a in ("--deselect", f"tests/test_pyset.py::test_random_traces_slot_for_slot[{seed}]")]
+    run = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "not gpu", "-p", "no:cacheprovider"] + skip + files, cwd=ROOT, env=env,
                          capture_output=True, text=True, timeout=1500)
     tail = run.stdout[-3000:] + run.stderr[-3000:]
     assert run.returncode == 0, tail

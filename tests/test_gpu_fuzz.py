@@ -186,3 +186,24 @@ def test_ranks_agree_on_a_gloo_group_when_rccl_refuses():
     r2 = json.loads(two.stdout.strip().splitlines()[-1])
     assert r2["n_gpus"] == 2 and r2["config"]["collectives"].startswith("gloo (RCCL")
     assert r2["config"]["n_cells"] == 12942 and sum(r2["config"]["cells_per_rank"]) == 12942
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("script,args,expect", [
+    ("s3_for_synthetic_cylinder2D.py", [], ["metric_0.75.h5", "metric_0.75.xdmf", "metric_0.75_p_svd.h5"]),
+    ("s3_for_synthetic_OAT15.py", ["250"], ["OAT15_synthetic_n_cells_25000.h5", "OAT15_synthetic_n_cells_25000.xdmf",
+                                            "OAT15_synthetic_n_cells_25000_p_svd.h5"]),
+])
+def test_example_scripts_run_end_to_end(tmp_path, script, args, expect):
+    """the example scripts -- the workflows of the reference's examples/s3_for_cylinder2D_Re100.py and s3_for_OAT15_airfoil.py on
+    synthetic data: metric, grid generation, export of scalar and vector fields in batches, SVD -- run as a user runs them and leave
+    their files (the OAT15 one with 250 instead of 2000 snapshots)"""
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "examples", script), str(tmp_path)] + args, cwd=ROOT, capture_output=True,
+                         text=True, timeout=900)
+    assert run.returncode == 0, (run.stdout + run.stderr)[-3000:]
+    for name in expect:
+        path = os.path.join(str(tmp_path), name)
+        assert os.path.exists(path) and os.path.getsize(path) > 1000, (name, os.listdir(str(tmp_path)))
+    from sparsespatialsampling_amd.data import Dataloader
+    loader = Dataloader(str(tmp_path), expect[0])
+    assert len(loader.write_times) == (250 if args else 400) and loader.vertices.shape[1] == 2

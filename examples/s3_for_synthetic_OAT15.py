@@ -20,7 +20,7 @@ import torch as pt
 sys.path.insert(0, dirname(dirname(abspath(__file__))))
 from sparsespatialsampling_amd.export import ExportData                                 # noqa: E402
 from sparsespatialsampling_amd.geometry import CubeGeometry, GeometryCoordinates2D      # noqa: E402
-from sparsespatialsampling_amd.metrics import temporal_std                              # noqa: E402
+from sparsespatialsampling_amd.metrics import RunningMoments                            # noqa: E402
 from sparsespatialsampling_amd.sparse_spatial_sampling import SparseSpatialSampling     # noqa: E402
 
 
@@ -62,7 +62,6 @@ if __name__ == "__main__":
     write_times = [str(round(1e-3 * i, 3)) for i in range(n_snapshots)]
 
     # metric = std_t(p) + std_t(|U|) (reference: pt.std(field, dim=1), line 91), one streaming pass per field on the GPU, in batches
-    from sparsespatialsampling_amd.metrics import RunningMoments
     mom_p, mom_u = RunningMoments(), RunningMoments()
     for t0 in range(0, n_snapshots, batch):
         p, u = synthetic_fields(xz, t0, min(n_snapshots, t0 + batch))

@@ -39,7 +39,6 @@ matrix: the coefficients ``A = (X - mean) V`` [N, found] are kept, and ``(X - me
 import ctypes as C
 from typing import Tuple
 
-import numpy as np
 import torch as pt
 
 from . import _lib, hipops, metrics

@@ -1276,6 +1276,12 @@ static int plan_schedule(s3_interp_plan *p, hipStream_t st) {
     // the balance it buys is worth less than the locality it loses.
     const char *mode = getenv("S3_STREAM_SCHEDULE");
     const bool round_robin = !(mode && mode[0] == 'c');
+    // (r5: balancing INSIDE a round -- the 64 tiles of a round, most expensive first, to the workgroups with the least work so far,
+    // so that the rounds stay together in time -- measured too: 0.1344 / 0.1318 / 0.464 / 0.476 / 0.934 ms at 25 / 32 / 100 / 128 / 256
+    // snapshots against 0.1317 / 0.1295 / 0.444 / 0.445 / 0.875 with plain round robin.  What round robin has is CORRELATION: workgroup
+    // s always works on the tile next to workgroup s + 1's, neighbouring tiles cost about the same, so the two stay in phase and
+    // share their halo through the L2; any reassignment breaks the pairs.)
+    auto cost_of = [&](size_t t) { return 128.0 * (rb[t + 1] - rb[t]) + (10.0 * p->k + 256.0) * (cb[t + 1] - cb[t]) + 4096.0; };
     for (int x = 0; x < 8; ++x) {
         const size_t lo = std::min(nt, x * per_xcd), hi = std::min(nt, lo + per_xcd);
         std::fill(busy.begin(), busy.end(), 0.0);
@@ -1287,7 +1293,7 @@ static int plan_schedule(s3_interp_plan *p, hipStream_t st) {
                 for (int s = 1; s < slots; ++s)
                     if (busy[s] < busy[best]) best = s;                 // (first of equals: the first `slots` tiles go out in order)
             }
-            busy[best] += 128.0 * (rb[t + 1] - rb[t]) + (10.0 * p->k + 256.0) * (cb[t + 1] - cb[t]) + 4096.0;
+            busy[best] += cost_of(t);
             lists[(size_t)best * 8 + x].push_back((int32_t)t);
         }
     }

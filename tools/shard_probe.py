@@ -16,7 +16,7 @@ k, nc_total = 26, len(centers)
 knn = hipops.KnnIndex(x, hipops.knn_occupancy(k, 3))
 # S3_PROBE_T_SPLIT=2: at 8 ranks the hybrid decomposition of bench.py (4 leaf-cell shards x 2 halves of the snapshot axis)
 t_split = int(os.environ.get("S3_PROBE_T_SPLIT", "1"))
-for world_total in (1, 2, 4, 8):
+for world_total in [int(v) for v in os.environ.get("S3_PROBE_WORLDS", "1,2,4,8").split(",")]:
     wt = t_split if world_total >= 8 else 1
     world, T = world_total // wt, 1000 // wt
     worst = 0.0

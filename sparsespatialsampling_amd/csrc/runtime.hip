@@ -415,7 +415,16 @@ int s3_abi_version(void) { return S3_ABI_VERSION; }
 // tear down (round 4 ended a suite run with a core dump in a joining destructor at static-destruction time and then detached
 // the threads for good; joining them while everything they could touch is still alive is the orderly form).  Harmless at any
 // other time: the next upload / download starts fresh lanes.
-int s3_shutdown(void) { return s3::g_pool.shutdown(); }
+int s3_shutdown(void) try {
+    // (never beside a transfer: the lanes' jobs run under this mutex.  A transfer still running two seconds into the process's
+    // exit is left alone -- its threads then simply end with the process, as they did before round 5)
+    std::unique_lock<std::mutex> guard(s3::g_upload_mutex, std::defer_lock);
+    for (int i = 0; i < 200 && !guard.try_lock(); ++i) std::this_thread::sleep_for(std::chrono::milliseconds(10));
+    if (!guard.owns_lock()) return 0;
+    return s3::g_pool.shutdown();
+} catch (...) {                                      // (nothing may cross the C boundary: a failing join must not end the process)
+    return -1;
+}
 
 int s3_device_count(int *h_count) {
     S3_REQUIRE(h_count != nullptr, "s3_device_count: null output");

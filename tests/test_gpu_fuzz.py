@@ -207,3 +207,31 @@ def test_example_scripts_run_end_to_end(tmp_path, script, args, expect):
     from sparsespatialsampling_amd.data import Dataloader
     loader = Dataloader(str(tmp_path), expect[0])
     assert len(loader.write_times) == (250 if args else 400) and loader.vertices.shape[1] == 2
+
+
+@pytest.mark.gpu
+def test_process_exits_cleanly_after_transfers():
+    """a process that has used the transfer lanes (staged upload of selected rows, staged download), a plan and the KNN index ends with
+    status 0: the lanes are joined by s3_shutdown() from the bindings' atexit hook, before the interpreter and the HIP runtime go
+    down (round 4 detached them after a core dump at exit; round 5 joins them in an orderly way).  Three fresh processes."""
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import numpy as np, torch as pt\n"
+        "from sparsespatialsampling_amd import hipops, _lib\n"
+        "rng = np.random.default_rng(0)\n"
+        "x, c = rng.random((60000, 3)), rng.random((4000, 3))\n"
+        "knn = hipops.KnnIndex(x)\n"
+        "idx, dist = knn.query(c, 26)\n"
+        "w = hipops.idw_weights(dist)\n"
+        "host = pt.from_numpy(rng.standard_normal((60000, 200)).astype(np.float32))\n"
+        "dev = hipops.to_device(host)\n"
+        "plan = hipops.InterpPlan(idx, 60000, c); plan.set_weights(w)\n"
+        "out = plan.interp(w, hipops.gather_rows(dev, pt.arange(60000, dtype=pt.int32, device='cuda'), hipops.padded_rows(60000, 200, pt.float32, 'cuda')))\n"
+        "back = hipops.to_host(out)\n"
+        "assert back.shape == (4000, 200)\n"
+        "print('lanes joined at exit:', _lib.hip_lib().s3_shutdown() >= 0, flush=True)\n"
+        "hipops.to_host(out)\n"                       # the pool is usable again after a shutdown; the atexit hook joins these lanes
+        "print('done', flush=True)\n") % ROOT
+    for _ in range(3):
+        run = subprocess.run([sys.executable, "-X", "faulthandler", "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=600)
+        assert run.returncode == 0 and "done" in run.stdout and "Fatal" not in run.stderr, (run.returncode, run.stdout[-500:], run.stderr[-3000:])

@@ -281,3 +281,26 @@ def test_self_launch_is_not_taken_under_a_launcher(monkeypatch):
     run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], cwd=ROOT, env=env, capture_output=True, text=True,
                          timeout=300)
     assert run.returncode == 2 and "starts its own ranks" in run.stderr and not run.stdout.strip()
+
+
+def test_rccl_bootstrap_timer_ends_a_rank_that_waits_for_ever():
+    """``ncclCommInitRank`` has no timeout: ``parallel.init`` arms a timer around the communicator's creation
+    (S3_COMM_INIT_TIMEOUT_S) that ends the process with status 86 and a message, so that a launcher sees a FAILED rank instead of a
+    silent hang.  Here the creation is replaced by a call that never returns (no GPU needed)."""
+    import subprocess
+    code = (
+        "import sys, time, types; sys.path.insert(0, %r)\n"
+        "from sparsespatialsampling_amd import parallel, hipops, _lib\n"
+        "hipops.device = lambda: 'cpu'\n"
+        "_lib.hip_lib = lambda: types.SimpleNamespace(s3_comm_available=lambda: 1)\n"
+        "class Never(parallel.SoloComm):\n"
+        "    def __init__(self, *a):\n"
+        "        time.sleep(3600)\n"
+        "parallel.RcclComm = Never\n"
+        "parallel.init()\n"
+        "print('returned')\n") % ROOT
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", S3_COMM_FORCE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               S3_COMM_INIT_TIMEOUT_S="2")
+    env.pop("S3_DIST_BACKEND", None)
+    run = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert run.returncode == 86 and "did not finish within 2 s" in run.stderr and "returned" not in run.stdout, (run.returncode, run.stderr[-1500:])

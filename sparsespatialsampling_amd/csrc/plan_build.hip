@@ -1,13 +1,13 @@
 // Device-side construction of an interpolation plan (the tables interp_planned_kernel consumes).  gfx950 only.
 //
 // The neighbour table never leaves HBM:
-//   1. validate the indices, bounding box of the cell centres, Hilbert key per cell, radix sort (hipCUB) -> processing
+//   1. validate the indices, bounding box of the cell centres, Hilbert key per cell, radix sort (scan_sort.h: hand-written) -> processing
 //      order `perm` (stable: equal keys keep the caller's order; without centres the caller's order is kept);
 //   2. the ordered cells are cut into blocks of 8 * `tc` consecutive cells, one wavefront per block packs its cells
 //      greedily into tiles (a tile is closed when it holds `tc` cells or the next cell would push it past `ucap` distinct
 //      source rows): lane m owns neighbour m of the current cell, the tile's distinct rows live in an LDS hash table
 //      (open addressing, compare-and-swap insertion), positions are handed out by ballot rank;
-//   3. exclusive scans (hipCUB) of the per-block tile / row counts, then a gather kernel writes the compact tables.
+//   3. exclusive scans (scan_sort.h) of the per-block tile / row counts, then a gather kernel writes the compact tables.
 #include "common.h"
 #include "plan_build.h"
 

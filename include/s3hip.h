@@ -51,6 +51,8 @@ int s3_abi_version(void);
 /* stop and join the library's own host threads (transfer lanes); returns their number.  Call once at process exit, before the
  * HIP runtime goes away (the Python bindings register it with atexit); safe at any time -- later calls start new lanes. */
 int s3_shutdown(void);
+/* debugging aid: install a SIGABRT handler that prints the native frames of the aborting thread to stderr, then aborts as usual */
+int s3_debug_abort_backtrace(void);
 int s3_device_count(int *h_count);
 int s3_set_device(int device);
 int s3_malloc(void **d_ptr, size_t bytes);

@@ -36,6 +36,7 @@ HIP_SIGNATURES = {
     "s3_last_error": (C.c_char_p, []),
     "s3_abi_version": (c_int, []),
     "s3_shutdown": (c_int, []),
+    "s3_debug_abort_backtrace": (c_int, []),
     "s3_device_count": (c_int, [C.POINTER(c_int)]),
     "s3_set_device": (c_int, [c_int]),
     "s3_malloc": (c_int, [C.POINTER(c_vp), C.c_size_t]),
@@ -201,6 +202,9 @@ def hip_lib():
         # reverse order of registration and torch (imported above) has registered its own already: this one runs before them.
         import atexit
         atexit.register(_shutdown)
+        if os.environ.get("S3_ABORT_BACKTRACE"):                 # (debugging aid: native frames of a thread that calls abort();
+                                                                 #  "1" -> stderr, an absolute path -> appended to that file)
+            lib.s3_debug_abort_backtrace()
     return _hip
 
 

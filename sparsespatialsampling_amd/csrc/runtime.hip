@@ -14,7 +14,10 @@
 #include <vector>
 
 #include "host_lanes.h"
+#include <execinfo.h>
+#include <fcntl.h>
 #include <pthread.h>
+#include <signal.h>
 #include <unistd.h>
 #include <sched.h>
 #include <cstdio>
@@ -348,9 +351,20 @@ int s3_download(void *h_dst, const void *d_src, size_t bytes, s3_stream stream) 
     if (bytes == 0) return S3_OK;
     S3_REQUIRE(h_dst && d_src, "s3_download: null array");
     hipStream_t st = as_stream(stream);
-    if (bytes < 4 * UP_CHUNK_BYTES) {                                    // small: not worth the threads
-        S3_HIP_CHECK(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, st));
-        S3_HIP_CHECK(hipStreamSynchronize(st));
+    if (bytes < 4 * UP_CHUNK_BYTES) {
+        // small: not worth the threads -- but through a page-locked buffer of the library all the same (r5): handed a pageable
+        // destination the runtime pins the caller's pages on the fly, and that path produced rare GPU memory faults ("write access
+        // to a read-only page" at a host heap address)
+        std::lock_guard<std::mutex> guard(g_upload_mutex);
+        S3_HIP_CHECK(upload_lane_init(g_lanes[0]));
+        UploadLane &l = g_lanes[0];
+        for (int b = 0; b < UP_BUFS; ++b) S3_HIP_CHECK(hipEventSynchronize(l.ev[b]));       // (an earlier upload may still read from them)
+        for (size_t off = 0; off < bytes; off += UP_CHUNK_BYTES) {
+            const size_t n = std::min(UP_CHUNK_BYTES, bytes - off);
+            S3_HIP_CHECK(hipMemcpyAsync(l.pinned[0], static_cast<const char *>(d_src) + off, n, hipMemcpyDeviceToHost, st));
+            S3_HIP_CHECK(hipStreamSynchronize(st));
+            std::memcpy(static_cast<char *>(h_dst) + off, l.pinned[0], n);
+        }
         return S3_OK;
     }
     std::lock_guard<std::mutex> guard(g_upload_mutex);
@@ -415,6 +429,35 @@ int s3_download(void *h_dst, const void *d_src, size_t bytes, s3_stream stream) 
 }
 
 const char *s3_last_error(void) { return s3::g_err; }
+
+// Debugging aid (S3_ABORT_BACKTRACE=1 through the bindings; off otherwise): a SIGABRT handler that writes the native frames of the
+// ABORTING thread to stderr (glibc backtrace_symbols_fd: async-signal-safe enough for a process that is ending anyway) and then
+// lets the default action run.  Python's faulthandler shows the interpreter's frames only; an abort() inside a runtime library says
+// nothing about itself.
+static struct sigaction s3_previous_abort_action;
+static int s3_abort_backtrace_fd = 2;                  // (a test runner may have redirected descriptor 2: S3_ABORT_BACKTRACE=<file>)
+static void s3_abort_backtrace_handler(int sig) {
+    void *frames[64];
+    const int n = backtrace(frames, 64);
+    static const char head[] = "\n[s3] SIGABRT: native frames of the aborting thread:\n";
+    if (write(s3_abort_backtrace_fd, head, sizeof(head) - 1) < 0) {}
+    backtrace_symbols_fd(frames, n, s3_abort_backtrace_fd);
+    (void)sigaction(sig, &s3_previous_abort_action, nullptr);      // whoever was there before (Python's faulthandler) goes next
+    raise(sig);
+}
+int s3_debug_abort_backtrace(void) {
+    if (const char *e = getenv("S3_ABORT_BACKTRACE"))
+        if (e[0] == '/') {
+            const int fd = open(e, O_WRONLY | O_CREAT | O_APPEND, 0644);
+            if (fd >= 0) s3_abort_backtrace_fd = fd;
+        }
+    struct sigaction sa;
+    std::memset(&sa, 0, sizeof(sa));
+    sa.sa_handler = s3_abort_backtrace_handler;
+    sigemptyset(&sa.sa_mask);
+    sa.sa_flags = SA_NODEFER;
+    return sigaction(SIGABRT, &sa, &s3_previous_abort_action) == 0 ? S3_OK : S3_EINVAL;
+}
 
 int s3_abi_version(void) { return S3_ABI_VERSION; }
 

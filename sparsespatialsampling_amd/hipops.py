@@ -71,18 +71,20 @@ def to_device(x, dtype=None):
         if rc == 0:
             return out                                          # (x was copied into the staging buffer: it may be reused)
         return x.to(dev, non_blocking=False).contiguous()       # no page-locked staging memory on this host
-    if nbytes < (32 << 20):
-        return x.to(dev, non_blocking=False).contiguous()
+    # (r5: every size goes through the library's own page-locked staging buffers -- no pageable pointer is handed to the HIP
+    # runtime, which would pin the caller's pages on the fly; round 5 saw rare GPU memory faults, "write access to a read-only page"
+    # at a host heap address, in copies the runtime had pinned that way: DESIGN 9)
     out = pt.empty(x.shape, dtype=x.dtype, device=dev)
     flat_h, flat_d = x.reshape(-1), out.reshape(-1)
     row = (1 << 20) // x.element_size()                     # 1-MiB rows, pitch = row length
     n_full = flat_h.numel() // row
     try:
         upload_rows(flat_h[:n_full * row].view(n_full, row), flat_d[:n_full * row].view(n_full, row))
+        tail = flat_h.numel() - n_full * row
+        if tail:
+            upload_rows(flat_h[n_full * row:].view(1, tail), flat_d[n_full * row:].view(1, tail))
     except _lib.S3HipError:                                 # no page-locked staging memory on this host: plain copy
-        n_full = 0
-    if n_full * row < flat_h.numel():
-        flat_d[n_full * row:].copy_(flat_h[n_full * row:])
+        flat_d.copy_(flat_h)
     synchronize()                                           # the caller may release or overwrite x
     return out
 

@@ -52,7 +52,6 @@ struct UploadLane {
                                                      // upload must not wait for the previous small upload's copy)
 };
 std::mutex g_upload_mutex;
-std::mutex g_submit_mutex;                          // the lanes' submissions to the caller's stream, one at a time (upload_rows_impl)
 UploadLane g_lanes[UP_THREADS_MAX];
 
 // host threads that pack rows into the pinned lanes (S3_UPLOAD_THREADS overrides; at most UP_THREADS_MAX).  EIGHT: more of
@@ -285,13 +284,6 @@ static int upload_rows_impl(const void *h_src, const int32_t *h_rows, int64_t n_
                         }
                     }
                 }
-                // The lanes pack in parallel but hand their chunks to the runtime ONE AT A TIME: all of them submit to the caller's
-                // one stream, the runtime serialises those calls on the stream's lock anyway, and in round 5 a test process ended with a
-                // silent SIGABRT while its main thread sat in a multi-lane upload (faulthandler's dump; no message from libstdc++,
-                // glibc or the HSA runtime; a second abort of the round and one of round 4 left no stack) -- one run in twenty, not
-                // reproducible on demand.  Concurrent entry into the runtime for ONE stream is what a multi-lane upload has and a
-                // single-lane one has not.
-                std::lock_guard<std::mutex> submit(g_submit_mutex);
                 if (row_bytes == dst_pitch_bytes)
                     e = hipMemcpyAsync(dst, stage, (size_t)(rows * row_bytes), hipMemcpyHostToDevice, st);
                 else if (pitched)

@@ -126,10 +126,14 @@ def cpu_baseline(w, idx, data, k, used, seconds=10.0, n_sweep=100_000):
     from oracle import s3_oracle as orc
     t = int(data.shape[1])
 
+    from sparsespatialsampling_amd import hipops
+
     def slice_of(nc):
-        i_s, w_s = idx[:nc].cpu().numpy(), w[:nc].cpu().numpy()
+        # (downloads through the library's staged path: its own page-locked buffers, several host threads -- the 9.7 GB of the
+        # referenced rows come down at the link's rate instead of a pageable copy's 7 GiB/s)
+        i_s, w_s = hipops.to_host(idx[:nc]), hipops.to_host(w[:nc])
         rows, inv = np.unique(i_s, return_inverse=True)
-        sub = data[used.long()[pt.from_numpy(rows).to(data.device).long()]].contiguous().cpu().numpy().reshape(len(rows), 1, t)   # (`idx` holds positions in `used`)
+        sub = hipops.to_host(data[used.long()[hipops.to_device(rows.astype(np.int64))]]).reshape(len(rows), 1, t)   # (`idx` holds positions in `used`)
         return w_s, inv.reshape(i_s.shape), sub, len(rows)
 
     nc_all = min(int(w.shape[0]), int(os.environ.get("S3_BENCH_CPU_CELLS", str(1 << 62))))

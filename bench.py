@@ -53,6 +53,10 @@ import torch as pt
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# (robustness, no timed leg depends on it: torch's own copies to / from PAGEABLE host tensors of a MiB and more are served from the
+# runtime's staging buffers instead of pinning the caller's pages on the fly -- that path produced rare GPU memory faults in round 5,
+# DESIGN 9.  The library itself stages through its own page-locked buffers.  Must be set before anything initialises HIP.)
+os.environ.setdefault("GPU_PINNED_MIN_XFER_SIZE", "4096")
 
 WORKLOADS = {
     # the configuration BASELINE.json's metric is quoted on

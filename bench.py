@@ -47,16 +47,17 @@ import sys
 import time
 import types
 
-import numpy as np
-import torch as pt
+# (robustness, no timed leg depends on it: torch's own copies to / from PAGEABLE host tensors of a MiB and more are served from the
+# runtime's staging buffers instead of pinning the caller's pages on the fly -- that path produced rare GPU memory faults in round 5,
+# DESIGN 9.  The library itself stages through its own page-locked buffers.  Set before the HIP runtime is even loaded.)
+os.environ.setdefault("GPU_PINNED_MIN_XFER_SIZE", "4096")
+
+import numpy as np  # noqa: E402
+import torch as pt  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-# (robustness, no timed leg depends on it: torch's own copies to / from PAGEABLE host tensors of a MiB and more are served from the
-# runtime's staging buffers instead of pinning the caller's pages on the fly -- that path produced rare GPU memory faults in round 5,
-# DESIGN 9.  The library itself stages through its own page-locked buffers.  Must be set before anything initialises HIP.)
-os.environ.setdefault("GPU_PINNED_MIN_XFER_SIZE", "4096")
 
 WORKLOADS = {
     # the configuration BASELINE.json's metric is quoted on

@@ -16,6 +16,9 @@ Fixture groups:
     uniform_*     _refine_uniform() neighbour + node tables       (s_cube.py:508-561, 904-1536)
     refine_*      full SamplingTree.refine() outputs + traces     (s_cube.py:563-667)
     refine_random_<seed>   final grids of randomly drawn configurations (inputs.random_refine_case)
+    export_*      the REAL ExportData.export / Datawriter / XDMFWriter (export.py:128-319, data.py:303-777) driven through
+                  inputs.run_export_case; h5py = h5py_standin.py (ctypes on the HDF5 C library).  Stored: the inventory of
+                  every file written (path -> array, hence shape and dtype) and the XDMF text
 
 The script must stay a real file with a ``__main__`` guard: the reference creates a *spawn* multiprocessing pool
 (s_cube.py:159) whose workers re-import this module and need the shims installed before unpickling.
@@ -31,8 +34,8 @@ import ref_stubs  # noqa: E402,F401  (installs shims + sys.path; must run in spa
 import numpy as np  # noqa: E402
 import torch as pt  # noqa: E402
 
-from inputs import (POLYTOPES, REFINE_CASES, build_geometries, c1_cylinder2d, cloud, mask_cells, polytope,  # noqa: E402
-                    polytope_cells, random_refine_case, refine_inputs, sha, wake_metric)
+from inputs import (EXPORT_CASES, POLYTOPES, REFINE_CASES, build_geometries, c1_cylinder2d, cloud, mask_cells, polytope,  # noqa: E402
+                    polytope_cells, random_refine_case, refine_inputs, run_export_case, sha, wake_metric)
 
 
 def save(name, **kw):
@@ -295,8 +298,57 @@ def gen_c2():
     print("C2:", len(x), "points ->", len(c), "cells, levels", np.bincount(lv.reshape(-1)))
 
 
+def h5_inventory(path):
+    """[(dataset path, array)] of a whole HDF5 file in h5py's iteration order (name order), read with the stand-in"""
+    import h5py
+    out = []
+
+    def walk(group, prefix):
+        for k in group.keys():
+            node = group[k]
+            if hasattr(node, "keys"):
+                walk(node, f"{prefix}{k}/")
+            else:
+                out.append((f"{prefix}{k}", np.asarray(node[()])))
+    with h5py.File(path, "r") as f:
+        walk(f, "")
+    return out
+
+
+def gen_export():
+    """the reference's export state machine, writer and XDMF writer on small grids the reference generated itself"""
+    import json
+    import shutil
+    import tempfile
+    import sparseSpatialSampling.geometry as ref_geometry
+    from sparseSpatialSampling.export import ExportData
+    from sparseSpatialSampling.sparse_spatial_sampling import SparseSpatialSampling
+    for tag, case in EXPORT_CASES.items():
+        x, y, geos, kw = refine_inputs(case["refine"], ref_geometry)
+        kw = {{"uniform_level": "uniform_levels", "n_cells": "n_cells_max"}.get(k, k): v for k, v in kw.items()}
+        tmp = tempfile.mkdtemp(prefix="s3_export_golden_")
+        try:
+            s3 = SparseSpatialSampling(pt.from_numpy(x), pt.from_numpy(y), geos, tmp, "case", n_jobs=2, **kw)
+            s3.execute_grid_generation()
+            info = run_export_case(tag, s3, ExportData, pt.from_numpy, x, y)
+            arrays, manifest, xdmf = {}, [], {}
+            for fn in sorted(os.listdir(tmp)):
+                if fn.endswith(".h5"):
+                    for path, a in h5_inventory(os.path.join(tmp, fn)):
+                        arrays[f"a{len(manifest)}"] = a
+                        manifest.append([fn, path, str(a.dtype), list(a.shape)])
+                elif fn.endswith(".xdmf"):
+                    xdmf[fn] = open(os.path.join(tmp, fn)).read()
+            save(tag, input_sha=np.array(sha(x, y)), manifest=np.array(json.dumps(manifest)), xdmf=np.array(json.dumps(xdmf)),
+                 error_second_file=np.array(info["error_second_file"]), **arrays)
+            print(f"{tag}: {len(manifest)} datasets in {sorted({m[0] for m in manifest})}, xdmf {sorted(xdmf)}, "
+                  f"second-file error {info['error_second_file']!r}")
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+
+
 if __name__ == "__main__":
-    groups = sys.argv[1:] or ["interp", "knncache", "predict", "masks", "masks_polytopes", "uniform", "refine", "refine_random", "c1"]
+    groups = sys.argv[1:] or ["interp", "knncache", "predict", "masks", "masks_polytopes", "uniform", "refine", "refine_random", "c1", "export"]
     pt.manual_seed(0)
     for g in groups:
         if g.startswith("refine_") and g != "refine_random":

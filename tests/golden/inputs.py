@@ -318,3 +318,75 @@ def c2_oat15(geometry, metric):
     geos = [geometry.CubeGeometry("domain", True, [-0.2, -0.5], [1.2, 0.5]),
             geometry.GeometryCoordinates2D("airfoil", False, poly, refine=True)]
     return x, np.asarray(metric, dtype=np.float64), geos, dict(uniform_level=5, n_cells=25000)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# export cases (fixture group ``export_*``): the same script of ExportData calls is run on the REAL reference (generator,
+# h5py through h5py_standin.py) and on the product (tests).  Pure orchestration of the public API -- no reference code.
+# ----------------------------------------------------------------------------------------------------------------------
+EXPORT_CASES = {
+    # scalar field in batches 7 + 7 + 3 with n_snapshots_total, then a 2-component field at once; one file
+    "export_2d_batches": dict(refine="refine_2d_metric", n_t=17, times="str", script="batches"),
+    # 3-D, interpolation at the cell vertices too, write times given as floats (dataset names = str(float))
+    "export_3d_vertices": dict(refine="refine_3d_delta", n_t=5, times="float", script="vertices"),
+    # one file per field
+    "export_2d_newfile": dict(refine="refine_2d_metric", n_t=6, times="str", script="newfile"),
+    # a second ExportData appends fields to the file of the first (append_existing=True); one field handed over as [N, T]
+    "export_2d_append": dict(refine="refine_2d_triangle", n_t=6, times="int", script="append"),
+}
+
+
+def export_fields(x, n_t, seed):
+    """p [N, 1, T], u [N, d, T] float32: smooth in space and time plus noise"""
+    rng = np.random.default_rng(seed)
+    t = np.arange(n_t, dtype=np.float64)
+    phase = 2.0 * np.pi * (x[:, :1] / 0.4 - t[None, :] / 7.0)
+    p = np.sin(phase) * np.exp(-x[:, 1:2]) + 1e-2 * rng.standard_normal((len(x), n_t))
+    u = np.stack([np.cos(phase + 0.3 * j) * (1.0 + x[:, j:j + 1]) for j in range(x.shape[1])], 1)
+    u = u + 1e-2 * rng.standard_normal(u.shape)
+    return p[:, None, :].astype(np.float32), u.astype(np.float32)
+
+
+def export_times(kind, n_t):
+    if kind == "str":
+        return [f"{0.05 * i:.2f}" for i in range(n_t)]
+    if kind == "float":
+        return [0.1 * i for i in range(n_t)]             # 0.30000000000000004: the names are str(t), whatever that is
+    return list(range(n_t))
+
+
+def run_export_case(name, s_cube, export_cls, to_tensor, x, y):
+    """drive ``export_cls`` (the reference's or the product's ExportData) through the calls of case ``name``.  ``s_cube`` is
+    the finished SparseSpatialSampling-like object of the same implementation, ``to_tensor`` turns a numpy array into the
+    tensor type the implementation takes.  Returns {"error_second_file": exception class name or ""}."""
+    case = EXPORT_CASES[name]
+    n_t, times = case["n_t"], export_times(case["times"], case["n_t"])
+    p, u = export_fields(x, n_t, seed=sum(map(ord, name)))
+    xt = to_tensor(x)
+    info = {"error_second_file": ""}
+    if case["script"] == "batches":
+        ex = export_cls(s_cube, write_times=times)
+        for a, b in ((0, 7), (7, 14), (14, 17)):
+            ex.export(xt, to_tensor(p[:, :, a:b]), "p", n_snapshots_total=n_t)
+        ex.export(xt, to_tensor(u), "U")
+    elif case["script"] == "vertices":
+        ex = export_cls(s_cube, interpolate_at_vertices=True, write_times=times)
+        for a, b in ((0, 3), (3, 5)):
+            ex.export(xt, to_tensor(p[:, :, a:b]), "p", n_snapshots_total=n_t)
+        ex.export(xt, to_tensor(u), "U", n_snapshots_total=n_t)
+    elif case["script"] == "newfile":
+        ex = export_cls(s_cube, write_new_file_for_each_field=True, write_times=times)
+        for a, b in ((0, 4), (4, 6)):
+            ex.export(xt, to_tensor(p[:, :, a:b]), "p", n_snapshots_total=n_t)
+        try:
+            ex.export(xt, to_tensor(u), "U")
+        except Exception as err:                           # the reference cannot write a second file (see the fixture)
+            info["error_second_file"] = type(err).__name__
+    elif case["script"] == "append":
+        ex = export_cls(s_cube, write_times=times)
+        ex.export(xt, to_tensor(p), "p")
+        ex2 = export_cls(s_cube, write_times=times, append_existing=True)
+        for a, b in ((0, 2), (2, 6)):
+            ex2.export(xt, to_tensor(u[:, :, a:b]), "U", n_snapshots_total=n_t)
+        ex2.export(xt, to_tensor(np.ascontiguousarray(p[:, 0, :] * 2.0)), "q")          # scalar as [N, T]
+    return info

@@ -1,0 +1,48 @@
+"""
+The reference's own loader / XDMF writer as the judge of files THIS build wrote (development container only: the
+reference never travels to the GPU box).  Run as a script in its own process, so that the import shims of
+``ref_stubs.py`` (numba, flowtorch, shapely, h5py -> h5py_standin.py) and the name ``sparseSpatialSampling`` = the
+reference never leak into the test process:
+
+    python ref_judge.py load <dir> <file.h5> <out.npz>        # reference Dataloader (data.py:22-300) -> everything it exposes
+    python ref_judge.py xdmf <dir> <file.h5> <mixed 0|1>      # reference XDMFWriter (data.py:504-777) writes <file>.xdmf
+
+Contains no reference code: it calls the reference's public classes.
+"""
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_stubs  # noqa: E402,F401
+
+import numpy as np  # noqa: E402
+import torch as pt  # noqa: E402
+
+
+def load(directory, file_name, out):
+    from sparseSpatialSampling.data import Dataloader
+    ld = Dataloader(directory, file_name, dtype=pt.float64)
+    res = {"vertices": ld.vertices.numpy(), "nodes": ld.nodes.numpy(), "faces": ld.faces.numpy(), "levels": ld.levels.numpy(),
+           "metric": ld.metric.numpy(), "weights": ld.weights.numpy(),
+           "write_times": np.array(json.dumps(ld.write_times)), "field_names": np.array(json.dumps(ld.field_names))}
+    fields = sorted({f for v in ld.field_names.values() for f in v})
+    for f in fields:
+        times = [t for t in ld.write_times if f in ld.field_names[t]]
+        res[f"snap_{f}"] = ld.load_snapshot(f, times).numpy()
+        res[f"times_{f}"] = np.array(json.dumps(times))
+    if len(fields) > 1:
+        both = [t for t in ld.write_times if all(f in ld.field_names[t] for f in fields[:2])]
+        pair = ld.load_snapshot(fields[:2], both)
+        res["pair_shapes"] = np.array(json.dumps([list(p.shape) for p in pair]))
+    np.savez(out, **res)
+
+
+def xdmf(directory, file_name, mixed):
+    from sparseSpatialSampling.data import XDMFWriter
+    XDMFWriter(directory, file_name, mixed=bool(int(mixed))).write_xdmf()
+
+
+if __name__ == "__main__":
+    {"load": load, "xdmf": xdmf}[sys.argv[1]](*sys.argv[2:])

@@ -10,7 +10,10 @@ packages the reference imports at module level:
                     unit tests pin (inclusive bounds; tests/test_cube_geometry.py:46-78,
                     tests/test_sphere_geometry.py:43-75), dummy ``FOAMDataloader`` and ``SVD``
 * ``shapely``    -> minimal ``Point`` / ``Polygon`` (strict-interior ``within``; bounds; boundary.is_closed)
-* ``pyvista``, ``pymeshfix``, ``h5py`` -> import-only dummies (never exercised by the golden generator)
+* ``pyvista``, ``pymeshfix`` -> import-only dummies (never exercised by the golden generator)
+* ``h5py``       -> ``h5py_standin.py`` (next to this file): ctypes on the HDF5 C library, independent of the product's
+                    ``libs3h5.so``; lets the reference's real ``ExportData.export`` / ``Datawriter`` / ``XDMFWriter`` /
+                    ``Dataloader`` run here.  Validated by the reference's own tests/test_s_cube_dataloader.py passing.
 
 It is used ONLY by ``tests/golden/gen_golden.py`` (fixture generation in the dev container).  Nothing in the
 product, the GPU tests, ``smoke()`` or ``bench.py`` imports it, and /root/reference never travels to the GPU box.
@@ -125,9 +128,12 @@ def install():
     try:
         import h5py  # noqa: F401
     except ModuleNotFoundError:
-        h5 = types.ModuleType("h5py")
-        h5.File = type("File", (), {})
+        import importlib.util as _ilu
+        import os as _os
+        spec = _ilu.spec_from_file_location("h5py", _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "h5py_standin.py"))
+        h5 = _ilu.module_from_spec(spec)
         sys.modules["h5py"] = h5
+        spec.loader.exec_module(h5)
 
     if REFERENCE_ROOT not in sys.path:
         sys.path.insert(0, REFERENCE_ROOT)

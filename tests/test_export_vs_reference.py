@@ -1,0 +1,236 @@
+"""
+The export state machine, the HDF5 writer and the XDMF writer judged by the REFERENCE'S OWN CODE.
+
+``tests/golden/export_*.npz`` were produced by the real ``ExportData.export`` (export.py:128-319) with the real ``Datawriter``
+/ ``XDMFWriter`` (data.py:303-777) on grids the reference generated itself, h5py being ``tests/golden/h5py_standin.py`` (ctypes
+on the HDF5 C library; what that pins is the reference's naming / shape / dtype / ordering / batching logic, not h5py).  Each
+fixture holds the inventory of every file written (dataset path -> array) and the XDMF text.  Here the SAME script of calls
+(``inputs.run_export_case``) runs on this package's ``ExportData`` and must yield
+
+  * the same datasets in the same (name) order, with the same shapes and dtypes,
+  * grid datasets bit-identical, interpolated values within 1e-12 (relative to the field's largest value),
+  * byte-identical XDMF text.
+
+The one documented deviation: with ``write_new_file_for_each_field=True`` the reference cannot write a second file (it hands
+``None`` to ``create_dataset`` for ``constant/levels`` -> ``TypeError``, export.py:257-265) -- this build writes it, complete.
+
+CPU tests run the host logic on oracle-backed stand-ins for the device entry points (as tests/test_export_host_logic.py does);
+the ``-m gpu`` tests run grid generation + export on the HIP path.  Files are read back with the independent stand-in binding,
+not with the package's own HDF5 layer.  Where the reference is present (development container), its ``Dataloader`` and
+``XDMFWriter`` additionally read / describe files THIS build wrote (``tests/golden/ref_judge.py``, own process).
+"""
+import json
+import os
+import subprocess
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch as pt
+
+import h5py_standin as h5ref                                                   # tests/golden (conftest puts it on sys.path)
+from inputs import EXPORT_CASES, export_fields, export_times, refine_inputs, run_export_case, sha
+from sparsespatialsampling_amd import h5io
+from tests.test_export_host_logic import _cpu_ops
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+HAVE_REFERENCE = os.path.isdir("/root/reference/sparseSpatialSampling")
+pytestmark = pytest.mark.skipif(h5io.native_lib() is None, reason="libs3h5.so not available")
+
+
+def fixture(tag):
+    z = np.load(os.path.join(GOLDEN, tag + ".npz"))
+    manifest = json.loads(str(z["manifest"]))
+    files = {}
+    for i, (fn, path, dtype, shape) in enumerate(manifest):
+        files.setdefault(fn, []).append((path, z[f"a{i}"]))
+    return files, json.loads(str(z["xdmf"])), str(z["error_second_file"]), str(z["input_sha"])
+
+
+def inventory(path):
+    """[(dataset path, array)] in name order, read with the independent binding"""
+    out = []
+
+    def walk(group, prefix):
+        for k in group.keys():
+            node = group[k]
+            if hasattr(node, "keys"):
+                walk(node, f"{prefix}{k}/")
+            else:
+                out.append((f"{prefix}{k}", np.asarray(node[()])))
+    with h5ref.File(path, "r") as f:
+        walk(f, "")
+    return out
+
+
+def compare_file(got, want, label):
+    assert [p for p, _ in got] == [p for p, _ in want], f"{label}: dataset names / order differ"
+    for (path, a), (_, b) in zip(got, want):
+        assert a.dtype == b.dtype and a.shape == b.shape, f"{label}:{path}: {a.dtype}{a.shape} vs reference {b.dtype}{b.shape}"
+        if path.startswith("grid/") or path in ("constant/levels", "constant/size_initial_cell"):
+            assert np.array_equal(a, b), f"{label}:{path} differs"
+        else:
+            scale = np.abs(b).max() or 1.0
+            assert np.abs(a - b).max() <= 1e-12 * scale, f"{label}:{path}: {np.abs(a - b).max() / scale:.3e}"
+
+
+def check_case(tag, directory, info):
+    files, xdmf, ref_error, _ = fixture(tag)
+    if EXPORT_CASES[tag]["script"] == "newfile":
+        # the documented deviation: the reference stops with a TypeError after the grid of the second file; this build goes on
+        assert ref_error == "TypeError" and info["error_second_file"] == ""
+        second = dict(inventory(os.path.join(directory, "case_U.h5")))
+        for path, b in files.pop("case_U.h5"):                           # what the reference managed to write is the same
+            assert np.array_equal(second[path], b), path
+        complete = dict(inventory(os.path.join(directory, "case_p.h5")))
+        assert sorted(k for k in second if not k.startswith("data/")) == sorted(k for k in complete if not k.startswith("data/"))
+        for k in ("constant/levels", "constant/metric", "constant/size_initial_cell"):
+            assert np.array_equal(second[k], complete[k]), k
+        assert sum(k.endswith("/U_center") for k in second) == EXPORT_CASES[tag]["n_t"]
+    else:
+        assert ref_error == "" and info["error_second_file"] == ""
+    for fn, want in files.items():
+        compare_file(inventory(os.path.join(directory, fn)), want, f"{tag}/{fn}")
+    for fn, text in xdmf.items():
+        got = open(os.path.join(directory, fn)).read()
+        assert got == text, f"{tag}/{fn}: XDMF text differs from the reference's"
+
+
+def scube_from_fixture(tag, directory, y):
+    """the finished grid of the reference (from the fixture) as the object ExportData takes"""
+    files, _, _, _ = fixture(tag)
+    first = dict(files[sorted(files)[-1] if EXPORT_CASES[tag]["script"] == "newfile" else sorted(files)[0]])
+    return types.SimpleNamespace(n_dimensions=first["grid/centers"].shape[1], faces=pt.from_numpy(first["grid/faces"]),
+                                 centers=pt.from_numpy(first["grid/centers"]), vertices=pt.from_numpy(first["grid/vertices"]),
+                                 levels=pt.from_numpy(first["constant/levels"]), metric=pt.from_numpy(y),
+                                 size_initial_cell=float(first["constant/size_initial_cell"]), save_path=str(directory),
+                                 save_name="case", grid_name="grid_s_cube")
+
+
+@pytest.fixture
+def export_mod(monkeypatch):
+    import sparsespatialsampling_amd.export as export
+    monkeypatch.setattr(export, "hipops", _cpu_ops())
+    yield export
+
+
+@pytest.mark.parametrize("tag", sorted(EXPORT_CASES))
+def test_export_matches_reference_files_host_logic(export_mod, tmp_path, tag):
+    from sparsespatialsampling_amd import geometry
+    x, y, _, _ = refine_inputs(EXPORT_CASES[tag]["refine"], geometry)
+    assert sha(x, y) == fixture(tag)[3]
+    s = scube_from_fixture(tag, tmp_path, y)
+    info = run_export_case(tag, s, export_mod.ExportData, pt.from_numpy, x, y)
+    check_case(tag, str(tmp_path), info)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", sorted(EXPORT_CASES))
+def test_export_matches_reference_files_gpu(tmp_path, tag):
+    """grid generation AND export on the HIP path: SparseSpatialSampling -> ExportData -> files == the reference's"""
+    from sparsespatialsampling_amd import geometry
+    from sparsespatialsampling_amd.export import ExportData
+    from sparsespatialsampling_amd.sparse_spatial_sampling import SparseSpatialSampling
+    x, y, geos, kw = refine_inputs(EXPORT_CASES[tag]["refine"], geometry)
+    kw = {{"uniform_level": "uniform_levels", "n_cells": "n_cells_max"}.get(k, k): v for k, v in kw.items()}
+    s3 = SparseSpatialSampling(pt.from_numpy(x), pt.from_numpy(y), geos, str(tmp_path), "case", **kw)
+    s3.execute_grid_generation()
+    info = run_export_case(tag, s3, ExportData, pt.from_numpy, x, y)
+    check_case(tag, str(tmp_path), info)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the reference's loader / XDMF writer on files this build wrote (development container only)
+# ----------------------------------------------------------------------------------------------------------------------
+def _judge(*args):
+    res = subprocess.run([sys.executable, os.path.join(GOLDEN, "ref_judge.py"), *map(str, args)], capture_output=True, text=True,
+                         timeout=300)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+
+
+def _write_with_build(directory, d, n_t, with_data=True, with_const=True, seed=0):
+    """a file written through this package's Datawriter the way a user script would (write_data per dataset + a batch through
+    the background writer); returns what went in"""
+    from sparsespatialsampling_amd.data import Datawriter
+    rng = np.random.default_rng(seed)
+    nc, nv = 37, 91
+    want = {"centers": rng.random((nc, d)), "nodes": rng.random((nv, d)),
+            "faces": rng.integers(0, nv, (nc, 2 ** d)).astype(np.int32), "levels": rng.integers(1, 6, (nc, 1)),
+            "metric": rng.random(nc), "size": 1.75}
+    wr = Datawriter(directory, "mine.h5")
+    wr.write_data("faces", group="grid", data=pt.from_numpy(want["faces"]))
+    wr.write_data("vertices", group="grid", data=pt.from_numpy(want["nodes"]))
+    wr.write_data("centers", group="grid", data=pt.from_numpy(want["centers"]))
+    if with_const:
+        wr.write_data("levels", group="constant", data=pt.from_numpy(want["levels"]))
+        wr.write_data("metric", group="constant", data=pt.from_numpy(want["metric"]))
+        wr.write_data("size_initial_cell", group="constant", data=want["size"])
+        wr.write_data("node_flag", group="constant", data=rng.random(nv))                 # a node-centred constant field
+        wr.write_data("odd", group="constant", data=rng.random(5))                        # matches neither: not in the XDMF
+    if with_data:
+        times = [f"{0.5 * i:g}" for i in range(n_t)]                                       # "0", "0.5", "1", ... "10": name order != time order
+        want["times"] = times
+        want["p"], want["U"] = rng.random((nc, n_t)), rng.random((nc, d, n_t))
+        for i, t in enumerate(times):
+            wr.write_data("p_center", group="data", time_step=t, data=pt.from_numpy(want["p"][:, i]))
+        wr.write_snapshots("U_center", times, np.ascontiguousarray(np.moveaxis(want["U"], -1, 0)))
+        wr.write_snapshots("U_vertices", times[:2], rng.random((2, nv, d)))
+    wr.close()
+    return want
+
+
+@pytest.mark.skipif(not HAVE_REFERENCE, reason="the reference is not on this machine (GPU box)")
+@pytest.mark.parametrize("d", [2, 3])
+def test_reference_dataloader_reads_our_file(tmp_path, d):
+    want = _write_with_build(str(tmp_path), d, n_t=21)
+    out = os.path.join(str(tmp_path), "seen.npz")
+    _judge("load", tmp_path, "mine.h5", out)
+    seen = np.load(out)
+    assert np.array_equal(seen["vertices"], want["centers"]) and np.array_equal(seen["nodes"], want["nodes"])
+    assert np.array_equal(seen["faces"], want["faces"]) and seen["faces"].dtype == np.int32
+    assert np.array_equal(seen["levels"], want["levels"][:, 0]) and np.array_equal(seen["metric"], want["metric"])
+    np.testing.assert_allclose(seen["weights"], (want["size"] / 2.0 ** want["levels"][:, 0]) ** d, rtol=1e-15)
+    times = json.loads(str(seen["write_times"]))
+    assert times == sorted(want["times"]) and set(times) == set(want["times"])            # h5py lists in name order
+    names = json.loads(str(seen["field_names"]))
+    assert all(names[t] == ["U", "p"] for t in times)
+    order = [want["times"].index(t) for t in json.loads(str(seen["times_p"]))]
+    assert np.array_equal(seen["snap_p"], want["p"][:, order]) and np.array_equal(seen["snap_U"], want["U"][:, :, order])
+    assert json.loads(str(seen["pair_shapes"])) == [[37, d, 21], [37, 21]]
+    # and this package's loader sees the same as the reference's
+    from sparsespatialsampling_amd.data import Dataloader
+    ld = Dataloader(str(tmp_path), "mine.h5", dtype=pt.float64)
+    assert ld.write_times == times and ld.field_names == names
+    assert np.array_equal(ld.load_snapshot("p").numpy(), seen["snap_p"]) and np.array_equal(ld.load_snapshot("U").numpy(), seen["snap_U"])
+    assert np.array_equal(ld.weights.numpy(), seen["weights"]) and np.array_equal(ld.levels.numpy(), seen["levels"])
+
+
+@pytest.mark.skipif(not HAVE_REFERENCE, reason="the reference is not on this machine (GPU box)")
+@pytest.mark.parametrize("d,with_data,with_const,mixed", [(2, True, True, 0), (3, True, True, 0), (3, False, True, 0),
+                                                          (2, True, False, 0), (2, False, False, 0), (3, True, True, 1),
+                                                          (2, False, True, 1)])
+def test_reference_xdmf_writer_agrees_on_our_file(tmp_path, d, with_data, with_const, mixed):
+    """both XDMF writers describe the same file (temporal collection / single grid, with and without constants, Mixed):
+    byte-identical text"""
+    from sparsespatialsampling_amd.data import XDMFWriter
+    _write_with_build(str(tmp_path), d, n_t=12, with_data=with_data, with_const=with_const, seed=d)
+    XDMFWriter(str(tmp_path), "mine.h5", mixed=bool(mixed)).write_xdmf()
+    mine = open(os.path.join(str(tmp_path), "mine.xdmf")).read()
+    os.remove(os.path.join(str(tmp_path), "mine.xdmf"))
+    _judge("xdmf", tmp_path, "mine.h5", mixed)
+    theirs = open(os.path.join(str(tmp_path), "mine.xdmf")).read()
+    assert mine == theirs
+
+
+def test_standin_and_native_layer_agree_on_the_reference_file():
+    """the two independent bindings (tests' ctypes stand-in, product's libs3h5) list and read the reference's own data file
+    (tests/s_cube_test_dataset.h5) identically"""
+    path = os.path.join(GOLDEN, "s_cube_test_dataset.h5")
+    inv = inventory(path)
+    with h5io.open_h5(path, "r") as f:
+        assert f.keys() == sorted({p.split("/")[0] for p, _ in inv})
+        for p, a in inv:
+            b = f.read(p)
+            assert b.dtype == a.dtype and b.shape == a.shape and np.array_equal(a, b), p
+            assert f.shape(p) == a.shape

@@ -370,6 +370,31 @@ def copy_bandwidth_gbs(n_bytes=2 << 30, reps=5):
     return 2.0 * n_bytes * reps / (a.elapsed_time(b) * 1e-3) / 1e9
 
 
+def yardsticks(hipops, plan, data, steps, warmup):
+    """what this chip's memory system gives hand-written kernels of this library (the runtime's blit is a soft
+    yardstick): a float4 copy, a 7-read / 2-write mix (the headline launch's own 78 % / 22 %), reads only, and the LOADS of the
+    headline's tile plan on the headline's table with nothing else in the kernel (s3_yard_stream, s3_yard_plan_loads) -- the last
+    one in the shift kernel's schedule (one 128-byte line of a row per visit) and with two consecutive lines per visit."""
+    res = {}
+    n_bytes = 4 << 30
+    src = pt.empty(n_bytes // 4, dtype=pt.float32, device="cuda").normal_()
+    dst = pt.empty(n_bytes // 4, dtype=pt.float32, device="cuda")
+    for key, r, w in (("copy_float4", 1, 1), ("mix_7r2w", 7, 2), ("read_only", 4, 0)):
+        moved = hipops.yard_stream(src, dst, r, w)
+        ms = launch_times_ms(lambda: hipops.yard_stream(src, dst, r, w), max(steps // 2, 5), 2)
+        res[key] = dict(GBs=sum(moved) / (float(np.mean(ms)) * 1e-3) / 1e9, bytes_read=moved[0], bytes_written=moved[1], **ms_stats(ms))
+    del src, dst
+    if plan is not None:
+        for key, variant in (("plan_loads_one_line_per_visit", 0), ("plan_loads_two_lines_per_visit", 1)):
+            staged = plan.yard_loads(data, variant)
+            ms = launch_times_ms(lambda: plan.yard_loads(data, variant), steps, warmup)
+            res[key] = dict(staged_bytes=staged, staged_GBs=staged / (float(np.mean(ms)) * 1e-3) / 1e9, **ms_stats(ms))
+    res["note"] = ("GBs = bytes read + written per second of a hand-written streaming kernel over 4-GiB buffers (short-lived workgroups, one "
+                   "contiguous block each, nontemporal loads / stores: the fastest form measured, tools/copy_probe.hip); plan_loads: the headline's tile plan on the headline's table, loads only (256 threads, two workgroups per CU, "
+                   "two rolling sets of sixteen 16-byte vectors per lane), staged bytes include the halo the L2 serves")
+    return res
+
+
 _SMI = {}
 
 
@@ -1016,6 +1041,9 @@ def main():
         data = None
 
     copy_bw = copy_bandwidth_gbs() if rank == 0 else None
+    yard = None
+    if rank == 0 and world == 1 and plan is not None and data is not None and not args.traffic_child and not args.no_pitched_copy:
+        yard = optional_leg("yardsticks", lambda: yardsticks(hipops, plan, data, args.steps, args.warmup))
     if rank == 0:
         units = (nc * world if args.shard == "snapshots" else nc_total) * t_b * args.steps
         value = units / elapsed / 1e6
@@ -1059,6 +1087,18 @@ def main():
                          "algorithmic_bytes": b_alg, "resident_source_rows": n_rows, "cells_on_this_rank": nc,
                          "gather_upper_bound_bytes": nc * k * row_len * 4 + nc * row_len * 8},
         }
+        if yard is not None:
+            res["roofline"]["yardsticks"] = yard
+            mix = yard.get("mix_7r2w", {}).get("GBs", 0.0)
+            if mix > 0.0 and traffic is not None:
+                # the launch's measured bytes per second over what the hand-written 78 % / 22 % streaming mix moves per second
+                res["roofline"]["streaming_ceiling_GBs"] = mix
+                res["roofline"]["traffic_GBs"] = traffic / (kernel_ms * 1e-3) / 1e9
+                res["roofline"]["frac_of_streaming_ceiling"] = traffic / (kernel_ms * 1e-3) / 1e9 / mix
+                res["roofline"]["frac_if_streaming_ceiling_were_reached"] = b_alg / traffic * mix / 8000.0
+            loads = yard.get("plan_loads_one_line_per_visit", {})
+            if "kernel_ms" in loads:
+                res["roofline"]["plan_loads_over_launch"] = loads["kernel_ms"] / kernel_ms
         if placement is not None:
             if "kernel_ms" in placement:
                 placement["frac"] = b_alg / (placement["kernel_ms"] * 1e-3) / 8e12

@@ -40,7 +40,7 @@ extern "C" {
 
 /* what s3_abi_version() of a library built from this header returns; the bindings refuse a library that reports another
  * number (a stale build) with the command that rebuilds it */
-#define S3_ABI_VERSION 5
+#define S3_ABI_VERSION 6
 
 typedef struct s3_knn s3_knn; /* opaque: grid-sorted copy of the original point cloud, resident in HBM */
 typedef void *s3_stream;
@@ -272,6 +272,25 @@ int s3_interp_planned(s3_interp_plan *plan, const double *d_w /*[nc,k] or NULL*/
 int s3_interp_plan_set_source_ids(s3_interp_plan *plan, const int32_t *d_ids /*[n_src]*/, int64_t n_table_rows, s3_stream stream);
 int s3_interp_planned_src(s3_interp_plan *plan, const void *d_table, int dtype, int64_t n_table_rows, int64_t row_len,
                           int64_t in_stride, double *d_out /*[nc,row_len]*/, s3_stream stream);
+
+/* ---- yardsticks of the measurement (bench.py's roofline line; no counterpart in the reference, not on any product path) ----
+ * s3_yard_stream      a hand-written streaming kernel over d_src: every lane reads `reads` 16-byte vectors (coalesced) and
+ *                     writes `writes` vectors derived from them; (reads, writes) = (1, 1) float4 copy, (7, 2) the read / write
+ *                     mix of the headline launch (78 % / 22 %), (4, 0) reads only.  Short-lived workgroups, one contiguous block each (the
+ *                     fastest form measured, csrc/yardstick.hip).
+ *                     *h_bytes_read / *h_bytes_written = what the launch moved.
+ * s3_yard_plan_loads  the loads of a tile plan and nothing else, at the headline kernel's occupancy and load schedule, on the
+ *                     table s3_interp_planned_src reads (n_table_rows > 0) or s3_interp_planned's compacted one (0):
+ *                     variant 0 one 128-byte line of a row per visit (the shift kernel's schedule), variant 1 two consecutive
+ *                     lines (256 contiguous bytes) per visit with the same bytes and loads in flight.  *h_staged_bytes =
+ *                     rows staged over all tiles x lines x 128. */
+int s3_yard_stream(const void *d_src, void *d_dst, int64_t src_bytes, int64_t dst_bytes, int reads, int writes,
+                   int nontemporal, s3_stream stream, int64_t *h_bytes_read, int64_t *h_bytes_written);
+int s3_yard_plan_loads(s3_interp_plan *plan, const void *d_table, int64_t n_table_rows, int64_t row_bytes, int64_t stride_bytes,
+                       int variant, s3_stream stream, int64_t *h_staged_bytes);
+/* re-read the S3_* environment switches of the planned launches (they are parsed once, at the first launch; A/B tools that
+ * flip them inside one process call this after every change) */
+int s3_debug_reload_env(void);
 
 
 /* ---- device-side bookkeeping of the KNN cache (replaces torch.unique / fancy indexing on the a16 path) ----------

@@ -26,7 +26,7 @@ class S3HipError(RuntimeError):
 
 _hip = None
 _topo = None
-ABI_VERSION = 5          # S3_ABI_VERSION of include/s3hip.h this file was written against
+ABI_VERSION = 6          # S3_ABI_VERSION of include/s3hip.h this file was written against
 _REBUILD = "python -c 'import __graft_entry__ as g; g.build()'"
 
 c_i64, c_i32, c_int, c_dbl, c_vp = C.c_int64, C.c_int32, C.c_int, C.c_double, C.c_void_p
@@ -88,6 +88,9 @@ HIP_SIGNATURES = {
     "s3_interp_planned": (c_int, [c_vp, c_vp, c_vp, c_int, c_i64, c_i64, c_vp, c_vp]),
     "s3_interp_plan_set_source_ids": (c_int, [c_vp, c_vp, c_i64, c_vp]),
     "s3_interp_planned_src": (c_int, [c_vp, c_vp, c_int, c_i64, c_i64, c_i64, c_vp, c_vp]),
+    "s3_yard_stream": (c_int, [c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_vp, C.POINTER(c_i64), C.POINTER(c_i64)]),
+    "s3_yard_plan_loads": (c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_vp, C.POINTER(c_i64)]),
+    "s3_debug_reload_env": (c_int, []),
     "s3_comm_available": (c_int, []),
     "s3_comm_gather_to_root": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_vp]),
     "s3_interp_plan_cost_profile": (c_int, [c_vp, c_int, c_vp, c_vp]),

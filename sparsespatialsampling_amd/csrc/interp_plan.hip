@@ -1199,10 +1199,45 @@ static int short_row_vecs() {
 
 // fewest workgroups a launch of the chunk kernel should have before the column chunks are split over blockIdx.y
 // (S3_PLAN_MIN_BLOCKS overrides, for A/B runs)
-static int64_t min_blocks() {
-    const char *e = getenv("S3_PLAN_MIN_BLOCKS");
-    return e ? atoll(e) : 2048ll;
+// The S3_* switches of the planned launches (A/B runs, tests) are parsed ONCE, at the first launch: getenv on every launch raced with
+// the interpreter's putenv from other threads.  A tool that flips a switch inside a process calls s3_debug_reload_env()
+// afterwards (hipops.reload_env()) -- not while another thread launches.
+struct LaunchSwitches {
+    int64_t min_blocks = 2048, stream_min_tiles = 64;
+    int stream_max_chunks = 24, inplace_shift = 1, shift_min_chunks = 6;
+    int short_stream = -1;                      // -1 unset (decided by the table's size), 0 never, 1 always
+    bool short_no_quad = false, short_lds_weights = false;
+    int plan_split = 0, plan_brick = 0;         // 0 unset
+    bool tail_given = false;
+    int tail = 32, tail_split = 4;
+    int out_hold = 0;
+};
+static LaunchSwitches parse_switches() {
+    LaunchSwitches w;
+    if (const char *e = getenv("S3_PLAN_MIN_BLOCKS")) w.min_blocks = atoll(e);
+    if (const char *e = getenv("S3_STREAM_MIN_TILES")) w.stream_min_tiles = atoll(e);
+    if (const char *e = getenv("S3_STREAM_MAX_CHUNKS")) w.stream_max_chunks = atoi(e);
+    if (const char *e = getenv("S3_INPLACE_SHIFT")) w.inplace_shift = atoi(e);
+    if (const char *e = getenv("S3_SHIFT_MIN_CHUNKS")) w.shift_min_chunks = atoi(e);
+    if (const char *e = getenv("S3_SHORT_STREAM")) w.short_stream = e[0] == '1' ? 1 : 0;
+    w.short_no_quad = getenv("S3_SHORT_NO_QUAD") != nullptr;
+    w.short_lds_weights = getenv("S3_SHORT_LDS_WEIGHTS") != nullptr;
+    if (const char *e = getenv("S3_PLAN_SPLIT")) w.plan_split = atoi(e) < 1 ? 1 : atoi(e);
+    if (const char *e = getenv("S3_PLAN_BRICK")) w.plan_brick = atoi(e) < 1 ? 1 : atoi(e);
+    if (const char *e = getenv("S3_PLAN_TAIL")) {
+        w.tail_given = true;
+        w.tail = atoi(e);
+        const char *x = strchr(e, 'x');
+        w.tail_split = x ? atoi(x + 1) : 4;
+    }
+    if (const char *e = getenv("S3_OUT_HOLD")) w.out_hold = atoi(e);
+    return w;
 }
+static LaunchSwitches &switches() {
+    static LaunchSwitches w = parse_switches();
+    return w;
+}
+static int64_t min_blocks() { return switches().min_blocks; }
 
 static int plan_ucap(int k, int tc) {
     const int budget = (tc == 128 ? 160 : 80) * 1024;
@@ -1221,25 +1256,13 @@ using namespace s3;
 // segment loads were spread over its accumulate phase): rows on the line grid, cylinder3D plan, one process -- 288 / 320 / 384 /
 // 512 / 768 snapshots 1.049 / 1.046 / 1.259 / 1.767 / 2.478 ms against 1.117 / 1.090 / 1.307 / 1.841 / 2.608 with the chunk kernel;
 // 1000 snapshots (32 chunks) 3.689 against 3.529: the long sweeps stay with the chunk kernel's two chunks of prefetch
-static int stream_max_chunks() {
-    const char *e = getenv("S3_STREAM_MAX_CHUNKS");
-    return e ? atoi(e) : 24;
-}
-static int64_t stream_min_tiles() {
-    const char *e = getenv("S3_STREAM_MIN_TILES");
-    return e ? atoll(e) : 64ll;
-}
-static int inplace_shift() {                 // 0: never (A/B runs), 1: rows off the 128-byte grid (default), 2: always (A/B runs)
-    const char *e = getenv("S3_INPLACE_SHIFT");
-    return e ? atoi(e) : 1;
-}
+static int stream_max_chunks() { return s3::switches().stream_max_chunks; }
+static int64_t stream_min_tiles() { return s3::switches().stream_min_tiles; }
+static int inplace_shift() { return s3::switches().inplace_shift; }   // 0: never (A/B runs), 1: rows off the 128-byte grid (default), 2: always (A/B runs)
 // rows OFF the line grid of at least this many chunks take the shift kernel (whole aligned lines), shorter ones the persistent
 // kernel with straddling segments.  6 (r4; 3 before): dense rows of 68 / 100 / 136 / 200 / 300 / 600 snapshots (3 / 4 / 5 / 7 / 10 /
 // 19 chunks), one process: shift 0.409 / 0.535 / 0.618 / 0.842 / 1.214 / 2.176 ms, persistent 0.372 / 0.535 / 0.605 / 0.862 / 1.362 / 2.531
-static int shift_min_chunks() {
-    const char *e = getenv("S3_SHIFT_MIN_CHUNKS");
-    return e ? atoi(e) : 6;
-}
+static int shift_min_chunks() { return s3::switches().shift_min_chunks; }
 static int stream_workgroups() {
     static const int v = [] {
         const char *e = getenv("S3_STREAM_WORKGROUPS");
@@ -1418,16 +1441,16 @@ static int launch_planned(s3_interp_plan *p, const int32_t *rows, int64_t n_rows
     // never / always, for A/B runs.
     {
         const int vpr_ = (int)((row_len + EPV - 1) / EPV);
-        const char *sw = getenv("S3_SHORT_STREAM");
+        const int sw = s3::switches().short_stream;
         const bool in_place = rows != p->rows;
         const bool big_table = in_place && (uint64_t)n_rows * (uint64_t)in_stride * sizeof(T) > ((uint64_t)1 << 30);
-        const bool want = sw ? sw[0] == '1' : !big_table;
+        const bool want = sw >= 0 ? sw == 1 : !big_table;
         if (vpr_ >= 2 && vpr_ <= 4 && want && stream_can_take(p) && p->n_tiles >= stream_min_tiles())
             return launch_stream<T, true, true>(p, rows, data, row_len, in_stride, out, st);
     }
     if ((row_len + EPV - 1) / EPV <= s3::short_row_vecs() && p->tc == 64) {
         const int vpr = (int)((row_len + EPV - 1) / EPV);
-        if (vpr == 4 && p->ucap * vpr <= 256 * 8 && p->k <= 32 && !getenv("S3_SHORT_NO_QUAD") && !getenv("S3_SHORT_LDS_WEIGHTS")) {
+        if (vpr == 4 && p->ucap * vpr <= 256 * 8 && p->k <= 32 && !s3::switches().short_no_quad && !s3::switches().short_lds_weights) {
             // four vectors per row: the lanes of a cell are a DPP quad and share the loads of its weights / positions
             const size_t lds = (size_t)p->ucap * vpr * 16;
 #define S3_LAUNCH_SHORT_QUAD(KQ)                                                                                                 \
@@ -1444,7 +1467,7 @@ static int launch_planned(s3_interp_plan *p, const int32_t *rows, int64_t n_rows
             S3_LAUNCH_CHECK();
             return S3_OK;
         }
-        if (vpr <= 4 && p->ucap * vpr <= 256 * 8 && p->k <= 32 && !getenv("S3_SHORT_LDS_WEIGHTS")) {
+        if (vpr <= 4 && p->ucap * vpr <= 256 * 8 && p->k <= 32 && !s3::switches().short_lds_weights) {
             // one lane per (cell, vector) pair, weights in registers
             const size_t lds = (size_t)p->ucap * vpr * 16;
 #define S3_LAUNCH_SHORT_REG(KM)                                                                                                  \
@@ -1478,24 +1501,20 @@ static int launch_planned(s3_interp_plan *p, const int32_t *rows, int64_t n_rows
     // workgroup, runs in 2-D grid order)
     int gy = 1;
     while (gx * gy < s3::min_blocks() && gy < n_chunks) gy *= 2;
-    if (const char *e = getenv("S3_PLAN_SPLIT")) gy = atoi(e);
+    const LaunchSwitches &sw_ = s3::switches();
+    if (sw_.plan_split > 0) gy = sw_.plan_split;
     if (gy > n_chunks) gy = n_chunks;
     if (gy < 1) gy = 1;
     const int chunks_per_block = (n_chunks + gy - 1) / gy;
     gy = (n_chunks + chunks_per_block - 1) / chunks_per_block;
     int brick = (int)std::min<int64_t>(tiles_per_xcd, 1 << 30);
-    if (const char *e = getenv("S3_PLAN_BRICK")) brick = std::max(1, std::min(brick, atoi(e)));
+    if (sw_.plan_brick > 0) brick = std::max(1, std::min(brick, sw_.plan_brick));
     // a finer grain for the last tiles of every XCD's share (tail_map): only where a tile is swept by ONE workgroup and a launch
     // has several rounds of tiles per slot to drain (S3_PLAN_TAIL="<tiles per XCD>x<runs>", 0 = off)
     int tail = 0, tail_split = 1;
-    const char *te = getenv("S3_PLAN_TAIL");
-    if (gy == 1 && (te || (n_chunks >= 8 && tiles_per_xcd >= 4 * 64))) {
+    if (gy == 1 && (sw_.tail_given || (n_chunks >= 8 && tiles_per_xcd >= 4 * 64))) {
         tail = 32, tail_split = 4;          // (MI355X, cylinder3D, interleaved in one process: off 3.768 ms, 64x4 3.749, 32x4 3.736, 128x4 3.789, 64x8 3.781)
-        if (te) {
-            tail = atoi(te);
-            const char *x = strchr(te, 'x');
-            tail_split = x ? atoi(x + 1) : 4;
-        }
+        if (sw_.tail_given) tail = sw_.tail, tail_split = sw_.tail_split;
         if (tail > tiles_per_xcd) tail = (int)tiles_per_xcd;
         if (tail_split > n_chunks) tail_split = n_chunks;
         if (tail < 1 || tail_split < 2) tail = 0, tail_split = 1;
@@ -1512,8 +1531,7 @@ static int launch_planned(s3_interp_plan *p, const int32_t *rows, int64_t n_rows
         // 3.488 / 3.456, 3.575 / 3.569 on three boxes, interleaved in one process): the counter tallies two partial write-backs of a
         // line as more than the line, the DRAM bursts are the same, and the divergent store path is not free.  Off by default.
         // (A form with ONE store sequence for all lanes behind selects: 3.588 ms -- worse than the branch.)
-        const char *he = getenv("S3_OUT_HOLD");
-        const int hold = he ? atoi(he) : 0;
+        const int hold = sw_.out_hold;
 #define S3_LAUNCH_SHIFT(H)                                                                                                       \
     do {                                                                                                                         \
         auto kern = interp_planned_shift_kernel<T, H>;                                                                           \
@@ -1543,6 +1561,80 @@ static int launch_planned(s3_interp_plan *p, const int32_t *rows, int64_t n_rows
     }
     S3_LAUNCH_CHECK();
     return S3_OK;
+}
+
+// ---- yardstick (measurement aid of bench.py, not on any product path) ------------------------------------------------------
+// The LOADS of a tile plan and nothing else: one workgroup per tile at the headline kernel's occupancy (256 threads, two per CU, the
+// same dynamic LDS), eight lanes per 128-byte line, sixteen passes of 32 rows, whole aligned lines of the rows where they lie, two
+// register sets of sixteen vectors rolling -- the shift kernel's load schedule with the LDS image, the conversions, the FMAs and the
+// stores taken away.  What it measures is the time the memory system needs for the bytes this plan STAGES (halo included), i.e. the
+// floor of the tiling on this table.  VARIANT 0: every visit of a row fetches ONE line (sets = {all rows} x {line c}, {all rows} x
+// {line c + 1}: the schedule of interp_planned_shift_kernel).  VARIANT 1: every visit fetches TWO consecutive lines = 256 contiguous
+// bytes, one address translation (sets = {rows of passes 0-7} x {lines c, c + 1}, {rows of passes 8-15} x {lines c, c + 1}): the
+// same bytes, the same number of loads per issue and in flight -- the only difference is which lines share an issue.  That isolates
+// what "256 bytes of a row per visit"  can be worth; TCP_UTCL1_TRANSLATION_MISS counts the translations.
+template <int VARIANT>
+__global__ void __launch_bounds__(256, 2)
+plan_loads_kernel(const int32_t *__restrict__ tile_row_begin, const int32_t *__restrict__ rows, const char *__restrict__ data,
+                  uint64_t stride_bytes, uint64_t row_bytes, int n_lines, int64_t n_tiles, int64_t tiles_per_xcd, float *__restrict__ sink) {
+    extern __shared__ float4 lds_raw[];
+    const int64_t tile = (int64_t)(blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);      // XCD-aware, tile order (brick_map, n_split = 1)
+    if (tile >= n_tiles) return;
+    const int r_begin = tile_row_begin[tile], n_r = tile_row_begin[tile + 1] - r_begin;
+    const int srow = threadIdx.x >> 3, svec = threadIdx.x & 7;
+    const uintptr_t base = reinterpret_cast<uintptr_t>(data);
+    const char *const data128 = data - (base & 127);
+    const char *ptr[16];
+    int last[16];                                    // last line that holds bytes of the row (lines beyond it are clamped to it)
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+        const uintptr_t a = base + (uint64_t)(uint32_t)rows[r_begin + min(p * 32 + srow, n_r - 1)] * stride_bytes;
+        ptr[p] = data128 + ((a & ~(uintptr_t)127) - (base & ~(uintptr_t)127)) + 16u * (unsigned)svec;
+        last[p] = (int)(((a & 127) + row_bytes - 1) >> 7);
+    }
+    float acc = 0.f;
+    float4 x[16], y[16];
+    auto line = [&](int p, int j) { return *reinterpret_cast<const float4 *>(ptr[p] + (int64_t)min(j, last[p]) * 128); };
+    if constexpr (VARIANT == 0) {
+#pragma unroll
+        for (int p = 0; p < 16; ++p) x[p] = line(p, 0);
+#pragma unroll
+        for (int p = 0; p < 16; ++p) y[p] = line(p, 1);
+        for (int c = 0; c < n_lines; c += 2) {
+#pragma unroll
+            for (int p = 0; p < 16; ++p) acc += x[p].x + x[p].w;
+            if (c + 2 < n_lines) {
+#pragma unroll
+                for (int p = 0; p < 16; ++p) x[p] = line(p, c + 2);
+            }
+#pragma unroll
+            for (int p = 0; p < 16; ++p) acc += y[p].x + y[p].w;
+            if (c + 3 < n_lines) {
+#pragma unroll
+                for (int p = 0; p < 16; ++p) y[p] = line(p, c + 3);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) x[2 * p] = line(p, 0), x[2 * p + 1] = line(p, 1);
+#pragma unroll
+        for (int p = 0; p < 8; ++p) y[2 * p] = line(p + 8, 0), y[2 * p + 1] = line(p + 8, 1);
+        for (int c = 0; c < n_lines; c += 2) {
+#pragma unroll
+            for (int p = 0; p < 16; ++p) acc += x[p].x + x[p].w;
+            if (c + 2 < n_lines) {
+#pragma unroll
+                for (int p = 0; p < 8; ++p) x[2 * p] = line(p, c + 2), x[2 * p + 1] = line(p, c + 3);
+            }
+#pragma unroll
+            for (int p = 0; p < 16; ++p) acc += y[p].x + y[p].w;
+            if (c + 2 < n_lines) {
+#pragma unroll
+                for (int p = 0; p < 8; ++p) y[2 * p] = line(p + 8, c + 2), y[2 * p + 1] = line(p + 8, c + 3);
+            }
+        }
+    }
+    if (acc == 123.456f) sink[0] = acc + lds_raw[threadIdx.x].x;          // never true: keeps the loads (and the LDS allocation)
 }
 
 extern "C" {
@@ -1792,6 +1884,48 @@ int s3_interp_planned_src(s3_interp_plan *p, const void *d_table, int dtype, int
     S3_REQUIRE(n_table_rows == p->n_table, "s3_interp_planned_src: the table has %lld rows, the ids were given for %lld",
                (long long)n_table_rows, (long long)p->n_table);
     return planned_dispatch(p, p->rows_src, p->n_table, "s3_interp_planned_src", d_table, dtype, row_len, in_stride, d_out, stream);
+}
+
+
+int s3_debug_reload_env(void) {
+    s3::switches() = s3::parse_switches();
+    return S3_OK;
+}
+
+// yardstick: see plan_loads_kernel.  The table is the one s3_interp_planned_src reads (after s3_interp_plan_set_source_ids) or, with
+// n_table_rows == 0, the compacted table of s3_interp_planned.  *h_staged_bytes = rows staged over all tiles x lines x 128.
+int s3_yard_plan_loads(s3_interp_plan *p, const void *d_table, int64_t n_table_rows, int64_t row_bytes, int64_t stride_bytes, int variant,
+                       s3_stream stream, int64_t *h_staged_bytes) {
+    S3_REQUIRE(p != nullptr && d_table != nullptr, "s3_yard_plan_loads: null argument");
+    S3_REQUIRE(p->tc == 64 && p->ucap <= 512, "s3_yard_plan_loads: 64-cell tiles of <= 512 rows only");
+    S3_REQUIRE(row_bytes >= 128 && stride_bytes >= row_bytes && stride_bytes % 16 == 0 && reinterpret_cast<uintptr_t>(d_table) % 16 == 0,
+               "s3_yard_plan_loads: rows of >= 128 bytes at a 16-byte aligned pitch");
+    S3_REQUIRE(variant == 0 || variant == 1, "s3_yard_plan_loads: variant 0 | 1");
+    const int32_t *rows = p->rows;
+    if (n_table_rows > 0) {
+        S3_REQUIRE(p->rows_src != nullptr && n_table_rows == p->n_table, "s3_yard_plan_loads: call s3_interp_plan_set_source_ids for this table first");
+        rows = p->rows_src;
+    }
+    static float *d_sink = nullptr;
+    if (!d_sink) S3_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&d_sink), 16));
+    // lines of the row that starts furthest into a line: starts are (table start + i * pitch) mod 128
+    int64_t g = 128, b = stride_bytes % 128;
+    while (b) { const int64_t t = g % b; g = b; b = t; }
+    const int64_t max_phase = 128 - g + (int64_t)(reinterpret_cast<uintptr_t>(d_table) & 127) % g;
+    int n_lines = (int)((max_phase + row_bytes + 127) / 128);
+    n_lines += n_lines & 1;
+    const int64_t tiles_per_xcd = (p->n_tiles + 7) / 8;
+    const size_t lds = (size_t)p->ucap * PL_SEG + (size_t)p->k * p->tc * (sizeof(double) + sizeof(uint16_t));
+    auto k0 = plan_loads_kernel<0>;
+    auto k1 = plan_loads_kernel<1>;
+    auto kern = variant == 0 ? k0 : k1;
+    S3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    kern<<<dim3((unsigned)(tiles_per_xcd * 8)), 256, lds, as_stream(stream)>>>(p->tile_row_begin, rows, static_cast<const char *>(d_table),
+                                                                              (uint64_t)stride_bytes, (uint64_t)row_bytes, n_lines,
+                                                                              p->n_tiles, tiles_per_xcd, d_sink);
+    S3_LAUNCH_CHECK();
+    if (h_staged_bytes) *h_staged_bytes = p->total_rows * (int64_t)n_lines * 128;
+    return S3_OK;
 }
 
 

@@ -6,6 +6,7 @@ current HIP stream.  Every function below ends in exactly one hand-written HIP k
 operator runs on the hot path.  All tensors passed in must live on the current CUDA(HIP) device and be contiguous.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch as pt
@@ -180,6 +181,16 @@ def interp(w, idx, data, out=None):
 ASYNC_TRANSFERS = True
 
 
+def yard_stream(src, dst, reads, writes, nontemporal=True):
+    """yardstick (bench.py): hand-written streaming kernel, ``reads`` 16-byte vectors read per ``writes`` written
+    (s3_yard_stream); -> (bytes read, bytes written)"""
+    r, w = C.c_int64(0), C.c_int64(0)
+    check(_lib.hip_lib().s3_yard_stream(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), src.numel() * src.element_size(),
+                                        dst.numel() * dst.element_size(), int(reads), int(writes), int(bool(nontemporal)),
+                                        _stream(), C.byref(r), C.byref(w)), "s3_yard_stream")
+    return r.value, w.value
+
+
 def snapshot_major(values, n_comp, n_snapshots, out=None):
     """device [nc, n_comp*T] (or [nc, n_comp, T]) f64 -> device [T, nc, n_comp]: contiguous snapshots for the HDF5 sink"""
     nc = int(values.shape[0])
@@ -199,6 +210,26 @@ def snapshot_major_rows(values, n_comp, n_snapshots, rows, n_out, out_ptr):
         raise TypeError("snapshot_major_rows: one int32 device row id per input row required")
     check(_lib.hip_lib().s3_snapshot_major_rows(_ptr(values), int(values.shape[0]), int(n_comp), int(n_snapshots), _ptr(rows),
                                                 int(n_out), C.c_void_p(int(out_ptr)), _stream()), "s3_snapshot_major_rows")
+
+
+_LAUNCH_SWITCHES = ("S3_PLAN_MIN_BLOCKS", "S3_STREAM_MIN_TILES", "S3_STREAM_MAX_CHUNKS", "S3_INPLACE_SHIFT", "S3_SHIFT_MIN_CHUNKS",
+                    "S3_SHORT_STREAM", "S3_SHORT_NO_QUAD", "S3_SHORT_LDS_WEIGHTS", "S3_PLAN_SPLIT", "S3_PLAN_BRICK", "S3_PLAN_TAIL",
+                    "S3_OUT_HOLD")
+_switch_state = [None]
+
+
+def reload_env():
+    """the library parses its S3_* launch switches once; tell it to read them again (A/B tools, tests)"""
+    check(_lib.hip_lib().s3_debug_reload_env(), "s3_debug_reload_env")
+    _switch_state[0] = tuple(os.environ.get(k) for k in _LAUNCH_SWITCHES)
+
+
+def _sync_switches():
+    """a switch flipped through ``os.environ`` since the last planned launch reaches the library before the next one
+    (``os.environ`` is the interpreter's own dict: reading it races with nothing)"""
+    now = tuple(os.environ.get(k) for k in _LAUNCH_SWITCHES)
+    if now != _switch_state[0]:
+        reload_env()
 
 
 class InterpPlan:
@@ -309,6 +340,7 @@ class InterpPlan:
         row_len, in_stride, out = self._check_batch(data, out, "interp")
         if w is not self._w_ref or w._version != self._w_version:    # another tensor, or modified through torch: re-attach
             self.set_weights(w)
+        _sync_switches()
         check(_lib.hip_lib().s3_interp_planned(self._handle, C.c_void_p(0), C.c_void_p(data.data_ptr()),
                                                DTYPE_CODE[data.dtype], row_len, in_stride, _ptr(out), _stream()),
               "s3_interp_planned")
@@ -327,6 +359,15 @@ class InterpPlan:
             raise TypeError(f"InterpPlan.{who}: device tensors required, out must be contiguous float64 [nc, ...]")
         return row_len, in_stride, out
 
+    def yard_loads(self, table, variant=0, in_place=True):
+        """yardstick (bench.py): the loads of this plan on ``table`` and nothing else (s3_yard_plan_loads); -> staged bytes"""
+        row_len, in_stride = self._layout(table, None)
+        staged = C.c_int64(0)
+        check(_lib.hip_lib().s3_yard_plan_loads(self._handle, C.c_void_p(table.data_ptr()), self.n_table if in_place else 0,
+                                                row_len * table.element_size(), in_stride * table.element_size(), int(variant),
+                                                _stream(), C.byref(staged)), "s3_yard_plan_loads")
+        return staged.value
+
     def interp_src(self, table, out=None):
         """like ``interp`` for a FULL batch ``table`` [n_table, ...] that is read where it lies (no gather of the referenced
         rows first); needs ``set_weights`` and ``set_source_ids``"""
@@ -335,6 +376,7 @@ class InterpPlan:
         if int(table.shape[0]) != self.n_table or table.dtype not in DTYPE_CODE:
             raise TypeError("InterpPlan.interp_src: the table does not match the ids given to set_source_ids")
         row_len, in_stride, out = self._check_batch(table, out, "interp_src")
+        _sync_switches()
         check(_lib.hip_lib().s3_interp_planned_src(self._handle, C.c_void_p(table.data_ptr()), DTYPE_CODE[table.dtype],
                                                    self.n_table, row_len, in_stride, _ptr(out), _stream()),
               "s3_interp_planned_src")

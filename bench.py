@@ -297,6 +297,13 @@ def export_sharded(x, centers, k, comm, t=200, reps=3):
                      "ready for the writer of rank 0; each rank over its own PCIe link")
 
 
+# the batch lengths the reference exports with (examples/s3_for_cylinder3D_Re3900.py:28-69, utils.py:204-226)
+BATCH_SHAPES = [("T25", 25, "25 snapshots of a scalar field: 100-byte ragged rows"),
+                ("T25x3", 75, "25 snapshots of a 3-component field: 300-byte rows"),
+                ("T100", 100, "100 snapshots of a scalar field: 400-byte rows")]
+CHILD_LAUNCHES = 3          # launches per group of a PMC child pass (after one warm launch of the headline)
+
+
 def recorded_traffic(workload_key):
     """HBM bytes per launch of the dominant kernel as RECORDED in the committed PMC passes (profiles/rNN/summary.json:
     FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE from separate rocprofv3 --pmc runs of this
@@ -324,7 +331,8 @@ def measure_traffic(argv, kernel_prefix):
     import tempfile
     if shutil.which("rocprofv3") is None or "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
         return None
-    out, t0 = {}, time.perf_counter()
+    out, groups, t0 = {}, {}, time.perf_counter()
+    group_names = [f"{name}/{where}" for name, _, _ in BATCH_SHAPES for where in ("inplace", "pitched")]
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="s3_bench_pmc_")
         try:
@@ -336,19 +344,34 @@ def measure_traffic(argv, kernel_prefix):
             if run.returncode != 0 or not files:
                 print(f"[bench] PMC pass {counter} failed (rc {run.returncode}): {run.stderr[-300:]}", file=sys.stderr)
                 return None
-            vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(files[0]))
-                    if r["Counter_Name"] == counter and kernel_prefix in r["Kernel_Name"] and "permute" not in r["Kernel_Name"]]
+            rows = sorted(((int(r["Dispatch_Id"]), float(r["Counter_Value"])) for r in csv.DictReader(open(files[0]))
+                           if r["Counter_Name"] == counter and kernel_prefix in r["Kernel_Name"] and "permute" not in r["Kernel_Name"]))
+            vals = [v for _, v in rows]
             if not vals:
                 print(f"[bench] PMC pass {counter}: no launch of {kernel_prefix}", file=sys.stderr)
                 return None
-            out[counter] = (sum(vals) / len(vals), len(vals))
+            # the child launches in a fixed order: the headline (1 warm + CHILD_LAUNCHES), then per batch shape CHILD_LAUNCHES in place
+            # and CHILD_LAUNCHES on the pitched copy
+            head = vals[:1 + CHILD_LAUNCHES][1:]
+            out[counter] = (sum(head) / len(head), len(head))
+            rest = vals[1 + CHILD_LAUNCHES:]
+            if len(rest) == len(group_names) * CHILD_LAUNCHES:
+                for gi, gname in enumerate(group_names):
+                    g = rest[gi * CHILD_LAUNCHES:(gi + 1) * CHILD_LAUNCHES]
+                    groups.setdefault(gname, {})[counter] = sum(g) / len(g)
+            elif rest:
+                print(f"[bench] PMC pass {counter}: {len(rest)} launches behind the headline's, expected {len(group_names) * CHILD_LAUNCHES}: "
+                      f"batch shapes not attributed", file=sys.stderr)
         except (OSError, subprocess.SubprocessError, ValueError, KeyError) as err:
             print(f"[bench] PMC pass {counter} failed: {type(err).__name__}: {err}", file=sys.stderr)
             return None
         finally:
             shutil.rmtree(d, ignore_errors=True)
     fetch, write = out["FETCH_SIZE"][0], out["WRITE_SIZE"][0]
+    batches = {g: dict(traffic=(2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0, FETCH_SIZE_KiB_per_launch=c["FETCH_SIZE"],
+                       WRITE_SIZE_KiB_per_launch=c["WRITE_SIZE"]) for g, c in groups.items() if len(c) == 2}
     return dict(traffic=(2.0 * fetch + write) * 1024.0, FETCH_SIZE_KiB_per_launch=fetch, WRITE_SIZE_KiB_per_launch=write,
+                batches=batches,
                 launches_averaged=[out["FETCH_SIZE"][1], out["WRITE_SIZE"][1]], seconds=time.perf_counter() - t0,
                 how="measured in this run: two child processes of this command under rocprofv3 --pmc (one pass per counter, kernel-trace "
                     "only), 2 x FETCH_SIZE + WRITE_SIZE")
@@ -471,7 +494,7 @@ def planned_kernel_name(t_elems, k, plan_tiles, pitch_elems=None, table_bytes=0)
     return "interp_planned_kernel<float,64>"
 
 
-def batch_record(hipops, plan, w, used, n_points, nc, k, row_len, label, workload_key, steps, warmup, gen):
+def batch_record(hipops, plan, w, used, n_points, nc, k, row_len, label, workload_key, steps, warmup, gen, measured=None):
     """roofline sub-record of one batch shape: a dense [n_points, row_len] fp32 batch read in place (the API's form); the same
     launch on the pitched copy of the referenced rows (the layout ExportData uploads host batches into) beside it"""
     n_rows = int(used.numel())
@@ -481,18 +504,25 @@ def batch_record(hipops, plan, w, used, n_points, nc, k, row_len, label, workloa
     ms = launch_times_ms(lambda: plan.interp_src(table, out=out), steps, warmup)
     b_alg = n_rows * row_len * 4 + nc * row_len * 8 + nc * k * (4 + 8)
     st = ms_stats(ms)
-    traffic, src, stale = recorded_traffic(workload_key + "/inplace")
+    # HBM bytes per launch: measured in THIS run (the PMC child passes launched these shapes behind the headline) or absent -- a figure
+    # recorded by an earlier collection is no longer printed (`traffic_stale` must not be true in the line)
+    shape = workload_key.rsplit("/", 1)[-1]
+    m_in = (measured or {}).get("batches", {}).get(f"{shape}/inplace")
+    m_p = (measured or {}).get("batches", {}).get(f"{shape}/pitched")
+    traffic = m_in["traffic"] if m_in else None
+    src, stale = ("measured in this run (PMC child passes, 2 x FETCH_SIZE + WRITE_SIZE)" if m_in else None), (False if m_in else None)
     rec = dict(rows=label + ", dense [N, L] batch of all points read in place", row_bytes=row_len * 4, pitch_bytes=row_len * 4,
                kernel=planned_kernel_name(row_len, k, plan.n_tiles, row_len, table_bytes=n_points * row_len * 4),
                algorithmic_bytes=b_alg, achieved=b_alg / (st["kernel_ms"] * 1e-3) / 1e9, unit="GB/s",
                frac=b_alg / (st["kernel_ms"] * 1e-3) / 8e12, frac_best_launch=b_alg / (st["kernel_ms_min"] * 1e-3) / 8e12,
                Gcells_snapshots_per_s=nc * row_len / (st["kernel_ms"] * 1e-3) / 1e9, traffic=traffic,
-               traffic_source=None if traffic is None else f"recorded, not measured in this run: {src}", traffic_stale=stale, **st)
+               traffic_source=src, traffic_stale=stale, traffic_over_algorithmic=None if traffic is None else traffic / b_alg, **st)
     data = hipops.gather_rows(table, used, hipops.padded_rows(n_rows, row_len, pt.float32, "cuda"))
     del table
     pms = ms_stats(launch_times_ms(lambda: plan.interp(w, data, out=out), steps, warmup))
     rec["pitched_copy"] = dict(pitch_bytes=int(data.stride(0)) * 4, kernel=planned_kernel_name(row_len, k, plan.n_tiles),
-                               frac=b_alg / (pms["kernel_ms"] * 1e-3) / 8e12, **pms)
+                               frac=b_alg / (pms["kernel_ms"] * 1e-3) / 8e12, traffic=m_p["traffic"] if m_p else None,
+                               traffic_over_algorithmic=m_p["traffic"] / b_alg if m_p else None, **pms)
     del data, out
     return rec
 
@@ -848,7 +878,7 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
         sys.exit(launch_ranks(args, sys.argv[1:]))            # no launcher around us: start (and watch) the N ranks ourselves
     if args.traffic_child:                 # what a PMC pass profiles: the headline launch only, three times
-        args.steps, args.warmup = 3, 1
+        args.steps, args.warmup = CHILD_LAUNCHES, 1
         args.no_cpu_baseline = args.no_batches = args.no_pitched_copy = args.no_traffic = True
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -1040,6 +1070,21 @@ def main():
         sharded_leg = optional_leg("export_sharded", lambda: export_sharded(x, centers, k, comm, t=t_leg))    # (a failure on ALL ranks: no line lost)
         data = None
 
+    if args.traffic_child and plan is not None and world == 1:
+        # (PMC child pass: the batch shapes behind the headline, in the order measure_traffic() attributes the launches by)
+        del data
+        pt.cuda.empty_cache()
+        for _, rl, _ in BATCH_SHAPES:
+            table = pt.empty((len(x), rl), dtype=pt.float32, device="cuda").normal_(generator=gen)
+            o = pt.empty((nc, rl), dtype=pt.float64, device="cuda")
+            for _ in range(CHILD_LAUNCHES):
+                plan.interp_src(table, out=o)
+            rows_p = hipops.gather_rows(table, used.contiguous(), hipops.padded_rows(n_rows, rl, pt.float32, "cuda"))
+            for _ in range(CHILD_LAUNCHES):
+                plan.interp(w, rows_p, out=o)
+            pt.cuda.synchronize()
+            del table, o, rows_p
+        data = None
     copy_bw = copy_bandwidth_gbs() if rank == 0 else None
     yard = None
     if rank == 0 and world == 1 and plan is not None and data is not None and not args.traffic_child and not args.no_pitched_copy:
@@ -1114,13 +1159,10 @@ def main():
         if world == 1 and plan is not None and not args.no_batches:
             # the batch lengths the reference exports with (examples/s3_for_cylinder3D_Re3900.py:28-69, utils.py:204-226)
             key = args.workload
-            shapes = [("T25", 25, "25 snapshots of a scalar field: 100-byte ragged rows"),
-                      ("T25x3", 75, "25 snapshots of a 3-component field: 300-byte rows"),
-                      ("T100", 100, "100 snapshots of a scalar field: 400-byte rows")]
             res["roofline_batches"] = {name: optional_leg(f"roofline_batches.{name}", lambda rl=rl, label=label, name=name: batch_record(
                                                  hipops, plan, w, used.contiguous(), len(x), nc, k, rl, label, f"{key}/{name}",
-                                                 args.steps, args.warmup, gen))
-                                       for name, rl, label in shapes if rl != row_len}
+                                                 args.steps, args.warmup, gen, measured))
+                                       for name, rl, label in BATCH_SHAPES if rl != row_len}
             if "kernel_ms" in res["roofline_batches"].get("T25", {}):
                 res["roofline_batches"]["T25"]["numbering_follows_space"] = optional_leg("numbering_follows_space", lambda: numbering_follows_space(
                     hipops, x, idx, used, w, my_centers, k, 25, args.steps, args.warmup, gen))

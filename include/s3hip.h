@@ -57,6 +57,9 @@ int s3_device_count(int *h_count);
 int s3_set_device(int device);
 int s3_malloc(void **d_ptr, size_t bytes);
 int s3_free(void *d_ptr);
+/* host <-> device copies.  PAGE-LOCKED host memory (hipHostMalloc / s3_host_register): one asynchronous copy on `stream`.  PAGEABLE
+ * host memory is never handed to the runtime's copy engine (which would pin the caller's pages on the fly): it goes through the
+ * library's page-locked lanes (s3_upload_rows / s3_download) and the call returns when the copy is complete. */
 int s3_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes, s3_stream stream);
 int s3_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes, s3_stream stream);
 int s3_stream_synchronize(s3_stream stream);
@@ -374,6 +377,15 @@ int s3_weighted_gram(const double *d_x, int64_t n_rows, int64_t t, int64_t in_st
  * L [m][k] row pitch l_stride, B [k][n] contiguous, E [m][n] row pitch e_stride, C [m][n] contiguous; means may be NULL. */
 int s3_centered_gemm(const double *d_l, int64_t m, int64_t k, int64_t l_stride, const double *d_lmean, const double *d_b,
                      int64_t n, const double *d_e, int64_t e_stride, const double *d_emean, double *d_c, s3_stream stream);
+
+/* Symmetric eigenproblem of the T x T Gram matrix (the step between s3_weighted_gram and the modes; the reference gets the whole
+ * decomposition from flowtorch.analysis.SVD, utils.py:302-346).  The one LIBRARY call of the SVD path: rocSOLVER's dsyevd, looked up
+ * with dlopen at the first call (s3_sym_eig_available: 1 when it loads); the scaling to a unit diagonal maximum and back is done
+ * around it.  d_g [t][t] symmetric (read only), d_lam [t] eigenvalues ASCENDING, d_vec [t][t] row-major with eigenvector j in ROW j,
+ * d_scratch s3_sym_eig_scratch_bytes(t) bytes.  Complete on return. */
+int s3_sym_eig_available(void);
+size_t s3_sym_eig_scratch_bytes(int64_t t);
+int s3_sym_eig(const double *d_g, int64_t t, double *d_lam, double *d_vec, void *d_scratch, s3_stream stream);
 
 /* ---- device-resident topology of the sampling tree (a9-a11, a15) ------------------------------------------
  * Neighbour links, shared-node numbering, invalid-cell bookkeeping and the final renumbering of s_cube.py:904-1536,

@@ -104,6 +104,9 @@ HIP_SIGNATURES = {
     "s3_sum_ordered": (c_int, [c_vp, c_i64, c_vp, c_vp]),
     "s3_weighted_gram_scratch_bytes": (C.c_size_t, [c_i64, c_i64]),
     "s3_weighted_gram": (c_int, [c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "s3_sym_eig_available": (c_int, []),
+    "s3_sym_eig_scratch_bytes": (C.c_size_t, [c_i64]),
+    "s3_sym_eig": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
     "s3_mark_rows": (c_int, [c_vp, c_i64, c_i64, c_vp, c_vp]),
     "s3_compact_rows": (c_int, [c_vp, c_i64, c_vp, C.POINTER(c_i64), c_vp]),
     "s3_remap_indices": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp]),

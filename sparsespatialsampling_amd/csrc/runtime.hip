@@ -527,14 +527,50 @@ int s3_host_unregister(void *h_ptr) {
     return S3_OK;
 }
 
+// page-locked (hipHostMalloc / hipHostRegister) host memory?  Only such a pointer is handed to the runtime's copy engine as it is:
+// given a PAGEABLE pointer the runtime pins the caller's pages on the fly for copies of a megabyte and more, and that path ended
+// rare test processes of round 5 with "Memory access fault by GPU ... write access to a read-only page" at a host heap address
+// (DESIGN "known hazards").  Pageable memory goes through the library's own page-locked lanes instead, whatever the size.
+static bool host_memory_is_page_locked(const void *p) {
+    hipPointerAttribute_t a{};
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();                       // (an unregistered pointer is an "error" for older runtimes: not ours)
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
+
 int s3_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes, s3_stream stream) {
-    S3_HIP_CHECK(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, s3::as_stream(stream)));
+    if (bytes == 0) return S3_OK;
+    S3_REQUIRE(d_dst && h_src, "s3_memcpy_h2d: null array");
+    if (host_memory_is_page_locked(h_src)) {
+        S3_HIP_CHECK(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, s3::as_stream(stream)));
+        return S3_OK;
+    }
+    // pageable source: 1-MiB rows through the staged upload (+ the tail as one short row); complete on return
+    const int64_t row = 1 << 20, n_full = (int64_t)(bytes / (size_t)row);
+    const size_t tail = bytes - (size_t)n_full * (size_t)row;
+    if (n_full) {
+        const int rc = s3_upload_rows(h_src, n_full, row, d_dst, row, stream);
+        if (rc != S3_OK) return rc;
+    }
+    if (tail) {
+        const int rc = s3_upload_rows(static_cast<const char *>(h_src) + (size_t)n_full * row, 1, (int64_t)tail,
+                                      static_cast<char *>(d_dst) + (size_t)n_full * row, (int64_t)tail, stream);
+        if (rc != S3_OK) return rc;
+    }
+    S3_HIP_CHECK(hipStreamSynchronize(s3::as_stream(stream)));
     return S3_OK;
 }
 
 int s3_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes, s3_stream stream) {
-    S3_HIP_CHECK(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, s3::as_stream(stream)));
-    return S3_OK;
+    if (bytes == 0) return S3_OK;
+    S3_REQUIRE(h_dst && d_src, "s3_memcpy_d2h: null array");
+    if (host_memory_is_page_locked(h_dst)) {
+        S3_HIP_CHECK(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, s3::as_stream(stream)));
+        return S3_OK;
+    }
+    return s3_download(h_dst, d_src, bytes, stream);          // pageable destination: staged, complete on return
 }
 
 int s3_stream_synchronize(s3_stream stream) {

@@ -315,7 +315,9 @@ class _DeviceTopology(_Topology):
             out = np.empty((rows, per) if per > 1 else (rows,), dtype=dtype)
             ptr = C.c_void_p(0)
             self._ops.check(self._hip.s3_topo_table(self._h, which, C.byref(ptr)), "s3_topo_table")
-            self._ops.check(self._hip.s3_memcpy_d2h(out.ctypes.data_as(C.c_void_p), ptr, out.nbytes, None), "s3_memcpy_d2h")
+            # (staged through the library's page-locked lanes: the finished grid of C4 is ~1 GB, and a plain copy into fresh pageable
+            # memory is the pattern the runtime serves by pinning the destination on the fly -- ADVICE r5)
+            self._ops.check(self._hip.s3_download(out.ctypes.data_as(C.c_void_p), ptr, out.nbytes, None), "s3_download")
             self._cache[name] = out
         return self._cache[name]
 

@@ -11,7 +11,8 @@ How it runs on the MI355X (method of snapshots; the snapshot count T is small ag
    (``v_mfma_f64_16x16x4_f64``, csrc/svd.hip); centring and weighting are fused into the operand staging, the data matrix
    is read as the interpolation kernel left it (f64, HBM resident);
 3. ``G = V diag(s^2) V^T`` -- symmetric eigenproblem of a T x T matrix: the vendor's dense solver, the ONE library call of the path
-   (rocSOLVER through ``torch.linalg.eigh``; ``bench.py --workload svd`` reports it as ``"eigh": "library"`` with its share of a
+   (rocSOLVER's ``dsyevd`` behind the C ABI entry ``s3_sym_eig``, csrc/eig.hip -- looked up with dlopen, no torch operator involved;
+   ``bench.py --workload svd`` reports it as ``"eigh": "library"`` with its share of a
    ``compute_svd`` call.  A hand-written solver was priced and not built: one-sided Jacobi needs ~10 sweeps x (T - 1) rounds with a
    chip-wide synchronisation each -- 10^4 x ~5 us at T = 1000, more than the 23 ms of the library's tridiagonal solver -- and the
    blocked form leaves 16 workgroups busy);
@@ -54,21 +55,23 @@ def optimal_rank(s: pt.Tensor, n_rows: int, n_cols: int) -> int:
 
 
 def _eigh(g: pt.Tensor):
-    """symmetric eigenproblem of the small T x T Gram matrix: the vendor's dense solver on the device (a plain library call;
-    1000 x 1000 float64: ~0.1 s against ~0.8 s with LAPACK on the host), LAPACK on the host if that is not available;
-    results on the host"""
-    # scaled to a unit diagonal maximum first: the device solver works with an absolute tolerance -- on the Gram matrix of a
-    # deflated residual (entries of 1e-12 and below) it returned eigenvalues with a relative error of 4e-6 where the scaled
-    # call gives 1e-14 (tools/svd_accuracy_probe.py)
-    scale = g.diagonal().max()
-    if not bool(scale > 0):
-        return pt.linalg.eigh(g.cpu())
-    try:
-        lam, vec = pt.linalg.eigh(g / scale)
-        return (lam * scale).cpu(), vec.cpu()
-    except RuntimeError:
-        lam, vec = pt.linalg.eigh((g / scale).cpu())
-        return lam * scale.cpu(), vec
+    """symmetric eigenproblem of the small T x T Gram matrix through the C ABI (``s3_sym_eig``: rocSOLVER's dense solver looked up by
+    libs3hip.so itself, scaled to a unit diagonal maximum around the call -- csrc/eig.hip; 1000 x 1000 float64: ~0.1 s against ~0.8 s
+    with LAPACK on the host).  Returns (eigenvalues ascending, eigenvectors in COLUMNS) on the host, as ``torch.linalg.eigh`` does.
+    A process in which rocSOLVER cannot be loaded takes LAPACK on the host (``torch.linalg.eigh`` of the downloaded matrix)."""
+    lib = _lib.hip_lib()
+    t = int(g.shape[0])
+    if not (g.is_cuda and g.dtype == pt.float64 and g.is_contiguous()):
+        raise TypeError("_eigh: contiguous float64 device matrix required")
+    if not lib.s3_sym_eig_available():
+        scale = g.diagonal().max()
+        lam, vec = pt.linalg.eigh((g / scale).cpu() if bool(scale > 0) else g.cpu())
+        return (lam * scale.cpu() if bool(scale > 0) else lam), vec
+    lam = pt.empty(t, dtype=pt.float64, device=g.device)
+    rows = pt.empty((t, t), dtype=pt.float64, device=g.device)                   # eigenvector j in ROW j
+    scratch = pt.empty(int(lib.s3_sym_eig_scratch_bytes(t)), dtype=pt.uint8, device=g.device)
+    hipops.check(lib.s3_sym_eig(hipops._ptr(g), t, hipops._ptr(lam), hipops._ptr(rows), hipops._ptr(scratch), hipops._stream()), "s3_sym_eig")
+    return pt.from_numpy(hipops.to_host(lam)), pt.from_numpy(hipops.to_host(rows)).T
 
 
 LEVEL_RANGE = 1e-3          # singular values down to this fraction of a level's largest one are taken from that level's Gram matrix
@@ -128,11 +131,14 @@ def _spectrum(x2: pt.Tensor, mean: pt.Tensor, w: pt.Tensor, wanted: int):
             # on the host) the found directions are SHIFTED out of the way first: G + sigma B B^T gives them the eigenvalue sigma, twice
             # the largest one of the residual -- an eigenvalue of its own, so the solver returns every other vector orthogonal to B
             # to rounding, and orthonormal among themselves as always.  B B^T on the f64 matrix cores (s3_centered_gemm).
-            basis = pt.cat(v_parts, dim=1).to(x2.device)                          # [T, found]
-            # (Frobenius norm >= largest eigenvalue, and a tighter bound than the trace when the residual's spectrum is flat: the
-            # solver's absolute tolerance scales with sigma)
-            sigma = 2.0 * float((gram * gram).sum().sqrt())
-            gram = gram + sigma * centered_gemm(basis, None, basis.T.contiguous()) if sigma > 0 else gram
+            basis = pt.cat(v_parts, dim=1)                                        # [T, found], host
+            # sigma: the residual's largest eigenvalue is at most the LAST ACCEPTED one (the spectrum is descending), so twice that
+            # is an eigenvalue of its own.  (Round 5 took 2 ||G||_F, up to 2 sqrt(T) times larger: the solver's absolute tolerance
+            # scales with sigma once the matrix is brought to a unit diagonal -- ADVICE r5.)
+            sigma = 2.0 * float(s_parts[-1][-1]) ** 2
+            if sigma > 0:
+                # G + sigma B B^T = G - (-sigma B) B^T: one s3_centered_gemm with the Gram matrix as its "minus_from" operand
+                gram = centered_gemm(hipops.to_device(-sigma * basis), None, hipops.to_device(basis.T.contiguous()), minus_from=gram)
         lam, vec = _eigh(gram)                                    # ascending; T x T
         lam, vec = lam.flip(0).clamp_min(0.0), vec.flip(1)
         lam, vec = lam[found:], vec[:, found:]                    # (the `found` directions come out first, at sigma: dropped)

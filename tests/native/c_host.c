@@ -92,6 +92,77 @@ int main(void) {
             bad += out[c * T + t] != acc || out2[c * T + t] != acc;
         }
     }
+    /* downstream of the interpolation, still without torch (utils.py:302-346): weighted SVD of the interpolated matrix
+     * out [NC][T] by the method of snapshots -- row means, Gram matrix on the f64 matrix cores, the symmetric eigenproblem (the one
+     * library call, rocSOLVER behind s3_sym_eig), modes U = (X - mean) V S^-1 -- checked on the host: G v = lambda v, V orthonormal,
+     * U^T A U = I for the leading modes */
+    long bad_svd = 0;
+    if (s3_sym_eig_available()) {
+        enum { R = 8 };
+        void *d_mean, *d_area, *d_gram, *d_lam, *d_vec, *d_scr, *d_escr, *d_b, *d_u;
+        double *area = malloc(sizeof(double) * NC);
+        for (int c = 0; c < NC; ++c) area[c] = 0.5 + lcg(&seed);
+        CHECK(s3_malloc(&d_mean, sizeof(double) * NC));
+        CHECK(s3_malloc(&d_area, sizeof(double) * NC));
+        CHECK(s3_malloc(&d_gram, sizeof(double) * T * T));
+        CHECK(s3_malloc(&d_lam, sizeof(double) * T));
+        CHECK(s3_malloc(&d_vec, sizeof(double) * T * T));
+        CHECK(s3_malloc(&d_scr, s3_weighted_gram_scratch_bytes(NC, T)));
+        CHECK(s3_malloc(&d_escr, s3_sym_eig_scratch_bytes(T)));
+        CHECK(s3_malloc(&d_b, sizeof(double) * T * R));
+        CHECK(s3_malloc(&d_u, sizeof(double) * NC * R));
+        CHECK(s3_memcpy_h2d(d_area, area, sizeof(double) * NC, NULL));
+        CHECK(s3_row_moments(d_out, S3_DTYPE_F64, NC, T, T, 1, d_mean, NULL, NULL));
+        CHECK(s3_weighted_gram(d_out, NC, T, T, d_mean, d_area, d_gram, d_scr, NULL));
+        CHECK(s3_sym_eig(d_gram, T, d_lam, d_vec, d_escr, NULL));
+        double *gram = malloc(sizeof(double) * T * T), *lam = malloc(sizeof(double) * T), *vec = malloc(sizeof(double) * T * T);
+        double *mean = malloc(sizeof(double) * NC), *b = malloc(sizeof(double) * T * R), *u = malloc(sizeof(double) * NC * R);
+        CHECK(s3_memcpy_d2h(gram, d_gram, sizeof(double) * T * T, NULL));
+        CHECK(s3_memcpy_d2h(lam, d_lam, sizeof(double) * T, NULL));
+        CHECK(s3_memcpy_d2h(vec, d_vec, sizeof(double) * T * T, NULL));
+        CHECK(s3_memcpy_d2h(mean, d_mean, sizeof(double) * NC, NULL));
+        /* the Gram matrix itself against a plain host sum */
+        for (int i = 0; i < T; i += 7)
+            for (int j = 0; j < T; j += 5) {
+                double g = 0.0;
+                for (int c = 0; c < NC; ++c) g += area[c] * (out[c * T + i] - mean[c]) * (out[c * T + j] - mean[c]);
+                bad_svd += fabs(g - gram[i * T + j]) > 1e-11 * fabs(gram[0]) + 1e-300;
+            }
+        const double top = lam[T - 1];
+        for (int j = 0; j < T; ++j) {                 /* eigenvector j = ROW j of vec, eigenvalues ascending */
+            bad_svd += j > 0 && lam[j] < lam[j - 1];
+            double res = 0.0;
+            for (int i = 0; i < T; ++i) {
+                double gv = 0.0;
+                for (int m = 0; m < T; ++m) gv += gram[i * T + m] * vec[j * T + m];
+                res = fmax(res, fabs(gv - lam[j] * vec[j * T + i]));
+            }
+            bad_svd += res > 1e-12 * top;
+            for (int l = 0; l <= j; ++l) {
+                double dot = 0.0;
+                for (int m = 0; m < T; ++m) dot += vec[j * T + m] * vec[l * T + m];
+                bad_svd += fabs(dot - (l == j ? 1.0 : 0.0)) > 1e-12;
+            }
+        }
+        /* the R leading modes: B[:, r] = v_r / s_r (descending), U = (X - mean) B; U^T diag(area) U = I */
+        for (int r = 0; r < R; ++r)
+            for (int m = 0; m < T; ++m) b[m * R + r] = vec[(T - 1 - r) * T + m] / sqrt(lam[T - 1 - r]);
+        CHECK(s3_memcpy_h2d(d_b, b, sizeof(double) * T * R, NULL));
+        CHECK(s3_centered_gemm(d_out, NC, T, T, d_mean, d_b, R, NULL, 0, NULL, d_u, NULL));
+        CHECK(s3_memcpy_d2h(u, d_u, sizeof(double) * NC * R, NULL));
+        for (int r = 0; r < R; ++r)
+            for (int l = 0; l <= r; ++l) {
+                double dot = 0.0;
+                for (int c = 0; c < NC; ++c) dot += area[c] * u[c * R + r] * u[c * R + l];
+                bad_svd += fabs(dot - (l == r ? 1.0 : 0.0)) > 1e-9;
+            }
+        void *more[] = {d_mean, d_area, d_gram, d_lam, d_vec, d_scr, d_escr, d_b, d_u};
+        for (unsigned i = 0; i < sizeof(more) / sizeof(more[0]); ++i) CHECK(s3_free(more[i]));
+        printf("c_host: Gram -> s3_sym_eig -> modes through the C ABI: s_max %.6g, s_min %.3g, mismatches %ld\n", sqrt(top), sqrt(fabs(lam[0])), bad_svd);
+    } else {
+        printf("c_host: rocSOLVER not loadable in this process: SVD chain skipped\n");
+    }
+    bad += bad_svd;
     int64_t n_tiles = 0, n_rows = 0;
     CHECK(s3_interp_plan_info(plan, &n_tiles, &n_rows));
     s3_interp_plan_destroy(plan);

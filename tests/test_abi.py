@@ -117,3 +117,5 @@ def test_c_host_without_torch(tmp_path):
     run = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert run.returncode == 0, run.stdout + run.stderr
     assert "mismatches 0" in run.stdout
+    # the weighted-SVD chain (row means -> Gram -> s3_sym_eig -> modes) ran too: rocSOLVER is part of the image
+    assert "s3_sym_eig -> modes through the C ABI" in run.stdout and run.stdout.count("mismatches 0") == 2, run.stdout

@@ -78,14 +78,37 @@ def test_bench_two_ranks_share_one_gpu():
     assert r1["captured_metric"] == r2["captured_metric"] and r1["refine_iterations"] == r2["refine_iterations"]
 
 
-def _self_launched_bench(extra_env, timeout=900):
+def _self_launched_bench(extra_env, timeout=900, gpus=2):
     import json
     env = dict(os.environ, S3_BENCH_SHARE_GPU="1", **extra_env)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "S3_DIST_BACKEND"):
         env.pop(k, None)
-    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "cylinder3D_small", "--steps", "2",
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--workload", "cylinder3D_small", "--steps", "2",
                           "--warmup", "1", "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
     return run, [json.loads(ln) for ln in run.stdout.splitlines() if ln.startswith("{")]
+
+
+@pytest.mark.gpu
+def test_bench_five_ranks_share_one_gpu():
+    """the largest world size one GPU box allows next to the test process itself (the pool's guard: six processes on the card): five
+    self-launched ranks, an ODD number -- uneven leaf-cell shards, uneven batch slices, five mappings of the shared batch buffer --
+    give one line, the single-rank grid and captured metric, and no collective on the export's data path.  (Eight ranks are
+    rehearsed on the CPU: tests/test_parallel_gloo.py.)"""
+    run, lines = _self_launched_bench({}, gpus=5)
+    assert run.returncode == 0, run.stderr[-3000:]
+    assert len(lines) == 1
+    line = lines[0]
+    assert line["n_gpus"] == 5 and line["value"] > 0 and line["config"]["parallelism"] == "leaf-cell shards x5"
+    assert len(line["config"]["cells_per_rank"]) == 5 and sum(line["config"]["cells_per_rank"]) == line["config"]["n_cells"]
+    assert min(line["config"]["cells_per_rank"]) > 0
+    assert line["export_sharded"]["data_path_collectives_per_batch"] == 0 and "ms_per_batch" in line["export_sharded"]
+    import json
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "cylinder3D_small", "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    r1 = json.loads(one.stdout.strip().splitlines()[-1])
+    assert r1["config"]["n_cells"] == line["config"]["n_cells"] and r1["captured_metric"] == line["captured_metric"]
+    assert r1["grid_sha256"] == line["grid_sha256"]
 
 
 @pytest.mark.gpu

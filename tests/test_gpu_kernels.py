@@ -899,6 +899,64 @@ def test_compute_svd_small_singular_values():
     assert (v[:, :lead] * sign - vt_ref[:lead].T).abs().max() <= 1e-6
 
 
+def test_deflated_levels_stay_orthonormal_and_relatively_accurate():
+    """the vectors of deflation levels >= 1 (the shift that moves the found directions out of the way replaced an explicit
+    projection + QR): V^T V = I across ALL levels to 1e-12, and the singular values taken from a level >= 1 are accurate RELATIVE to
+    that level's largest one (1e-9), not only relative to s_max"""
+    from sparsespatialsampling_amd import svd
+    rng = np.random.default_rng(11)
+    n, t = 4000, 48
+    q1, _ = np.linalg.qr(rng.standard_normal((n, t)))
+    q2, _ = np.linalg.qr(rng.standard_normal((t, t)))
+    spectrum = 10.0 ** np.linspace(0, -8, t)
+    area = rng.random(n) * 0.5 + 0.05
+    centred = (q1 * spectrum) @ q2.T
+    centred -= centred.mean(1, keepdims=True)
+    data = pt.from_numpy(centred / np.sqrt(area)[:, None])
+    xw = (data - data.mean(-1, keepdim=True)) * pt.from_numpy(np.sqrt(area))[:, None]
+    s_ref = pt.linalg.svdvals(xw)
+    s, u, v = svd.compute_svd(data, pt.from_numpy(area), rank=t - 1)
+    gram_v = v.T @ v
+    assert float((gram_v - pt.eye(t - 1, dtype=pt.float64)).abs().max()) <= 1e-12
+    # levels: values below LEVEL_RANGE of the largest come from level >= 1 (s_max 1 -> level 1 starts near 1e-3, level 2 near 1e-6)
+    rel = ((s - s_ref[:t - 1]).abs() / s_ref[:t - 1])
+    for lo, hi in ((1e-3, 1.1), (1e-6, 1e-3), (3e-8, 1e-6)):
+        band = (s_ref[:t - 1] < hi) & (s_ref[:t - 1] >= lo)
+        assert int(band.sum()) > 3
+        top = float(s_ref[:t - 1][band].max())
+        assert float(((s - s_ref[:t - 1]).abs()[band]).max()) <= 1e-9 * top, (lo, hi)
+    assert float(rel[s_ref[:t - 1] >= 1e-5].max()) <= 1e-7
+    uw = u * pt.from_numpy(np.sqrt(area))[:, None]
+    lead = int((s_ref >= 1e-5).sum())
+    assert float((uw[:, :lead].T @ uw[:, :lead] - pt.eye(lead, dtype=pt.float64)).abs().max()) <= 1e-6
+
+
+@pytest.mark.parametrize("t,scale", [(1, 1.0), (7, 1.0), (64, 1e-14), (300, 1e9)])
+def test_sym_eig_through_the_c_abi(ops, t, scale):
+    """s3_sym_eig (rocSOLVER's dsyevd looked up by libs3hip.so, scaled to a unit diagonal maximum around the call): eigenvalues
+    ascending, eigenvector j in ROW j, G v = lambda v to 1e-13 * lambda_max -- also for a matrix whose entries are 1e-14 (the Gram
+    matrix of a deflated residual) -- against torch.linalg.eigh on the host as the checker"""
+    import ctypes as C
+    from sparsespatialsampling_amd import _lib
+    lib = _lib.hip_lib()
+    assert lib.s3_sym_eig_available() == 1
+    rng = np.random.default_rng(t)
+    a = rng.standard_normal((t + 5, t))
+    g = pt.from_numpy((a.T @ a) * scale).cuda()
+    lam = pt.empty(t, dtype=pt.float64, device="cuda")
+    rows = pt.empty((t, t), dtype=pt.float64, device="cuda")
+    scratch = pt.empty(int(lib.s3_sym_eig_scratch_bytes(t)), dtype=pt.uint8, device="cuda")
+    ops.check(lib.s3_sym_eig(C.c_void_p(g.data_ptr()), t, C.c_void_p(lam.data_ptr()), C.c_void_p(rows.data_ptr()),
+                             C.c_void_p(scratch.data_ptr()), None), "s3_sym_eig")
+    lam_h, rows_h, g_h = lam.cpu(), rows.cpu(), g.cpu()
+    lam_ref = pt.linalg.eigvalsh(g_h)
+    top = float(lam_ref[-1])
+    assert bool((lam_h[1:] >= lam_h[:-1]).all()) and float((lam_h - lam_ref).abs().max()) <= 1e-13 * top
+    assert float((g_h @ rows_h.T - rows_h.T * lam_h).abs().max()) <= 1e-13 * top
+    assert float((rows_h @ rows_h.T - pt.eye(t, dtype=pt.float64)).abs().max()) <= 1e-13
+    assert pt.equal(g.cpu(), g_h)                                # the input is left alone
+
+
 # ---- RCCL communicator inside the library (SURVEY 8(e)) -------------------------------------------------------------
 def test_rccl_comm_single_rank_roundtrip():
     """the s3_comm_* entry points on hardware with a one-rank communicator (a one-GPU box cannot host more ranks on RCCL):

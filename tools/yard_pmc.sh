@@ -3,9 +3,10 @@
 # counter group, kernel-trace only): the headline kernel against the load-only yardstick with one / two lines of a row per visit
 root=$(pwd); out=$root/gpurun_out/yard_pmc; mkdir -p $out; export TMPDIR=/tmp
 cd /tmp
-for grp in "TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum" "FETCH_SIZE WRITE_SIZE"; do
+# (one pass per group; FETCH_SIZE and WRITE_SIZE do NOT fit one pass -- asked for together rocprofv3 aborts and then hangs)
+for grp in "TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum" "FETCH_SIZE" "WRITE_SIZE"; do
   g=$(echo $grp | tr ' ' '_')
-  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $out/$g -- python $root/tools/yard_probe.py 1 plan > $out/$g.log 2>&1 &
+  timeout -k 10 400 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $out/$g -- python $root/tools/yard_probe.py 1 plan > $out/$g.log 2>&1 &
   pid=$!
   while kill -0 $pid 2>/dev/null; do sleep 30; echo "[yard_pmc] $g still running"; done
   wait $pid

@@ -49,7 +49,7 @@ import types
 
 # (robustness, no timed leg depends on it: torch's own copies to / from PAGEABLE host tensors of a MiB and more are served from the
 # runtime's staging buffers instead of pinning the caller's pages on the fly -- that path produced rare GPU memory faults in round 5,
-# DESIGN 9.  The library itself stages through its own page-locked buffers.  Set before the HIP runtime is even loaded.)
+# HISTORY 9.  The library itself stages through its own page-locked buffers.  Set before the HIP runtime is even loaded.)
 os.environ.setdefault("GPU_PINNED_MIN_XFER_SIZE", "4096")
 
 import numpy as np  # noqa: E402
@@ -708,7 +708,7 @@ def bench_svd(args, json_fd):
            "roofline": {"bound": "mfma", "achieved": achieved, "peak": 78.6, "unit": "TFLOP/s", "frac": achieved / 78.6,
                         "peak_source": "AMD MI355X datasheet, f64 matrix (the CDNA4 guide lists no f64 figure)",
                         "sustained_instruction_rate": 46.0, "frac_of_sustained": achieved / 46.0,
-                        "sustained_source": "bare v_mfma_f64_16x16x4_f64 loop, operands in registers (tools/mfma_f64_peak.hip, DESIGN 5.6)",
+                        "sustained_source": "bare v_mfma_f64_16x16x4_f64 loop, operands in registers (tools/mfma_f64_peak.hip, HISTORY 5.6)",
                         "kernel": "gram_block_kernel", "algorithmic_flops": flops, "traffic": None, **st},
            "mode_gemm": dict(kernel="centered_gemm_kernel", shapes=gemm,
                              note="C[N, r] = (X - mean 1^T) B, X [N, T] f64 as the interpolation left it, B [T, r]; flops 2 N T r"),
@@ -1173,7 +1173,7 @@ def main():
             # the transport legs BEFORE the CPU baselines: the download buffers of a 1000-snapshot batch (2 x 3.7 GB of page-locked
             # memory) allocated after the CPU baseline had run came down at 31 GB/s instead of 57 (cause not isolated) -- on
             # every box tried, whatever the threads' placement (device_resident_input.T1000.fit_data_ms 118 ms against 66 in a process
-            # that does only that)
+            # that does only that; HISTORY 6.2)
             if not cfg.get("kind") == "box":
                 res["device_resident_input"] = optional_leg("device_resident_input", lambda: device_resident_input(x, centers, k, sorted({25, t_b}), bare))
                 pt.cuda.empty_cache()

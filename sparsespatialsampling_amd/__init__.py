@@ -8,7 +8,7 @@ keep the reference's names and signatures (``SparseSpatialSampling``, ``s_cube.S
 """
 import os as _os
 
-# A hazard of the HIP runtime this package met in its own test processes (round 5; DESIGN "known hazards", INTEGRATION "Deviations /
+# A hazard of the HIP runtime this package met in its own test processes (round 5; DESIGN §8, INTEGRATION "Deviations /
 # hazards"): a copy between the device and PAGEABLE host memory of a megabyte or more is served by pinning the caller's pages on the
 # fly, and rare processes ended with "Memory access fault by GPU ... write access to a read-only page" at a host heap address inside
 # torch's ``tensor.cpu()`` right after this library's multi-threaded uploads.  The library itself stages every pageable copy through

@@ -156,7 +156,7 @@ permute_weights_kernel(const int32_t *__restrict__ perm, const int32_t *__restri
 // The persistent kernel keeps a tile's tables in registers: lane (cell, v0) of a cell's DPP quad holds the entries m = 4 i + v0.  Read
 // from the [m][cell] layout above that is 2 * ceil(k / 4) loads of 8 and 2 bytes per lane and tile -- fourteen vector-memory
 // instructions at k = 26, as many as the tile's row segments take when a row is one chunk long, and the number of those a CU has
-// accepted is what paces a step.  Second copy in LANE order: per tile and lane the weights as ceil(KQ / 2) 16-byte
+// accepted is what paces a step (HISTORY 5.2b).  Second copy in LANE order: per tile and lane the weights as ceil(KQ / 2) 16-byte
 // vectors ([vector][lane]: a wavefront's load is one contiguous KiB) and the positions as ONE vector of eight 16-bit entries.
 //   wl: tile offset c_begin * 4 * NV * 2 doubles, then [j < NV][lane < 4 n_c][2];  pl: c_begin * 32 entries, then [lane][8]
 __global__ void __launch_bounds__(256)
@@ -751,7 +751,7 @@ interp_planned_shift_kernel(const int32_t *__restrict__ perm, const int32_t *__r
     // [c_start, n) and then [0, c_start)).  Tiles that share rows then ask for the same lines within the few microseconds the L2 keeps
     // them: FETCH_SIZE -11.6 % with 10-us slots, -6.3 % at 6.0 us, -3.7 % at 5.4 us (a step takes 5.8 us on its own) -- but the launch
     // took 4.07 / 3.86 ms against 3.65: in lock-step all workgroups load at once and compute at once, and the overlap between
-    // workgroups that the memory system lives on is gone.  (tools/ab_order.py, tools/pmc_order.sh)
+    // workgroups that the memory system lives on is gone.  (tools/ab_order.py, tools/pmc_order.sh; HISTORY 5.1b.)
     if (chunk0 < chunk1) {
         S3H_ISSUE(A, chunk0, 0);
         S3H_ISSUE(B, chunk0 + 1, 1);

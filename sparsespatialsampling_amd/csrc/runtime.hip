@@ -346,7 +346,7 @@ int s3_download(void *h_dst, const void *d_src, size_t bytes, s3_stream stream) 
     if (bytes < 4 * UP_CHUNK_BYTES) {
         // small: not worth the threads -- but through a page-locked buffer of the library all the same (r5): handed a pageable
         // destination the runtime pins the caller's pages on the fly, and that path produced rare GPU memory faults ("write access
-        // to a read-only page" at a host heap address)
+        // to a read-only page" at a host heap address, HISTORY 9)
         std::lock_guard<std::mutex> guard(g_upload_mutex);
         S3_HIP_CHECK(upload_lane_init(g_lanes[0]));
         UploadLane &l = g_lanes[0];
@@ -530,7 +530,7 @@ int s3_host_unregister(void *h_ptr) {
 // page-locked (hipHostMalloc / hipHostRegister) host memory?  Only such a pointer is handed to the runtime's copy engine as it is:
 // given a PAGEABLE pointer the runtime pins the caller's pages on the fly for copies of a megabyte and more, and that path ended
 // rare test processes of round 5 with "Memory access fault by GPU ... write access to a read-only page" at a host heap address
-// (DESIGN "known hazards").  Pageable memory goes through the library's own page-locked lanes instead, whatever the size.
+// (DESIGN §8).  Pageable memory goes through the library's own page-locked lanes instead, whatever the size.
 static bool host_memory_is_page_locked(const void *p) {
     hipPointerAttribute_t a{};
     if (hipPointerGetAttributes(&a, p) != hipSuccess) {

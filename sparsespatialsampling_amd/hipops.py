@@ -74,7 +74,7 @@ def to_device(x, dtype=None):
         return x.to(dev, non_blocking=False).contiguous()       # no page-locked staging memory on this host
     # (r5: every size goes through the library's own page-locked staging buffers -- no pageable pointer is handed to the HIP
     # runtime, which would pin the caller's pages on the fly; round 5 saw rare GPU memory faults, "write access to a read-only page"
-    # at a host heap address, in copies the runtime had pinned that way: DESIGN 9)
+    # at a host heap address, in copies the runtime had pinned that way: HISTORY 9)
     out = pt.empty(x.shape, dtype=x.dtype, device=dev)
     flat_h, flat_d = x.reshape(-1), out.reshape(-1)
     row = (1 << 20) // x.element_size()                     # 1-MiB rows, pitch = row length

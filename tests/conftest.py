@@ -13,7 +13,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 # The tests move a lot of data with torch's own ``.cpu()`` / ``.cuda()`` on PAGEABLE host tensors.  For copies of a MiB and more the
 # HIP runtime pins the caller's pages on the fly and lets the GPU read / write them directly; in round 5 four test processes in ~60
 # ended with "Memory access fault by GPU ... Write access to a read-only page" at a host HEAP address inside such a copy (always a
-# ``tensor.cpu()`` of test_upload_rows, right after host threads had swept large host tensors).  The library itself never
+# ``tensor.cpu()`` of test_upload_rows, right after host threads had swept large host tensors; HISTORY 9).  The library itself never
 # hands a pageable pointer to the runtime (it stages through its own page-locked buffers); for the tests' own copies the runtime is
 # told to use ITS staging buffers instead of pinning below 4 GiB -- set before anything initialises HIP.
 os.environ.setdefault("GPU_PINNED_MIN_XFER_SIZE", "4096")

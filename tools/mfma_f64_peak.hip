@@ -1,5 +1,5 @@
 // dev helper (standalone): sustained rate of v_mfma_f64_16x16x4_f64 with operands in registers -- the practical ceiling next to
-// the 78.6 TFLOP/s datasheet figure that DESIGN 5.6 prices the Gram kernel against.
+// the 78.6 TFLOP/s datasheet figure that HISTORY 5.6 prices the Gram kernel against.
 //   hipcc --offload-arch=gfx950 -O3 -o tools/bin/mfma_f64_peak tools/mfma_f64_peak.hip && tools/bin/mfma_f64_peak
 #include <hip/hip_runtime.h>
 #include <cstdio>

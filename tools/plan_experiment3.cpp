@@ -1,6 +1,6 @@
 // dev helper (offline, no GPU): row-segment fetch counts when ONE workgroup walks a run of R consecutive tiles per column chunk
 // and keeps the rows of the previous tiles in LDS (optimal replacement: the plan is static), for tile sizes / LDS row
-// capacities / run lengths.
+// capacities / run lengths (HISTORY 5.1).
 //   g++ -O2 -std=c++17 -o /tmp/pe3 tools/plan_experiment3.cpp && /tmp/pe3 gpurun_out/c3_centers.f64 gpurun_out/c3_idx.i32 26
 #include <algorithm>
 #include <cstdint>

@@ -21,6 +21,29 @@ os.environ.setdefault("GPU_PINNED_MIN_XFER_SIZE", "4096")
 
 _BUILD_ERROR = []
 
+# A process WITHOUT torch that reaches s3_sym_eig loads the image's own rocSOLVER (/opt/rocm/lib/librocsolver.so.0: 0.9 GB); on a
+# fresh GPU box the image's files are paged in on first touch and that load took one to five minutes.  On a machine with a GPU the
+# file is read into the page cache from the start of the session, in the background, so that the test which needs it
+# (test_c_host_svd_chain_without_torch, late in the run) finds it warm.  (Python processes are not affected: torch brings its own copy
+# and has loaded it at import.)
+_WARM = {"thread": None}
+
+
+def _warm_libraries():
+    for path in ("/opt/rocm/lib/librocsolver.so.0", "/opt/rocm/lib/librocblas.so.5"):
+        try:
+            with open(path, "rb", buffering=0) as f:
+                while f.read(16 << 20):
+                    pass
+        except OSError:
+            pass
+
+
+def wait_for_warm_libraries(timeout_s):
+    t = _WARM["thread"]
+    if t is not None:
+        t.join(timeout_s)
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
@@ -34,6 +57,10 @@ def pytest_configure(config):
         entry.build_oracle()
     except Exception as err:                         # compiler missing / compile error / ...
         _BUILD_ERROR.append(f"{type(err).__name__}: {err}")
+    if os.path.exists("/dev/kfd") and _WARM["thread"] is None:      # a machine with a GPU (nothing here initialises it)
+        import threading
+        _WARM["thread"] = threading.Thread(target=_warm_libraries, daemon=True)
+        _WARM["thread"].start()
 
 
 @pytest.fixture(autouse=True, scope="session")

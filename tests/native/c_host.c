@@ -5,6 +5,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <string.h>
 #include <stdlib.h>
 
 #include "s3hip.h"
@@ -23,7 +24,9 @@ static double lcg(uint64_t *s) {
     return (double)(*s >> 11) / 9007199254740992.0;
 }
 
-int main(void) {
+int main(int argc, char **argv) {
+    /* "nosvd": without the weighted-SVD chain (its one library call loads rocSOLVER, a 0.9-GB file that a fresh machine pages in for minutes) */
+    const int with_svd = !(argc > 1 && strcmp(argv[1], "nosvd") == 0);
     enum { N = 5000, NC = 700, K = 26, DIM = 3, T = 40 };
     int n_dev = 0;
     CHECK(s3_device_count(&n_dev));
@@ -47,10 +50,12 @@ int main(void) {
     CHECK(s3_malloc(&d_data, sizeof(float) * N * T));
     CHECK(s3_malloc(&d_out, sizeof(double) * NC * T));
     CHECK(s3_malloc(&d_out2, sizeof(double) * NC * T));
+    fprintf(stderr, "c_host: uploading\n");
     CHECK(s3_memcpy_h2d(d_pts, pts, sizeof(double) * N * DIM, NULL));
     CHECK(s3_memcpy_h2d(d_q, q, sizeof(double) * NC * DIM, NULL));
     CHECK(s3_memcpy_h2d(d_data, data, sizeof(float) * N * T, NULL));
 
+    fprintf(stderr, "c_host: kernels\n");
     s3_knn *knn = NULL;
     CHECK(s3_knn_create(d_pts, N, DIM, 0.0, NULL, &knn));
     CHECK(s3_knn_query(knn, d_q, NC, K, d_idx, d_dist, NULL));
@@ -64,6 +69,7 @@ int main(void) {
     int32_t *idx = malloc(sizeof(int32_t) * NC * K);
     double *dist = malloc(sizeof(double) * NC * K), *w = malloc(sizeof(double) * NC * K);
     double *out = malloc(sizeof(double) * NC * T), *out2 = malloc(sizeof(double) * NC * T);
+    fprintf(stderr, "c_host: downloading\n");
     CHECK(s3_memcpy_d2h(idx, d_idx, sizeof(int32_t) * NC * K, NULL));
     CHECK(s3_memcpy_d2h(dist, d_dist, sizeof(double) * NC * K, NULL));
     CHECK(s3_memcpy_d2h(w, d_w, sizeof(double) * NC * K, NULL));
@@ -97,7 +103,10 @@ int main(void) {
      * library call, rocSOLVER behind s3_sym_eig), modes U = (X - mean) V S^-1 -- checked on the host: G v = lambda v, V orthonormal,
      * U^T A U = I for the leading modes */
     long bad_svd = 0;
-    if (s3_sym_eig_available()) {
+    fprintf(stderr, "c_host: svd chain\n");
+    if (!with_svd) {
+        printf("c_host: SVD chain not asked for\n");
+    } else if (s3_sym_eig_available()) {
         enum { R = 8 };
         void *d_mean, *d_area, *d_gram, *d_lam, *d_vec, *d_scr, *d_escr, *d_b, *d_u;
         double *area = malloc(sizeof(double) * NC);
@@ -111,10 +120,16 @@ int main(void) {
         CHECK(s3_malloc(&d_escr, s3_sym_eig_scratch_bytes(T)));
         CHECK(s3_malloc(&d_b, sizeof(double) * T * R));
         CHECK(s3_malloc(&d_u, sizeof(double) * NC * R));
+        fprintf(stderr, "c_host:   area up\n");
         CHECK(s3_memcpy_h2d(d_area, area, sizeof(double) * NC, NULL));
+        fprintf(stderr, "c_host:   moments\n");
         CHECK(s3_row_moments(d_out, S3_DTYPE_F64, NC, T, T, 1, d_mean, NULL, NULL));
+        fprintf(stderr, "c_host:   gram\n");
         CHECK(s3_weighted_gram(d_out, NC, T, T, d_mean, d_area, d_gram, d_scr, NULL));
+        CHECK(s3_stream_synchronize(NULL));
+        fprintf(stderr, "c_host:   eig\n");
         CHECK(s3_sym_eig(d_gram, T, d_lam, d_vec, d_escr, NULL));
+        fprintf(stderr, "c_host:   eig done, downloading\n");
         double *gram = malloc(sizeof(double) * T * T), *lam = malloc(sizeof(double) * T), *vec = malloc(sizeof(double) * T * T);
         double *mean = malloc(sizeof(double) * NC), *b = malloc(sizeof(double) * T * R), *u = malloc(sizeof(double) * NC * R);
         CHECK(s3_memcpy_d2h(gram, d_gram, sizeof(double) * T * T, NULL));
@@ -147,6 +162,7 @@ int main(void) {
         /* the R leading modes: B[:, r] = v_r / s_r (descending), U = (X - mean) B; U^T diag(area) U = I */
         for (int r = 0; r < R; ++r)
             for (int m = 0; m < T; ++m) b[m * R + r] = vec[(T - 1 - r) * T + m] / sqrt(lam[T - 1 - r]);
+        fprintf(stderr, "c_host:   modes\n");
         CHECK(s3_memcpy_h2d(d_b, b, sizeof(double) * T * R, NULL));
         CHECK(s3_centered_gemm(d_out, NC, T, T, d_mean, d_b, R, NULL, 0, NULL, d_u, NULL));
         CHECK(s3_memcpy_d2h(u, d_u, sizeof(double) * NC * R, NULL));
@@ -174,5 +190,9 @@ int main(void) {
     for (unsigned i = 0; i < sizeof(bufs) / sizeof(bufs[0]); ++i) CHECK(s3_free(bufs[i]));
     printf("c_host: %d cells x %d snapshots, %lld tiles / %lld staged rows, mismatches %ld\n", NC, T, (long long)n_tiles,
            (long long)n_rows, bad);
+    fflush(stdout);
+    fprintf(stderr, "c_host: shutting the library's transfer threads down\n");
+    s3_shutdown();          /* the staged copies of pageable memory started the library's lane threads: join them before exit */
+    fprintf(stderr, "c_host: done\n");
     return bad ? 4 : 0;
 }

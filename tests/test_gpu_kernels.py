@@ -957,6 +957,20 @@ def test_sym_eig_through_the_c_abi(ops, t, scale):
     assert pt.equal(g.cpu(), g_h)                                # the input is left alone
 
 
+def test_c_host_svd_chain_without_torch(tmp_path):
+    """the plain-C host of tests/native/c_host.c WITH its weighted-SVD chain: row means -> Gram matrix on the f64 matrix cores ->
+    s3_sym_eig (rocSOLVER looked up by libs3hip.so in a process that holds no torch: the image's own 0.9-GB librocsolver, which
+    tests/conftest.py reads into the page cache from the start of a GPU session -- a cold first load takes minutes) -> modes,
+    checked on the host in C: G v = lambda v, V orthonormal, U^T A U = I"""
+    import subprocess
+    from tests.conftest import wait_for_warm_libraries
+    from tests.test_abi import build_c_host
+    wait_for_warm_libraries(240)
+    run = subprocess.run([build_c_host(tmp_path)], capture_output=True, text=True, timeout=420)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "s3_sym_eig -> modes through the C ABI" in run.stdout and run.stdout.count("mismatches 0") == 2, run.stdout
+
+
 # ---- RCCL communicator inside the library (SURVEY 8(e)) -------------------------------------------------------------
 def test_rccl_comm_single_rank_roundtrip():
     """the s3_comm_* entry points on hardware with a one-rank communicator (a one-GPU box cannot host more ranks on RCCL):

@@ -46,8 +46,17 @@ def test_bench_contract_small_workload():
     import shutil
     if shutil.which("rocprofv3"):
         m = res["roofline"]["traffic_measured"]
-        assert m is not None and m["launches_averaged"] == [4, 4] and "measured in this run" in res["roofline"]["traffic_source"]
+        assert m is not None and m["launches_averaged"] == [3, 3] and "measured in this run" in res["roofline"]["traffic_source"]
         assert 0.9 < res["roofline"]["traffic_over_algorithmic"] < 3 and res["roofline"]["traffic_stale"] is False
+        # ... and so is the traffic of every batch shape printed (the same child passes launch them behind the headline): no
+        # `traffic_stale` anywhere in the line, no figure taken over from an earlier collection
+        assert set(m["batches"]) == {f"{n}/{w}" for n in ("T25", "T25x3", "T100") for w in ("inplace", "pitched")}
+        for name, rec in res["roofline_batches"].items():
+            assert rec["traffic_stale"] is False and "measured in this run" in rec["traffic_source"], name
+            assert 0.9 < rec["traffic_over_algorithmic"] < 4 and 0.9 < rec["pitched_copy"]["traffic_over_algorithmic"] < 4, name
+    assert "mix_7r2w" in res["roofline"]["yardsticks"] and res["roofline"]["yardsticks"]["mix_7r2w"]["GBs"] > 1000
+    if res["roofline"].get("traffic") is not None:
+        assert 0.05 < res["roofline"]["frac_of_streaming_ceiling"] < 1.2
     assert res["roofline"]["bound"] == "hbm" and 0 < res["roofline"]["frac"] < 1 and res["value"] > 0
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(res["cpu_baseline"]) and res["cpu_baseline"]["kind"] == "port"
     assert res["config"]["parallelism"] == "leaf-cell shards x1"

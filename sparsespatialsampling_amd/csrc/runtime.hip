@@ -438,6 +438,14 @@ static void s3_abort_backtrace_handler(int sig) {
     raise(sig);
 }
 int s3_debug_abort_backtrace(void) {
+    // installed once: a second installation would save THIS handler as the "previous" one, and the handler would then restore
+    // itself and raise again without end (SA_NODEFER) instead of reaching the default action
+    static bool installed = false;
+    if (installed) return S3_OK;
+    {   // the first backtrace() of a process may load the unwinder (dlopen of libgcc): done here, not inside the signal handler
+        void *warm[2];
+        (void)backtrace(warm, 2);
+    }
     if (const char *e = getenv("S3_ABORT_BACKTRACE"))
         if (e[0] == '/') {
             const int fd = open(e, O_WRONLY | O_CREAT | O_APPEND, 0644);
@@ -448,7 +456,9 @@ int s3_debug_abort_backtrace(void) {
     sa.sa_handler = s3_abort_backtrace_handler;
     sigemptyset(&sa.sa_mask);
     sa.sa_flags = SA_NODEFER;
-    return sigaction(SIGABRT, &sa, &s3_previous_abort_action) == 0 ? S3_OK : S3_EINVAL;
+    if (sigaction(SIGABRT, &sa, &s3_previous_abort_action) != 0) return S3_EINVAL;
+    installed = true;
+    return S3_OK;
 }
 
 int s3_abi_version(void) { return S3_ABI_VERSION; }

@@ -331,14 +331,18 @@ class SharedHostArray:
                 # (the host's identity travels with the name: a rank on another node must not look for the segment in ITS /dev/shm)
                 proposal = (name + "\n" + socket.gethostname() + "\n" + _boot_id()).encode()
             except OSError:
-                if fd is not None:
+                if fd is not None:                           # created, but not usable (ftruncate failed): the name must not stay behind
                     os.close(fd)
                     fd = None
+                    try:
+                        os.unlink(os.path.join("/dev/shm", name))
+                    except OSError:
+                        pass
                 proposal = b""
         msg = comm.broadcast_bytes(proposal).decode()
         if not msg:                                          # (decided by the root, learnt by everybody: all ranks take the same way)
             raise SharedMemoryUnavailable(f"/dev/shm cannot hold a batch buffer of {self.n_bytes} bytes")
-        name, root_host, root_boot = msg.split("\n")
+        name, root_host, root_boot = msg.split("\n", 2)
         path = os.path.join("/dev/shm", name)
         ok, self._map = True, None
         try:

@@ -326,6 +326,39 @@ def test_shift_kernel_reads_rows_off_the_line_grid(ops, orc, row_len, dtype, lay
     plan.close(); plan2.close()
 
 
+@pytest.mark.parametrize("row_len", [252, 260, 404])
+def test_default_tail_map_with_ragged_chunk_counts(ops, row_len):
+    """the DEFAULT launch form of the chunk kernels on a large plan (only the A/B switches covered it): with >= 256 tiles
+    per XCD and >= 8 chunks the last 32 tiles of every XCD's share are cut into 4 runs of chunks (tail_map) -- here with chunk
+    counts that the 4 runs do not divide (8, 9 and 13 chunks: runs of 2 / 3 / 4 with a short or empty last one) on dense rows off
+    the line grid (the shift kernel).  Same bits as the direct gather kernel; switching the tail off changes nothing."""
+    rng = np.random.default_rng(row_len)
+    n, nc, k = 260_000, 110_000, 26
+    x, c = rng.random((n, 3)), rng.random((nc, 3))
+    knn = ops.KnnIndex(x)
+    idx, dist = knn.query(c, k)
+    w = ops.idw_weights(dist)
+    knn.close()
+    table = pt.randn((n, row_len), dtype=pt.float32, device="cuda", generator=pt.Generator(device="cuda").manual_seed(row_len))
+    assert (row_len * 4) % 16 == 0 and (row_len * 4) % 128 != 0 and -(-row_len * 4 // 128) in (8, 9, 13)
+    direct = ops.interp(w, idx, table)
+    used, remap = ops.referenced_rows([idx], n, coords=x)
+    idx_c = idx.clone()
+    ops.remap_indices(idx_c, remap)
+    plan = ops.InterpPlan(idx_c, int(used.numel()), c)
+    assert plan.n_tiles >= 8 * 256                       # the default takes the tail map
+    plan.set_weights(w)
+    plan.set_source_ids(used.contiguous(), n)
+    assert pt.equal(plan.interp_src(table), direct)
+    os.environ["S3_PLAN_TAIL"] = "0"
+    try:
+        assert pt.equal(plan.interp_src(table), direct)
+    finally:
+        del os.environ["S3_PLAN_TAIL"]
+    assert pt.equal(plan.interp_src(table), direct)      # (and the switch went back with the environment)
+    plan.close()
+
+
 @pytest.mark.parametrize("n_mine,n_out,n_comp,t", [(1000, 5000, 1, 37), (333, 400, 3, 8), (64, 64, 2, 33)])
 def test_snapshot_major_rows_into_registered_host_memory(ops, n_mine, n_out, n_comp, t):
     """s3_snapshot_major_rows: a shard's [n_mine, n_comp, T] values land transposed in ITS rows of a [T, n_out, n_comp] batch

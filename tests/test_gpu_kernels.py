@@ -333,7 +333,7 @@ def test_default_tail_map_with_ragged_chunk_counts(ops, row_len):
     counts that the 4 runs do not divide (8, 9 and 13 chunks: runs of 2 / 3 / 4 with a short or empty last one) on dense rows off
     the line grid (the shift kernel).  Same bits as the direct gather kernel; switching the tail off changes nothing."""
     rng = np.random.default_rng(row_len)
-    n, nc, k = 260_000, 110_000, 26
+    n, nc, k = 300_000, 160_000, 26
     x, c = rng.random((n, 3)), rng.random((nc, 3))
     knn = ops.KnnIndex(x)
     idx, dist = knn.query(c, k)

@@ -650,7 +650,7 @@ def bench_svd(args, json_fd):
     1000 snapshots f64 resident in HBM, a step = one launch.  MFMA-bound: algorithmic flops N * T * (T + 1) (upper triangle)
     against AMD's datasheet peak for f64 matrix operations (78.6 TFLOP/s; the guide lists none) and against the rate a bare
     loop of the same instruction sustains on this pool (46 TFLOP/s, tools/mfma_f64_peak.hip).  Eigen-solve and mode GEMM of
-    compute_svd: the eigen-solve of the T x T matrix is a vendor-library call (rocSOLVER through torch), the mode GEMM is
+    compute_svd: the eigen-solve of the T x T matrix is a vendor-library call (rocSOLVER's dsyevd behind s3_sym_eig), the mode GEMM is
     s3_centered_gemm on the same matrix cores (`mode_gemm`); the whole call is timed in `compute_svd_s`, not in `value`."""
     from sparsespatialsampling_amd import svd, metrics
     n, t = 461_130, args.t_batch or 1000
@@ -685,9 +685,12 @@ def bench_svd(args, json_fd):
     pt.cuda.synchronize()
     parts["eigen_solve_ms"] = (time.perf_counter() - t1) * 1e3
     # the ONE library call of the path, said so in the line itself: the symmetric eigen-solve of the T x T Gram matrix
-    # is rocSOLVER through torch.linalg.eigh; everything else of compute_svd is this repository's kernels
+    # is rocSOLVER's dsyevd, reached through the C ABI (s3_sym_eig looks it up with dlopen; no torch operator); everything else of
+    # compute_svd is this repository's kernels
+    from sparsespatialsampling_amd import _lib as _s3lib
     parts["eigh"] = "library"
-    parts["eigh_library"] = "rocSOLVER (torch.linalg.eigh)"
+    parts["eigh_library"] = ("rocSOLVER dsyevd behind s3_sym_eig (C ABI, dlopen)" if _s3lib.hip_lib().s3_sym_eig_available()
+                             else "LAPACK on the host (torch.linalg.eigh): rocSOLVER not loadable")
     parts["eigh_share_of_compute_svd"] = parts["eigen_solve_ms"] * 1e-3 / float(np.median(steady))
     achieved = flops / (st["kernel_ms"] * 1e-3) / 1e12
     # the tall GEMMs of the same SVD on the same matrix cores (s3_centered_gemm): the mode GEMM U = (X - mean) V S^-1 at the rank

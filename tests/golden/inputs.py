@@ -390,3 +390,29 @@ def run_export_case(name, s_cube, export_cls, to_tensor, x, y):
             ex2.export(xt, to_tensor(u[:, :, a:b]), "U", n_snapshots_total=n_t)
         ex2.export(xt, to_tensor(np.ascontiguousarray(p[:, 0, :] * 2.0)), "q")          # scalar as [N, T]
     return info
+
+
+def datawriter_script(dataloader_cls, datawriter_cls, directory, src_name, dst_name):
+    """a user's script against ``data.Datawriter`` (the same calls for the reference's class and the product's): the grid copied from
+    an existing S^3 file through a loader (``write_grid`` -> the writer knows the number of cells), temporal fields under plain names
+    (the writer appends ``_center`` / ``_vertices`` by the leading size, data.py:388-391), names that carry their suffix already, an
+    int and a float time step, the warning path of a missing time step (-> ``data/0``), a duplicate (logged and skipped,
+    data.py:403-407), constants incl. a scalar, then the XDMF file"""
+    import torch as pt
+    rng = np.random.default_rng(17)
+    loader = dataloader_cls(directory, src_name)
+    n_c, n_v, d = loader.vertices.shape[0], loader.nodes.shape[0], loader.vertices.shape[1]
+    w = datawriter_cls(directory, dst_name)
+    w.write_grid(loader)
+    assert w.n_cells == n_c
+    w.write_data("levels", group="constant", data=loader.levels.unsqueeze(-1))
+    w.write_data("scale", group="constant", data=3.25)
+    w.write_data("flag", group="constant", data=pt.from_numpy(rng.integers(0, 2, n_v).astype(np.int32)))
+    for t in (0.5, 2, "10"):
+        w.write_data("p", group="data", time_step=t, data=pt.from_numpy(rng.random(n_c)))                 # -> p_center
+        w.write_data("U", group="data", time_step=t, data=pt.from_numpy(rng.random((n_v, d))))            # -> U_vertices
+        w.write_data("T_center", group="data", time_step=t, data=pt.from_numpy(rng.random((n_c, 1))))      # keeps its name
+    w.write_data("p", group="data", time_step=2, data=pt.from_numpy(rng.random(n_c)))                     # exists: skipped
+    w.write_data("q", group="data", data=pt.from_numpy(rng.random(n_c)))                                  # no time step -> data/0
+    w.write_data("k", time_step="0.5", data=pt.from_numpy(rng.random(n_c).astype(np.float32)))            # a time step alone means "data"
+    w.write_xdmf_file()

@@ -6,6 +6,7 @@ reference never leak into the test process:
 
     python ref_judge.py load <dir> <file.h5> <out.npz>        # reference Dataloader (data.py:22-300) -> everything it exposes
     python ref_judge.py xdmf <dir> <file.h5> <mixed 0|1>      # reference XDMFWriter (data.py:504-777) writes <file>.xdmf
+    python ref_judge.py write <dir> <src.h5> <dst.h5>         # reference Datawriter (data.py:303-501) through inputs.datawriter_script
 
 Contains no reference code: it calls the reference's public classes.
 """
@@ -44,5 +45,12 @@ def xdmf(directory, file_name, mixed):
     XDMFWriter(directory, file_name, mixed=bool(int(mixed))).write_xdmf()
 
 
+def write(directory, src_name, dst_name):
+    """the calls of inputs.datawriter_script on the REFERENCE's Datawriter / Dataloader"""
+    from inputs import datawriter_script
+    from sparseSpatialSampling.data import Dataloader, Datawriter
+    datawriter_script(Dataloader, Datawriter, directory, src_name, dst_name)
+
+
 if __name__ == "__main__":
-    {"load": load, "xdmf": xdmf}[sys.argv[1]](*sys.argv[2:])
+    {"load": load, "xdmf": xdmf, "write": write}[sys.argv[1]](*sys.argv[2:])

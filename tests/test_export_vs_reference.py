@@ -241,6 +241,29 @@ def test_reference_xdmf_writer_agrees_on_our_file(tmp_path, d, with_data, with_c
     assert mine == theirs
 
 
+@pytest.mark.skipif(not HAVE_REFERENCE, reason="the reference is not on this machine (GPU box)")
+def test_datawriter_script_equals_the_reference_datawriter(tmp_path):
+    """``data.Datawriter`` driven directly, the way a user's script does (inputs.datawriter_script: write_grid through a loader,
+    plain field names that get their ``_center`` / ``_vertices`` suffix, int / float / missing time steps, a duplicate, constants,
+    XDMF): the reference's class (own process, h5py = the stand-in) and this package's write the same file -- same datasets in the
+    same order, same shapes, dtypes and VALUES (nothing is computed here: bit-identical), byte-identical XDMF"""
+    import shutil
+    from inputs import datawriter_script
+    from sparsespatialsampling_amd.data import Dataloader, Datawriter
+    theirs, mine = tmp_path / "theirs", tmp_path / "mine"
+    for d in (theirs, mine):
+        d.mkdir()
+        shutil.copy(os.path.join(GOLDEN, "s_cube_test_dataset.h5"), d / "src.h5")
+    _judge("write", theirs, "src.h5", "out.h5")
+    datawriter_script(Dataloader, Datawriter, str(mine), "src.h5", "out.h5")
+    a, b = inventory(str(mine / "out.h5")), inventory(str(theirs / "out.h5"))
+    assert [p for p, _ in a] == [p for p, _ in b]
+    assert "data/0/q_center" in dict(a) and "data/0.5/k_center" in dict(a) and "data/10/U_vertices" in dict(a)
+    for (path, x), (_, y) in zip(a, b):
+        assert x.dtype == y.dtype and x.shape == y.shape and np.array_equal(x, y), path
+    assert open(mine / "out.xdmf").read() == open(theirs / "out.xdmf").read()
+
+
 def test_standin_and_native_layer_agree_on_the_reference_file():
     """the two independent bindings (tests' ctypes stand-in, product's libs3h5) list and read the reference's own data file
     (tests/s_cube_test_dataset.h5) identically"""

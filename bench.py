@@ -407,7 +407,9 @@ def yardsticks(hipops, plan, data, steps, warmup):
         ms = launch_times_ms(lambda: hipops.yard_stream(src, dst, r, w), max(steps // 2, 5), 2)
         res[key] = dict(GBs=sum(moved) / (float(np.mean(ms)) * 1e-3) / 1e9, bytes_read=moved[0], bytes_written=moved[1], **ms_stats(ms))
     del src, dst
-    if plan is not None:
+    # (the load probe models the chunk kernels: rows of at least one 128-byte line on a 16-byte aligned pitch, 64-cell tiles)
+    row_bytes = int(data.shape[1]) * data.element_size()
+    if plan is not None and row_bytes >= 128 and row_bytes % 16 == 0:
         for key, variant in (("plan_loads_one_line_per_visit", 0), ("plan_loads_two_lines_per_visit", 1)):
             staged = plan.yard_loads(data, variant)
             ms = launch_times_ms(lambda: plan.yard_loads(data, variant), steps, warmup)

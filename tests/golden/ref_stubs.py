@@ -92,6 +92,7 @@ class _Point:
 
 def install():
     """Seed ``sys.modules`` and put the reference on ``sys.path``.  Idempotent."""
+    sys.dont_write_bytecode = True       # /root/reference is read-only by contract: importing it must not leave __pycache__ behind
     if "numba" not in sys.modules:
         numba = types.ModuleType("numba")
         numba.njit = _njit

@@ -117,7 +117,14 @@ class _Node:
     """something with a file and an absolute path inside it"""
 
     def __init__(self, file, path):
-        self._file_obj, self._path = file, path
+        # (a File is its own root group: it must not hold a reference to itself -- the cycle would keep a dropped, still open File
+        # alive until the garbage collector runs, and HDF5 refuses to reopen a file read-write while a read-only handle exists; h5py's
+        # File objects close when their last reference goes, which data.py relies on for the XDMFWriter's handle)
+        self._file_ref, self._path = (None if file is self else file), path
+
+    @property
+    def _file_obj(self):
+        return self if self._file_ref is None else self._file_ref
 
     @property
     def _fid(self):

@@ -416,3 +416,42 @@ def datawriter_script(dataloader_cls, datawriter_cls, directory, src_name, dst_n
     w.write_data("q", group="data", data=pt.from_numpy(rng.random(n_c)))                                  # no time step -> data/0
     w.write_data("k", time_step="0.5", data=pt.from_numpy(rng.random(n_c).astype(np.float32)))            # a time step alone means "data"
     w.write_xdmf_file()
+
+
+def random_export_case(seed):
+    """a randomly drawn export: dimension, cloud, snapshot count, batch cuts, flags, kind of write times, scalar handed over as
+    [N, T] or [N, 1, T] -- the script both implementations run is ``run_random_export``"""
+    rng = np.random.default_rng(1000 + seed)
+    d = int(rng.integers(2, 4))
+    n_t = int(rng.integers(1, 10))
+    cuts = sorted(set(int(c) for c in rng.integers(1, n_t, size=int(rng.integers(0, 3))))) if n_t > 1 else []
+    return dict(d=d, n=int(rng.integers(900, 2200)), n_t=n_t, cuts=[0] + cuts + [n_t], vertices=bool(rng.integers(0, 2)),
+                times=["str", "float", "int"][int(rng.integers(0, 3))], flat_scalar=bool(rng.integers(0, 2)),
+                append=bool(rng.integers(0, 2)), new_file=bool(rng.integers(0, 2)), seed=int(seed),
+                uniform=int(rng.integers(2, 4)), min_metric=float(rng.uniform(0.3, 0.6)))
+
+
+def random_export_cloud(case, geometry):
+    rng = np.random.default_rng(5000 + case["seed"])
+    d = case["d"]
+    hi = [1.0, 0.6, 0.5][:d]
+    x = rng.random((case["n"], d)) * hi
+    y = wake_metric(np.concatenate([x, np.zeros((len(x), 3 - d))], 1)[:, :3] if d == 2 else x, [0.3, 0.3, 0.2][:d] + [0.0] * (3 - d), decay=4.0)
+    geos = [geometry.CubeGeometry("domain", True, [0.0] * d, hi)]
+    # (a constant six cells per refinement step: a step that selects exactly ONE cell is an IndexError in the reference, s_cube.py:883,
+    # and its ramp, s_cube.py:287-315, ends at one)
+    return x, y[:len(x)], geos, dict(uniform_levels=case["uniform"], min_metric=case["min_metric"], n_cells_iter_start=6, n_cells_iter_end=6)
+
+
+def run_random_export(case, s_cube, export_cls, to_tensor, x):
+    n_t, times = case["n_t"], export_times(case["times"], case["n_t"])
+    p, u = export_fields(x, n_t, seed=case["seed"])
+    xt = to_tensor(x)
+    ex = export_cls(s_cube, write_new_file_for_each_field=case["new_file"], interpolate_at_vertices=case["vertices"], write_times=times)
+    for a, b in zip(case["cuts"][:-1], case["cuts"][1:]):
+        piece = np.ascontiguousarray(p[:, 0, a:b]) if case["flat_scalar"] else p[:, :, a:b]
+        ex.export(xt, to_tensor(piece), "p", n_snapshots_total=n_t)
+    if case["new_file"]:
+        return                                   # (a second file is what the reference cannot write: export_2d_newfile pins that)
+    target = export_cls(s_cube, interpolate_at_vertices=case["vertices"], write_times=times, append_existing=True) if case["append"] else ex
+    target.export(xt, to_tensor(u), "U")

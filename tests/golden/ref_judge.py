@@ -7,6 +7,8 @@ reference never leak into the test process:
     python ref_judge.py load <dir> <file.h5> <out.npz>        # reference Dataloader (data.py:22-300) -> everything it exposes
     python ref_judge.py xdmf <dir> <file.h5> <mixed 0|1>      # reference XDMFWriter (data.py:504-777) writes <file>.xdmf
     python ref_judge.py write <dir> <src.h5> <dst.h5>         # reference Datawriter (data.py:303-501) through inputs.datawriter_script
+    python ref_judge.py fuzz_export <dir> <seed0> <n>         # n random exports (inputs.random_export_case) by the REAL reference,
+                                                              # grid generation included, one sub-directory per seed
 
 Contains no reference code: it calls the reference's public classes.
 """
@@ -52,5 +54,22 @@ def write(directory, src_name, dst_name):
     datawriter_script(Dataloader, Datawriter, directory, src_name, dst_name)
 
 
+def fuzz_export(directory, seed0, n):
+    import sparseSpatialSampling.geometry as ref_geometry
+    from inputs import random_export_case, random_export_cloud, run_random_export
+    from sparseSpatialSampling.export import ExportData
+    from sparseSpatialSampling.sparse_spatial_sampling import SparseSpatialSampling
+    import logging
+    logging.getLogger().setLevel(logging.ERROR)
+    for seed in range(int(seed0), int(seed0) + int(n)):
+        case = random_export_case(seed)
+        x, y, geos, kw = random_export_cloud(case, ref_geometry)
+        out = os.path.join(directory, f"seed{seed}")
+        os.makedirs(out)
+        s3 = SparseSpatialSampling(pt.from_numpy(x), pt.from_numpy(y), geos, out, "case", n_jobs=1, **kw)
+        s3.execute_grid_generation()
+        run_random_export(case, s3, ExportData, pt.from_numpy, x)
+
+
 if __name__ == "__main__":
-    {"load": load, "xdmf": xdmf, "write": write}[sys.argv[1]](*sys.argv[2:])
+    {"load": load, "xdmf": xdmf, "write": write, "fuzz_export": fuzz_export}[sys.argv[1]](*sys.argv[2:])

@@ -264,6 +264,47 @@ def test_datawriter_script_equals_the_reference_datawriter(tmp_path):
     assert open(mine / "out.xdmf").read() == open(theirs / "out.xdmf").read()
 
 
+def fuzz_export_against_reference(directory, seed0, n):
+    """n randomly drawn exports (inputs.random_export_case: dimension, cloud, batch cuts, vertices, one file per field, append, kind
+    of write times, scalar as [N, T]) run by the REAL reference in its own process -- grid generation included -- and by this
+    package's ExportData (host logic on the oracle-backed device stand-ins) on the reference's grid; returns the number compared"""
+    import sparsespatialsampling_amd.export as export
+    from inputs import random_export_case, random_export_cloud, run_random_export
+    from sparsespatialsampling_amd import geometry
+    ref_dir, my_dir = os.path.join(directory, "ref"), os.path.join(directory, "mine")
+    os.makedirs(ref_dir)
+    _judge("fuzz_export", ref_dir, seed0, n)
+    saved, export.hipops = export.hipops, _cpu_ops()
+    try:
+        for seed in range(seed0, seed0 + n):
+            case = random_export_case(seed)
+            x, y, _, _ = random_export_cloud(case, geometry)
+            theirs, mine = os.path.join(ref_dir, f"seed{seed}"), os.path.join(my_dir, f"seed{seed}")
+            os.makedirs(mine)
+            first = sorted(f for f in os.listdir(theirs) if f.endswith(".h5"))[0]
+            grid = dict(inventory(os.path.join(theirs, first)))
+            s = types.SimpleNamespace(n_dimensions=case["d"], faces=pt.from_numpy(grid["grid/faces"]), centers=pt.from_numpy(grid["grid/centers"]),
+                                      vertices=pt.from_numpy(grid["grid/vertices"]), levels=pt.from_numpy(grid["constant/levels"]),
+                                      metric=pt.from_numpy(y), size_initial_cell=float(grid["constant/size_initial_cell"]), save_path=mine,
+                                      save_name="case", grid_name="grid_s_cube")
+            run_random_export(case, s, export.ExportData, pt.from_numpy, x)
+            files = sorted(f for f in os.listdir(theirs) if f.endswith((".h5", ".xdmf")))
+            assert files == sorted(f for f in os.listdir(mine) if f.endswith((".h5", ".xdmf"))), (case, files)
+            for f in files:
+                if f.endswith(".h5"):
+                    compare_file(inventory(os.path.join(mine, f)), inventory(os.path.join(theirs, f)), f"seed {seed} {case}: {f}")
+                else:
+                    assert open(os.path.join(mine, f)).read() == open(os.path.join(theirs, f)).read(), f"seed {seed} {case}: {f}"
+    finally:
+        export.hipops = saved
+    return n
+
+
+@pytest.mark.skipif(not HAVE_REFERENCE, reason="the reference is not on this machine (GPU box)")
+def test_random_exports_equal_the_reference(tmp_path):
+    assert fuzz_export_against_reference(str(tmp_path), 0, 6) == 6
+
+
 def test_standin_and_native_layer_agree_on_the_reference_file():
     """the two independent bindings (tests' ctypes stand-in, product's libs3h5) list and read the reference's own data file
     (tests/s_cube_test_dataset.h5) identically"""

@@ -455,3 +455,27 @@ def run_random_export(case, s_cube, export_cls, to_tensor, x):
         return                                   # (a second file is what the reference cannot write: export_2d_newfile pins that)
     target = export_cls(s_cube, interpolate_at_vertices=case["vertices"], write_times=times, append_existing=True) if case["append"] else ex
     target.export(xt, to_tensor(u), "U")
+
+
+def describe_facade(s3, directory):
+    """what ``SparseSpatialSampling.execute_grid_generation()`` leaves behind, as JSON-able facts (the same function describes the
+    reference's object and the product's): public attributes (type, dtype, shape, checksum), the saved ``mesh_info_<name>.pt``
+    (keys in order, value types, the values that are not wall-clock times) and the pickled ``s_cube_<name>.pt`` loaded back"""
+    import os
+    import torch as pt
+
+    def fact(v):
+        if isinstance(v, pt.Tensor):
+            return ["tensor", str(v.dtype), list(v.shape), sha(v.detach().cpu().contiguous().numpy())]
+        if isinstance(v, (list, tuple)):
+            return [type(v).__name__, len(v), [float(e) for e in v]]
+        return [type(v).__name__, v if isinstance(v, (int, float, str, bool, type(None))) else repr(v)]
+    public = ("n_jobs", "save_path", "save_name", "grid_name", "n_dimensions", "size_initial_cell", "centers", "vertices", "faces",
+              "levels", "coordinates", "metric")
+    info = pt.load(os.path.join(directory, f"mesh_info_{s3.save_name}.pt"), weights_only=False)
+    again = pt.load(os.path.join(directory, f"s_cube_{s3.save_name}.pt"), weights_only=False)
+    return {"attributes": {k: fact(getattr(s3, k)) for k in public},
+            "mesh_info_keys": list(info), "mesh_info": {k: fact(v) for k, v in info.items() if not k.startswith("t_")},
+            "mesh_info_time_types": {k: type(v).__name__ for k, v in info.items() if k.startswith("t_")},
+            "pickled": {k: fact(getattr(again, k)) for k in public}, "sampling_dropped": getattr(again, "_sampling", "missing") is None,
+            "files": sorted(f for f in os.listdir(directory) if f.endswith(".pt"))}

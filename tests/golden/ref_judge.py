@@ -71,5 +71,17 @@ def fuzz_export(directory, seed0, n):
         run_random_export(case, s3, ExportData, pt.from_numpy, x)
 
 
+def facade(directory, case, out_json):
+    """reference SparseSpatialSampling on refine case `case` (inputs.REFINE_CASES): what execute_grid_generation leaves behind"""
+    import sparseSpatialSampling.geometry as ref_geometry
+    from inputs import describe_facade, refine_inputs
+    from sparseSpatialSampling.sparse_spatial_sampling import SparseSpatialSampling
+    x, y, geos, kw = refine_inputs(case, ref_geometry)
+    kw = {{"uniform_level": "uniform_levels", "n_cells": "n_cells_max"}.get(k, k): v for k, v in kw.items()}
+    s3 = SparseSpatialSampling(pt.from_numpy(x), pt.from_numpy(y), geos, directory, "case", n_jobs=1, **kw)
+    s3.execute_grid_generation()
+    json.dump(describe_facade(s3, directory), open(out_json, "w"))
+
+
 if __name__ == "__main__":
-    {"load": load, "xdmf": xdmf, "write": write, "fuzz_export": fuzz_export}[sys.argv[1]](*sys.argv[2:])
+    {"load": load, "xdmf": xdmf, "write": write, "fuzz_export": fuzz_export, "facade": facade}[sys.argv[1]](*sys.argv[2:])

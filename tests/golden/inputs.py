@@ -479,3 +479,75 @@ def describe_facade(s3, directory):
             "mesh_info_time_types": {k: type(v).__name__ for k, v in info.items() if k.startswith("t_")},
             "pickled": {k: fact(getattr(again, k)) for k in public}, "sampling_dropped": getattr(again, "_sampling", "missing") is None,
             "files": sorted(f for f in os.listdir(directory) if f.endswith(".pt"))}
+
+
+def invalid_calls(geometry, s3_cls, tree_cls):
+    """[(label, thunk)]: calls the reference rejects (geometry constructors `_check_geometry`, `SparseSpatialSampling._check_input`,
+    `SamplingTree` dimension checks) and a few it accepts -- the same list is run on the reference's classes and on the product's, the
+    outcomes (exception TYPE, or "ok") are compared"""
+    import torch as pt
+    g = geometry
+    x2, m2 = pt.rand((50, 2), generator=pt.Generator().manual_seed(0)).double(), pt.ones(50, dtype=pt.float64)
+    dom2 = lambda: g.CubeGeometry("domain", True, [0, 0], [1, 1])
+    tet = [[0.1, 0.1, 0.1], [0.9, 0.1, 0.1], [0.1, 0.9, 0.1], [0.1, 0.1, 0.9]]
+    pyr = [[0.3, 0.3, 0.2], [0.7, 0.3, 0.2], [0.7, 0.7, 0.2], [0.3, 0.7, 0.2], [0.5, 0.5, 0.7]]
+    tri3 = lambda z: [(0.1, 0.1, z), (0.3, 0.1, z), (0.1, 0.35, z)]
+    calls = [
+        ("cube ok", lambda: g.CubeGeometry("c", False, [0, 0], [1, 1])),
+        ("cube empty name", lambda: g.CubeGeometry("", False, [0, 0], [1, 1])),
+        ("cube keep_inside not bool", lambda: g.CubeGeometry("c", 1, [0, 0], [1, 1])),
+        ("cube empty lower", lambda: g.CubeGeometry("c", False, [], [1, 1])),
+        ("cube empty upper", lambda: g.CubeGeometry("c", False, [0, 0], [])),
+        ("cube bounds of different length", lambda: g.CubeGeometry("c", False, [0, 0], [1, 1, 1])),
+        ("cube lower >= upper", lambda: g.CubeGeometry("c", False, [0, 1], [1, 1])),
+        ("cube min_refinement_level 0", lambda: g.CubeGeometry("c", False, [0, 0], [1, 1], refine=True, min_refinement_level=0)),
+        ("sphere ok", lambda: g.SphereGeometry("s", False, [0.5, 0.5], 0.1)),
+        ("sphere empty position", lambda: g.SphereGeometry("s", False, [], 0.1)),
+        ("sphere radius 0", lambda: g.SphereGeometry("s", False, [0.5, 0.5], 0.0)),
+        ("sphere radius list", lambda: g.SphereGeometry("s", False, [0.5, 0.5], [0.1])),
+        ("cylinder ok", lambda: g.CylinderGeometry3D("c", False, [(0, 0, 0), (0, 0, 1)], 0.1)),
+        ("cone ok", lambda: g.CylinderGeometry3D("c", False, [(0, 0, 0), (0, 0, 1)], [0.2, 0.0])),
+        ("cylinder empty position", lambda: g.CylinderGeometry3D("c", False, [], 0.1)),
+        ("cylinder one position", lambda: g.CylinderGeometry3D("c", False, [(0, 0, 0)], 0.1)),
+        ("cylinder zero length", lambda: g.CylinderGeometry3D("c", False, [(0, 0, 0), (0, 0, 0)], 0.1)),
+        ("cylinder radius str", lambda: g.CylinderGeometry3D("c", False, [(0, 0, 0), (0, 0, 1)], "1")),
+        ("cylinder radius 0", lambda: g.CylinderGeometry3D("c", False, [(0, 0, 0), (0, 0, 1)], 0)),
+        ("cylinder three radii", lambda: g.CylinderGeometry3D("c", False, [(0, 0, 0), (0, 0, 1)], [0.1, 0.2, 0.3])),
+        ("cylinder negative radius", lambda: g.CylinderGeometry3D("c", False, [(0, 0, 0), (0, 0, 1)], [0.1, -0.2])),
+        ("cylinder both radii 0", lambda: g.CylinderGeometry3D("c", False, [(0, 0, 0), (0, 0, 1)], [0.0, 0.0])),
+        ("triangle ok", lambda: g.TriangleGeometry("t", False, [(0.3, 0.1), (0.6, 0.2), (0.3, 0.3)])),
+        ("triangle two points", lambda: g.TriangleGeometry("t", False, [(0.3, 0.1), (0.6, 0.2)])),
+        ("triangle 3-d points", lambda: g.TriangleGeometry("t", False, [(0.3, 0.1, 0), (0.6, 0.2, 0), (0.3, 0.3, 0)])),
+        ("triangle zero area", lambda: g.TriangleGeometry("t", False, [(0.1, 0.1), (0.2, 0.2), (0.3, 0.3)])),
+        ("triangle points str", lambda: g.TriangleGeometry("t", False, "abc")),
+        ("prism ok", lambda: g.PrismGeometry3D("p", False, [tri3(0.1), tri3(0.4)])),
+        ("prism empty", lambda: g.PrismGeometry3D("p", False, [])),
+        ("prism one triangle", lambda: g.PrismGeometry3D("p", False, [tri3(0.1)])),
+        ("prism triangle of two points", lambda: g.PrismGeometry3D("p", False, [tri3(0.1)[:2], tri3(0.4)[:2]])),
+        ("tetrahedron ok", lambda: g.TetrahedronGeometry3D("t", False, tet)),
+        ("tetrahedron three points", lambda: g.TetrahedronGeometry3D("t", False, tet[:3])),
+        ("tetrahedron 2-d points", lambda: g.TetrahedronGeometry3D("t", False, [p[:2] for p in tet])),
+        ("tetrahedron flat", lambda: g.TetrahedronGeometry3D("t", False, [[0, 0, 0], [1, 0, 0], [0, 1, 0], [1, 1, 0]])),
+        ("tetrahedron empty", lambda: g.TetrahedronGeometry3D("t", False, [])),
+        ("pyramid ok", lambda: g.PyramidGeometry3D("p", False, pyr)),
+        ("pyramid four vertices", lambda: g.PyramidGeometry3D("p", False, pyr[:4])),
+        ("pyramid vertex of two components", lambda: g.PyramidGeometry3D("p", False, [v[:2] for v in pyr])),
+        ("facade metric 2-d", lambda: s3_cls(x2, m2.reshape(-1, 1), [dom2()], "/tmp", "x")),
+        ("facade no geometries", lambda: s3_cls(x2, m2, [], "/tmp", "x")),
+        ("facade no domain", lambda: s3_cls(x2, m2, [g.SphereGeometry("s", False, [0.5, 0.5], 0.1)], "/tmp", "x")),
+        ("facade ok", lambda: s3_cls(x2, m2, [dom2()], "/tmp", "x", uniform_levels=0, min_metric=1.5)),
+        ("tree geometry of another dimension", lambda: tree_cls(x2, m2, [dom2(), g.SphereGeometry("s", False, [0.5, 0.5, 0.5], 0.1)])),
+        ("tree no domain", lambda: tree_cls(x2, m2, [g.SphereGeometry("s", False, [0.5, 0.5], 0.1)])),
+    ]
+    return calls
+
+
+def outcomes_of(calls):
+    out = {}
+    for label, thunk in calls:
+        try:
+            thunk()
+            out[label] = "ok"
+        except BaseException as err:                 # noqa: BLE001 -- the TYPE is what is compared
+            out[label] = type(err).__name__
+    return out

@@ -83,5 +83,14 @@ def facade(directory, case, out_json):
     json.dump(describe_facade(s3, directory), open(out_json, "w"))
 
 
+def errors(out_json):
+    """outcome (exception type or "ok") of every call of inputs.invalid_calls on the REFERENCE's classes"""
+    import sparseSpatialSampling.geometry as ref_geometry
+    from inputs import invalid_calls, outcomes_of
+    from sparseSpatialSampling.s_cube import SamplingTree
+    from sparseSpatialSampling.sparse_spatial_sampling import SparseSpatialSampling
+    json.dump(outcomes_of(invalid_calls(ref_geometry, SparseSpatialSampling, SamplingTree)), open(out_json, "w"))
+
+
 if __name__ == "__main__":
-    {"load": load, "xdmf": xdmf, "write": write, "fuzz_export": fuzz_export, "facade": facade}[sys.argv[1]](*sys.argv[2:])
+    {"load": load, "xdmf": xdmf, "write": write, "fuzz_export": fuzz_export, "facade": facade, "errors": errors}[sys.argv[1]](*sys.argv[2:])

@@ -117,3 +117,28 @@ def test_facade_side_effects_equal_the_reference(tmp_path, monkeypatch):
         metric_g, metric_w = got["mesh_info"].pop("metric_per_iter"), want["mesh_info"].pop("metric_per_iter")
         assert metric_g[:2] == metric_w[:2] and np.allclose(metric_g[2], metric_w[2], rtol=1e-12, atol=0)     # (summation order)
         assert got == want, {k: (got[k], want[k]) for k in got if got[k] != want[k]}
+
+
+def test_invalid_input_outcomes_equal_the_reference(tmp_path, monkeypatch):
+    """the error conventions of the boundary: 45 calls -- every `_check_geometry` assertion of every body type, the
+    facade's `_check_input`, the tree's dimension / domain checks, and valid calls in between -- give the same outcome (exception
+    TYPE, or none) on this package as on the reference's classes (own process, development container only)"""
+    import json
+    import pytest
+    if not os.path.isdir("/root/reference/sparseSpatialSampling"):
+        pytest.skip("the reference is not on this machine (GPU box)")
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden")) if os.path.join(ROOT, "tests", "golden") not in sys.path else None
+    import sparsespatialsampling_amd.s_cube as s_cube
+    from inputs import invalid_calls, outcomes_of
+    from sparsespatialsampling_amd import geometry
+    from sparsespatialsampling_amd.sparse_spatial_sampling import SparseSpatialSampling
+    from tests.oracle_backend import OracleTreeBackend
+    monkeypatch.setattr(s_cube, "_make_backend", lambda v, t, k: OracleTreeBackend(v, t, k))
+    out = str(tmp_path / "ref.json")
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "golden", "ref_judge.py"), "errors", out], capture_output=True,
+                         text=True, timeout=600, env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1"))
+    assert run.returncode == 0, run.stderr[-3000:]
+    want = json.load(open(out))
+    got = outcomes_of(invalid_calls(geometry, SparseSpatialSampling, s_cube.SamplingTree))
+    assert len(want) >= 45 and sum(v != "ok" for v in want.values()) >= 30          # the list does exercise the checks
+    assert got == want, {k: (got[k], want[k]) for k in want if got.get(k) != want[k]}

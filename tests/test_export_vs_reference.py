@@ -125,6 +125,34 @@ def test_export_matches_reference_files_host_logic(export_mod, tmp_path, tag):
     check_case(tag, str(tmp_path), info)
 
 
+def test_a_new_save_name_starts_a_complete_file(export_mod, tmp_path):
+    """``ExportData.save_name`` / ``save_dir`` are settable so that the next export starts a new file (export.py:363-401).  In the
+    reference that export ends in the ``TypeError`` of the one-file-per-field case (the constants were set to ``None`` after the first
+    file); here the new file is complete: the first file's grid and constants bit for bit, its own field, its own XDMF."""
+    from sparsespatialsampling_amd import geometry
+    tag = "export_2d_batches"
+    x, y, _, _ = refine_inputs(EXPORT_CASES[tag]["refine"], geometry)
+    s = scube_from_fixture(tag, tmp_path, y)
+    p, u = export_fields(x, 3, seed=5)
+    ex = export_mod.ExportData(s, write_times=["0.1", "0.2", "0.3"])
+    ex.export(pt.from_numpy(x), pt.from_numpy(p), "p")
+    ex.save_name = "renamed"
+    other = tmp_path / "elsewhere"
+    ex.export(pt.from_numpy(x), pt.from_numpy(u), "U")
+    ex.save_dir = str(other)
+    ex.export(pt.from_numpy(x), pt.from_numpy(p), "p")
+    first, second, third = (dict(inventory(str(f))) for f in (tmp_path / "case.h5", tmp_path / "renamed.h5", other / "renamed.h5"))
+    shared = [k for k in first if not k.startswith("data/")]
+    assert sorted(shared) == ["constant/levels", "constant/metric", "constant/size_initial_cell", "grid/centers", "grid/faces", "grid/vertices"]
+    for later in (second, third):
+        assert [k for k in later if not k.startswith("data/")] == shared
+        for k in shared:
+            assert np.array_equal(later[k], first[k]), k
+    assert sorted(k for k in second if k.startswith("data/")) == [f"data/{t}/U_center" for t in ("0.1", "0.2", "0.3")]
+    assert all(np.array_equal(third[f"data/{t}/p_center"], first[f"data/{t}/p_center"]) for t in ("0.1", "0.2", "0.3"))
+    assert "renamed.h5:/data/0.2/U_center" in open(tmp_path / "renamed.xdmf").read() and (other / "renamed.xdmf").exists()
+
+
 @pytest.mark.parametrize("tag", ["export_2d_batches", "export_3d_vertices"])
 def test_export_matches_reference_files_on_the_h5py_backend(export_mod, tmp_path, monkeypatch, tag):
     """the package's OTHER HDF5 backend -- ``h5io.H5pyFile``, taken where libs3h5.so cannot be loaded -- had never run (h5py is not

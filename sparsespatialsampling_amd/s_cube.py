@@ -938,17 +938,18 @@ class SamplingTree(object):
             logger.info("Selecting max. number of cells as stopping criterion.")
         else:
             logger.info("Selecting min. approximation of the metric as stopping criterion.")
-        shown = {"pre_select": self._pre_select, "n_jobs": self._n_jobs, "max_delta_level": self._max_delta_level,
-                 "geometry": [g.name for g in self._geometry], "min_level": self._min_level,
-                 "cells_per_iter_start": self._cells_per_iter_start, "cells_per_iter_end": self._cells_per_iter_end,
-                 "reach_at_least": self._reach_at_least, "n_dimensions": self._n_dimensions,
-                 "n_cells_orig": self._n_cells_orig, "relTol": self._relTol, "backend": "MI355X / libs3hip.so"}
-        if self._n_cells_max is not None:
-            shown["n_cells_max"] = self._n_cells_max
-        else:
-            shown["min_metric"] = self._min_metric
-        width = max(len(k) for k in shown)
-        logger.info("\n".join(["\n\tSelected settings:"] + [f"\t\t{k:<{width}}:\t{v}" for k, v in shown.items()]))
+        # the reference lists its instance dictionary in creation order (s_cube.py:1669-1692: the stopping criterion in use after the
+        # geometry, names padded to the longest ATTRIBUTE name, i.e. one more than the longest shown name); the same lines here, and the
+        # backend as an extra last line
+        criterion = ("n_cells_max", self._n_cells_max) if self._n_cells_max is not None else ("min_metric", self._min_metric)
+        shown = [("pre_select", self._pre_select), ("n_jobs", self._n_jobs), ("max_delta_level", self._max_delta_level),
+                 ("geometry", [g.name for g in self._geometry]), criterion, ("min_level", self._min_level),
+                 ("cells_per_iter_start", self._cells_per_iter_start), ("cells_per_iter_end", self._cells_per_iter_end),
+                 ("cells_per_iter", self._cells_per_iter), ("cells_per_iter_last", self._cells_per_iter_last),
+                 ("reach_at_least", self._reach_at_least), ("n_dimensions", self._n_dimensions), ("n_cells_orig", self._n_cells_orig),
+                 ("relTol", self._relTol), ("backend", "MI355X / libs3hip.so")]
+        width = max(len(k) for k, _ in shown) + 1
+        logger.info("\n".join(["\n\tSelected settings:"] + [f"\t\t{k:<{width}}:\t{v}" for k, v in shown]))
 
 
 def _directions(n_dims: int) -> np.ndarray:

@@ -551,3 +551,33 @@ def outcomes_of(calls):
         except BaseException as err:                 # noqa: BLE001 -- the TYPE is what is compared
             out[label] = type(err).__name__
     return out
+
+
+def logged_run(geometry, s3_cls, export_cls, directory):
+    """a small grid generation + export (scalar handed over as [N, T] in two batches, then a vector field; write times set late) with
+    every ``logging`` record captured: [(level, message)] -- run on the reference's classes and on the product's"""
+    import logging
+    import torch as pt
+    records = []
+
+    class Capture(logging.Handler):
+        def emit(self, r):
+            records.append([r.levelname, r.getMessage()])
+    root = logging.getLogger()
+    saved, level = root.handlers[:], root.level
+    root.handlers, _ = [Capture()], root.setLevel(logging.INFO)
+    try:
+        x, y, geos, kw = refine_inputs("refine_2d_metric", geometry)
+        kw = {{"uniform_level": "uniform_levels", "n_cells": "n_cells_max"}.get(k, k): v for k, v in kw.items()}
+        s3 = s3_cls(pt.from_numpy(x), pt.from_numpy(y), geos, directory, "case", n_jobs=1, **kw)
+        s3.execute_grid_generation()
+        p, u = export_fields(x, 4, 1)
+        ex = export_cls(s3)
+        ex.write_times = ["0", "1", "2", "3"]
+        ex.export(pt.from_numpy(x), pt.from_numpy(np.ascontiguousarray(p[:, 0, :2])), "p", n_snapshots_total=4)
+        ex.export(pt.from_numpy(x), pt.from_numpy(p[:, :, 2:]), "p", n_snapshots_total=4)
+        ex.export(pt.from_numpy(x), pt.from_numpy(u), "U")
+    finally:
+        root.handlers = saved
+        root.setLevel(level)
+    return records

@@ -92,5 +92,15 @@ def errors(out_json):
     json.dump(outcomes_of(invalid_calls(ref_geometry, SparseSpatialSampling, SamplingTree)), open(out_json, "w"))
 
 
+def logs(directory, out_json):
+    """every logging record of inputs.logged_run on the REFERENCE's classes"""
+    import sparseSpatialSampling.geometry as ref_geometry
+    from inputs import logged_run
+    from sparseSpatialSampling.export import ExportData
+    from sparseSpatialSampling.sparse_spatial_sampling import SparseSpatialSampling
+    json.dump(logged_run(ref_geometry, SparseSpatialSampling, ExportData, directory), open(out_json, "w"))
+
+
 if __name__ == "__main__":
-    {"load": load, "xdmf": xdmf, "write": write, "fuzz_export": fuzz_export, "facade": facade, "errors": errors}[sys.argv[1]](*sys.argv[2:])
+    {"load": load, "xdmf": xdmf, "write": write, "fuzz_export": fuzz_export, "facade": facade, "errors": errors,
+     "logs": logs}[sys.argv[1]](*sys.argv[2:])

@@ -142,3 +142,38 @@ def test_invalid_input_outcomes_equal_the_reference(tmp_path, monkeypatch):
     got = outcomes_of(invalid_calls(geometry, SparseSpatialSampling, s_cube.SamplingTree))
     assert len(want) >= 45 and sum(v != "ok" for v in want.values()) >= 30          # the list does exercise the checks
     assert got == want, {k: (got[k], want[k]) for k in want if got.get(k) != want[k]}
+
+
+def test_log_lines_equal_the_reference(tmp_path, monkeypatch):
+    """the ``logging`` output a script sees -- the settings block, the progress line of every refinement iteration,
+    the mesh summary, the warnings and progress lines of an export -- is the reference's, record by record (levels equal, messages
+    equal with numbers masked: wall-clock times differ).  This build adds two things, both removed before comparing: the ``backend``
+    line at the end of the settings block and one INFO line about the referenced source rows."""
+    import json
+    import re
+    import pytest
+    if not os.path.isdir("/root/reference/sparseSpatialSampling"):
+        pytest.skip("the reference is not on this machine (GPU box)")
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden")) if os.path.join(ROOT, "tests", "golden") not in sys.path else None
+    import sparsespatialsampling_amd.export as export
+    import sparsespatialsampling_amd.s_cube as s_cube
+    from inputs import logged_run
+    from sparsespatialsampling_amd import geometry
+    from sparsespatialsampling_amd.sparse_spatial_sampling import SparseSpatialSampling
+    from tests.oracle_backend import OracleTreeBackend
+    from tests.test_export_host_logic import _cpu_ops
+    monkeypatch.setattr(s_cube, "_make_backend", lambda v, t, k: OracleTreeBackend(v, t, k))
+    monkeypatch.setattr(export, "hipops", _cpu_ops())
+    (tmp_path / "ref").mkdir(); (tmp_path / "mine").mkdir()
+    out = str(tmp_path / "ref.json")
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "golden", "ref_judge.py"), "logs", str(tmp_path / "ref"), out],
+                         capture_output=True, text=True, timeout=600, env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1"))
+    assert run.returncode == 0, run.stderr[-3000:]
+    want = json.load(open(out))
+    got = logged_run(geometry, SparseSpatialSampling, export.ExportData, str(tmp_path / "mine"))
+    got = [[lv, "\n".join(ln for ln in msg.split("\n") if not ln.startswith("\t\tbackend "))] for lv, msg in got
+           if "only those are uploaded per batch" not in msg]
+    mask = lambda m: re.sub(r"\d+\.?\d*(e-?\d+)?", "#", m)
+    assert len(want) > 80 and len(got) == len(want), (len(got), len(want))
+    for i, ((lg, mg), (lw, mw)) in enumerate(zip(got, want)):
+        assert lg == lw and mask(mg) == mask(mw), (i, lg, mg, lw, mw)
